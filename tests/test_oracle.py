@@ -1,0 +1,168 @@
+"""CPU tests of the oracle itself: the C restatement (oracle/sgr_oracle.c) against an independent
+float64 torch.autograd restatement (tests/torch_ref.py) on tiny scenes, plus structural invariants of
+the binning stage.  No GPU needed."""
+import numpy as np
+import pytest
+import torch
+
+import torch_ref as tr
+from helpers import oracle_kwargs, small_case
+from oracle import oracle
+from street_gaussians_amd import synthetic as syn
+
+
+def _d(t):
+    return t.double().clone().requires_grad_(True)
+
+
+CASES = {
+    # name: (scene kwargs, options)
+    "sparse_sh3": (dict(P=80, S=2), dict()),
+    "dense_saturating": (dict(P=300, S=0, scale_px=0.03, zmax=6.0), dict()),
+    "offscreen_tanclamp": (dict(P=120, S=1, scale_px=0.02), dict(margin=1.6)),
+    "neg_colors_clamped": (dict(P=100, S=0, scale_px=0.01), dict(neg_dc=True)),
+    "white_bg_deg1": (dict(P=100, S=3, scale_px=0.01), dict(bg=[1.0, 1.0, 1.0], deg=1)),
+    "precomp": (dict(P=100, S=2, scale_px=0.01), dict(precomp=True)),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_matches_float64_autograd(name):
+    skw, opt = CASES[name]
+    cam, sc = small_case(**skw)
+    if "margin" in opt:
+        sc = syn.make_scene(skw["P"], cam, S=skw["S"], margin=opt["margin"], zmin=1.0, zmax=20.0,
+                            scale_px=skw.get("scale_px", 0.004))
+    if opt.get("neg_dc"):
+        sc.shs[:, 0, :] -= 1.2
+    # boost opacity for the saturating case so that `done` triggers
+    if name == "dense_saturating":
+        sc.opacities.fill_(0.95)
+    deg = opt.get("deg", 3)
+    bg = torch.tensor(opt.get("bg", [0.3, 0.1, 0.7]))
+    S = sc.semantics.shape[1]
+    W, H = cam.image_width, cam.image_height
+
+    m3, s, q, o, sh, sem = map(_d, (sc.means3D, sc.scales, sc.rotations, sc.opacities, sc.shs, sc.semantics))
+    colors = cov6 = None
+    if opt.get("precomp"):
+        g = torch.Generator().manual_seed(5)
+        colors = torch.rand(sc.P, 3, generator=g)
+        Sig = tr.cov3d_from_scale_rot(sc.scales.double(), sc.rotations.double(), 1.0)
+        cov6 = torch.stack([Sig[:, 0, 0], Sig[:, 0, 1], Sig[:, 0, 2], Sig[:, 1, 1], Sig[:, 1, 2], Sig[:, 2, 2]],
+                           -1).float()
+        kw = oracle_kwargs(cam, sc, deg=deg, bg=bg, use_sh=False, colors=colors, use_cov_precomp=True, cov3D=cov6)
+        colors_d, cov6_d = _d(colors), _d(cov6)
+        pre = tr.preprocess(m3, cam.viewmatrix, cam.projmatrix, cam.campos, cam.tanfovx, cam.tanfovy, W, H, deg, o,
+                            colors_precomp=colors_d, cov3D_precomp=cov6_d)
+    else:
+        kw = oracle_kwargs(cam, sc, deg=deg, bg=bg)
+        pre = tr.preprocess(m3, cam.viewmatrix, cam.projmatrix, cam.campos, cam.tanfovx, cam.tanfovy, W, H, deg, o,
+                            shs=sh, scales=s, rotations=q)
+    fw = oracle.forward(**kw)
+    vis = fw.radii > 0
+    assert vis.sum() > 10
+    if name == "neg_colors_clamped":
+        assert fw.clamped.sum() > 0
+    # forward intermediates
+    for n, a, b, tol in [("depth", pre["depth"], fw.depths, 1e-5), ("pix", pre["pix"], fw.means2D, 1e-4),
+                         ("conic", pre["conic"], fw.conic_opacity[:, :3], 2e-3)]:
+        a = a.detach().numpy()[vis]
+        assert np.abs(a - b[vis]).max() <= tol * max(1.0, np.abs(a).max()), n
+    if not opt.get("precomp"):
+        assert np.abs(pre["rgb"].detach().numpy()[vis] - fw.rgb[vis]).max() < 1e-5
+    # radius: float32 vs float64 may differ by one on exact boundaries
+    assert (np.abs(pre["radius"].detach().numpy()[vis] - fw.radii[vis]) <= 1).all()
+
+    pl = torch.from_numpy(fw.point_list.astype(np.int64))
+    col, dep, alp, se, nc = tr.render(pre, pl, fw.ranges, W, H, bg, sem if S else None)
+    assert np.abs(col.detach().numpy() - fw.color).max() < 2e-5
+    assert np.abs(dep.detach().numpy() - fw.depth).max() < 2e-4
+    assert np.abs(alp.detach().numpy() - fw.alpha).max() < 2e-5
+    if S:
+        assert np.abs(se.detach().numpy() - fw.semantic).max() < 5e-5
+    assert (nc.numpy() != fw.n_contrib).mean() < 0.01
+    if name == "dense_saturating":
+        assert fw.alpha.max() > 0.999  # early termination exercised
+
+    w = syn.loss_weights(cam, S=S)
+    loss = (col * w["color"].double()).sum() + (dep * w["depth"].double()).sum() + (alp * w["alpha"].double()).sum()
+    if S:
+        loss = loss + (se * w["semantic"].double()).sum()
+    pre["pix"].retain_grad()
+    loss.backward()
+    g = oracle.backward(fw, w["color"], w["depth"], w["alpha"], w["semantic"])
+    pairs = [("means3D", m3.grad, g["means3D"]), ("opacity", o.grad, g["opacity"])]
+    if opt.get("precomp"):
+        pairs += [("colors", colors_d.grad, g["colors"]), ("cov3D", cov6_d.grad, g["cov3D"])]
+    else:
+        pairs += [("scales", s.grad, g["scales"]), ("rotations", q.grad, g["rotations"]), ("sh", sh.grad, g["sh"])]
+    if S:
+        pairs.append(("semantics", sem.grad, g["semantics"]))
+    # the saturating case recovers T by repeated division by (1-alpha)=0.01 in float32
+    # (backward.cu:547): inherent fp32 noise of the reference algorithm, not an oracle defect
+    gtol = 3e-3 if name == "dense_saturating" else 3e-4
+    for n, a, b in pairs:
+        a = a.numpy().reshape(b.shape)
+        assert np.abs(a - b).max() <= gtol * np.abs(a).max() + 1e-9, f"{n}: {np.abs(a - b).max()} vs {np.abs(a).max()}"
+    pg = pre["pix"].grad.numpy()
+    sc2 = np.abs(g["means2D"][:, :2]).max()
+    assert np.abs(pg[:, 0] * 0.5 * W - g["means2D"][:, 0]).max() <= gtol * sc2
+    assert np.abs(pg[:, 1] * 0.5 * H - g["means2D"][:, 1]).max() <= gtol * sc2
+    fw.free()
+
+
+def test_binning_invariants():
+    cam, sc = small_case(P=2000, W=100, H=70, S=0, scale_px=0.01)
+    fw = oracle.forward(**oracle_kwargs(cam, sc))
+    R = fw.num_rendered
+    assert R == fw.tiles_touched.sum() == fw.point_offsets[-1]
+    assert (np.diff(fw.keys.astype(np.uint64)) >= 0).all()            # sorted
+    # stable: ties (same tile, same depth bits) keep ascending Gaussian index
+    same = np.diff(fw.keys.astype(np.uint64)) == 0
+    assert (np.diff(fw.point_list.astype(np.int64))[same] > 0).all()
+    tiles = (fw.keys >> np.uint64(32)).astype(np.int64)
+    for t in range(fw.ranges.shape[0]):
+        a, b = fw.ranges[t]
+        assert (tiles[a:b] == t).all()
+        assert b - a == (tiles == t).sum()
+    assert oracle.get_higher_msb(9600) == 14 and oracle.get_higher_msb(256) == 9
+
+
+def test_empty_and_all_culled():
+    cam, sc = small_case(P=50)
+    kw = oracle_kwargs(cam, sc)
+    kw0 = dict(kw)
+    for k in ("means3D", "opacities", "shs", "scales", "rotations", "semantics"):
+        kw0[k] = kw[k][:0]
+    fw = oracle.forward(**kw0)
+    assert fw.num_rendered == 0 and fw.color.shape == (3, cam.image_height, cam.image_width)
+    kwb = dict(kw)
+    kwb["means3D"] = sc.means3D * torch.tensor([1.0, 1.0, -1.0])  # behind the camera
+    fw = oracle.forward(**kwb)
+    assert fw.num_rendered == 0 and (fw.radii == 0).all() and fw.color.max() == 0.0
+
+
+def test_visible_filter_and_mark_visible_agree_with_forward():
+    cam, sc = small_case(P=500, W=100, H=70, S=0, scale_px=0.01)
+    kw = oracle_kwargs(cam, sc)
+    fw = oracle.forward(**kw)
+    radii, m2d = oracle.visible_filter(means3D=sc.means3D, viewmatrix=cam.viewmatrix, projmatrix=cam.projmatrix,
+                                       tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, image_height=cam.image_height,
+                                       image_width=cam.image_width, scales=sc.scales, rotations=sc.rotations)
+    assert (radii == fw.radii).all()
+    vis = radii > 0
+    assert (m2d[vis] == fw.means2D[vis]).all()
+    mv = oracle.mark_visible(sc.means3D, cam.viewmatrix, cam.projmatrix)
+    t = (torch.cat([sc.means3D, torch.ones(sc.P, 1)], 1) @ cam.viewmatrix)[:, 2].numpy()
+    assert (mv == (t > 0.2)).mean() > 0.999
+
+
+def test_knn_matches_bruteforce():
+    g = torch.Generator().manual_seed(3)
+    pts = torch.rand(3000, 3, generator=g) * torch.tensor([10.0, 4.0, 7.0]) - 2.0
+    d = oracle.dist2(pts)
+    D = torch.cdist(pts.double(), pts.double()) ** 2
+    D.fill_diagonal_(float("inf"))
+    ref = D.topk(3, largest=False).values.mean(1).numpy()
+    assert np.abs(d - ref).max() <= 1e-4 * ref.max()
