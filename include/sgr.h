@@ -1,0 +1,111 @@
+/*
+ * sgr.h -- C ABI of the MI355X-native differentiable Gaussian rasterizer (libsgr_hip.so).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch types.  Every entry point mirrors a
+ * native interface of the reference (zju3dv/street_gaussians); paths below are relative to
+ * /root/reference/submodules/.  All array arguments are DEVICE pointers (HIP) unless stated otherwise; a
+ * NULL pointer means "feature absent", exactly like an empty tensor does in the reference
+ * (diff-gaussian-rasterization/cuda_rasterizer/rasterizer_impl.cu:324,452,482).  `stream` is a
+ * hipStream_t (NULL = default stream); unlike the reference (legacy default stream everywhere) all
+ * work is enqueued on it.
+ *
+ * Return convention: >= 0 success, < 0 = -SGR_E_*; sgr_last_error() gives the message (thread local).
+ * INTEGRATION.md shows the binding a maintainer of the reference adds on top of this header.
+ */
+#ifndef SGR_H_INCLUDED
+#define SGR_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGR_E_INVALID 1   /* bad argument (shape / size / unsupported channel count)          */
+#define SGR_E_HIP 2       /* a HIP runtime call or kernel failed (message has hipGetErrorString) */
+#define SGR_E_ALLOC 3     /* a scratch callback returned NULL                                   */
+#define SGR_E_PREFILTER 4 /* prefiltered=1 but a Gaussian failed the frustum test
+                             (reference: device printf + __trap(), cuda_rasterizer/auxiliary.h:156-161) */
+
+/* Growable device scratch supplied by the caller: must return a device pointer to at least `nbytes`
+ * bytes that stays valid until the matching backward has run.  Replaces std::function<char*(size_t)>
+ * of CudaRasterizer::Rasterizer::forward (diff-gaussian-rasterization/cuda_rasterizer/rasterizer.h:32-34;
+ * the torch glue builds them in rasterize_points.cu:27-33). */
+typedef char* (*sgr_alloc_fn)(size_t nbytes, void* user);
+
+const char* sgr_last_error(void);
+int sgr_version(void);
+
+/* CudaRasterizer::Rasterizer::forward  (cuda_rasterizer/rasterizer.h:31-62, rasterizer_impl.cu:197-343).
+ * P Gaussians, D = active SH degree, M = SH coefficients per Gaussian (row stride of shs), S = semantic
+ * channels (<= 32).  Outputs: out_color[3,H,W], out_depth[1,H,W], out_alpha[1,H,W] (= sum alpha_i*T_i),
+ * out_semantic[S,H,W], radii[P] (may be NULL).  Every output element is written (P == 0: zeros, as the
+ * reference's torch::full(0) would leave them).  Returns num_rendered (R). */
+int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn binning_buffer, void* binning_user,
+                sgr_alloc_fn image_buffer, void* image_user, int P, int D, int M, int S, const float* background,
+                int width, int height, const float* means3D, const float* shs, const float* colors_precomp,
+                const float* semantics, const float* opacities, const float* scales, float scale_modifier,
+                const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                float* out_depth, float* out_alpha, float* out_semantic, int* radii, int debug, void* stream);
+
+/* CudaRasterizer::Rasterizer::backward  (cuda_rasterizer/rasterizer.h:64-102, rasterizer_impl.cu:396-506).
+ * geom/binning/image buffers and R are the ones forward produced.  `scratch` provides temporary device
+ * memory (R * row_stride floats) that may be released when the call returns.  All gradient outputs are
+ * fully written (no zero-initialisation needed, cf. rasterize_points.cu:166-176):
+ * dL_dmean2D[P,3] (z = sum |gx|+|gy|), dL_dopacity[P], dL_dcolor[P,3], dL_dmean3D[P,3], dL_dcov3D[P,6],
+ * dL_dsh[P,M,3] (NULL if shs NULL), dL_dscale[P,3], dL_drot[P,4], dL_dsemantic[P,S].
+ * (The reference's dL_dconic / dL_ddepth intermediates are internal here.) */
+int sgr_backward(int P, int D, int M, int R, int S, const float* background, int width, int height,
+                 const float* means3D, const float* shs, const float* colors_precomp, const float* semantics,
+                 const float* alphas, const float* scales, float scale_modifier, const float* rotations,
+                 const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+                 float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer,
+                 char* image_buffer, const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dalphas,
+                 const float* dL_dpix_semantic, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
+                 float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                 float* dL_dsemantic, sgr_alloc_fn scratch, void* scratch_user, int debug, void* stream);
+
+/* CudaRasterizer::Rasterizer::markVisible  (cuda_rasterizer/rasterizer.h:24-29, rasterizer_impl.cu:141-153).
+ * present[P] as bytes (0/1). */
+int sgr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                     void* stream);
+
+/* CudaRasterizer::Rasterizer::visible_filter  (cuda_rasterizer/rasterizer.h:104-121, rasterizer_impl.cu:345-392).
+ * radii[P], means2D[P,2]; both fully written. */
+int sgr_visible_filter(int P, int width, int height, const float* means3D, const float* scales, float scale_modifier,
+                       const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                       const float* projmatrix, float tan_fovx, float tan_fovy, int prefiltered, int* radii,
+                       float* means2D, int debug, void* stream);
+
+/* SimpleKNN::knn  (simple-knn/simple_knn.h:14-18, simple_knn.cu:185-220): mean squared distance to the three
+ * nearest neighbours of each of the P points[P,3] -> meanDists[P]. */
+int sgr_knn(int P, const float* points, float* meanDists, sgr_alloc_fn scratch, void* scratch_user, void* stream);
+
+/* ---- sizes of the opaque buffers (so a caller may pre-allocate) ------------------------------------------- */
+size_t sgr_geometry_bytes(int P);
+size_t sgr_binning_bytes(int R);
+size_t sgr_image_bytes(int width, int height);
+int sgr_partial_row_floats(int S);
+
+/* ---- introspection for parity tests: copies one internal array, densely packed, to dst (device). -------------
+ * which: 0 depths f32[P] | 1 clamped u8[3P] | 2 means2D f32[2P] | 3 cov3D f32[6P] | 4 conic_opacity f32[4P]
+ *        5 rgb f32[3P] | 6 tiles_touched u32[P] | 7 point_offsets u32[P] | 8 point_list u32[R]
+ *        9 sorted keys u64[R] | 12 ranges u32[2T] | 13 n_contrib u32[H*W] | 14 extents f32[2P]          */
+int sgr_export_internal(int which, int P, int R, int width, int height, char* geom_buffer, char* binning_buffer,
+                        char* image_buffer, void* dst, void* stream);
+
+/* ---- primitive self-tests (used by tests/ on the GPU box) ---------------------------------------------------- */
+int sgr_test_scan(const uint32_t* in, uint32_t* out, size_t n, int inclusive, uint32_t* tmp, void* stream);
+/* keys0/vals0 hold the input; returns 0 or 1 = which of (keys0,vals0)/(keys1,vals1) holds the sorted result */
+int sgr_test_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_t* vals1, uint32_t n, int end_bit,
+                  uint32_t* hist, uint32_t* scan_tmp, void* stream);
+size_t sgr_test_sort_hist_words(uint32_t n);
+size_t sgr_test_scan_tmp_words(size_t n);
+int sgr_test_wave_sum(const float* in, float* out_dpp, float* out_shfl, int nwaves, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

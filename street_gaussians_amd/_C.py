@@ -1,0 +1,218 @@
+"""Native entry points with the signatures of the reference's pybind module
+``diff_gaussian_rasterization._C`` (/root/reference/submodules/diff-gaussian-rasterization/ext.cpp:15-20,
+rasterize_points.h:18-88) and ``simple_knn._C`` (/root/reference/submodules/simple-knn/ext.cpp:15-17),
+implemented over the C ABI of libsgr_hip.so.  PyTorch is used only for device memory and the stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _native
+from ._native import ALLOC_FN, SgrError, check
+
+NUM_CHANNELS = 3  # config.h:15
+
+
+def _dev_check(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise SgrError(f"{name} must be a HIP (cuda) tensor: street_gaussians_amd has no CPU path")
+    if t.dtype != torch.float32 and t.dtype != torch.int32 and t.dtype != torch.uint8 and t.dtype != torch.bool:
+        raise SgrError(f"{name} has unsupported dtype {t.dtype}")
+
+
+def _fptr(t, name="tensor"):
+    """device pointer of a float tensor; empty tensor -> NULL ("feature absent")."""
+    if t is None or t.numel() == 0:
+        return None, None
+    _dev_check(t, name)
+    if t.dtype != torch.float32:
+        raise SgrError(f"{name} must be float32")
+    t = t.contiguous()
+    return t, C.c_void_p(t.data_ptr())
+
+
+class _Grow:
+    """Growable byte buffer handed to the C side (resizeFunctional, rasterize_points.cu:27-33)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
+        self.cb = ALLOC_FN(self._alloc)
+
+    def _alloc(self, nbytes, _user):
+        self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self.tensor.data_ptr()
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def rasterize_gaussians(background, means3D, colors, semantics, opacity, scales, rotations, scale_modifier,
+                        cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh,
+                        degree, campos, prefiltered, debug):
+    """RasterizeGaussiansCUDA (rasterize_points.cu:35-124)."""
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    _dev_check(means3D, "means3D")
+    dev = means3D.device
+    P, H, W = means3D.size(0), int(image_height), int(image_width)
+    S = semantics.size(1) if semantics is not None and semantics.ndimension() == 2 else 0
+    M = sh.size(1) if sh is not None and sh.numel() != 0 and sh.size(0) != 0 else 0
+    with torch.cuda.device(dev):
+        fopt = dict(dtype=torch.float32, device=dev)
+        out_color = torch.empty((NUM_CHANNELS, H, W), **fopt)
+        out_depth = torch.empty((1, H, W), **fopt)
+        out_alpha = torch.empty((1, H, W), **fopt)
+        out_semantic = torch.empty((S, H, W), **fopt)
+        radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+        geom, binning, img = _Grow(dev), _Grow(dev), _Grow(dev)
+        keep = []
+        def p(t, n):
+            t, ptr = _fptr(t, n)
+            keep.append(t)
+            return ptr
+        rendered = check(_native.lib().sgr_forward(
+            geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, S, p(background, "bg"), W, H,
+            p(means3D, "means3D"), p(sh, "sh"), p(colors, "colors_precomp"), p(semantics, "semantics"),
+            p(opacity, "opacities"), p(scales, "scales"), float(scale_modifier), p(rotations, "rotations"),
+            p(cov3D_precomp, "cov3D_precomp"), p(viewmatrix, "viewmatrix"), p(projmatrix, "projmatrix"),
+            p(campos, "campos"), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
+            C.c_void_p(out_color.data_ptr()), C.c_void_p(out_depth.data_ptr()), C.c_void_p(out_alpha.data_ptr()),
+            C.c_void_p(out_semantic.data_ptr()) if S else None, C.c_void_p(radii.data_ptr()) if P else None,
+            int(bool(debug)), _stream(dev)))
+    return rendered, out_color, out_depth, out_alpha, out_semantic, radii, geom.tensor, binning.tensor, img.tensor
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
+                                 dL_dout_alpha, dL_dout_semantic, sh, degree, campos, geomBuffer, R, binningBuffer,
+                                 imageBuffer, alphas, semantics, debug):
+    """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:126-220).  Returns
+    (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dsemantic)."""
+    _dev_check(means3D, "means3D")
+    dev = means3D.device
+    P = means3D.size(0)
+    H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+    S = dL_dout_semantic.size(0) if dL_dout_semantic is not None and dL_dout_semantic.numel() != 0 else 0
+    M = sh.size(1) if sh is not None and sh.numel() != 0 and sh.size(0) != 0 else 0
+    with torch.cuda.device(dev):
+        fopt = dict(dtype=torch.float32, device=dev)
+        # every element is written by the kernels (include/sgr.h), so no torch.zeros (rasterize_points.cu:166-176)
+        mk = torch.empty if P else torch.zeros
+        dL_dmeans3D = mk((P, 3), **fopt)
+        dL_dmeans2D = mk((P, 3), **fopt)
+        dL_dcolors = mk((P, NUM_CHANNELS), **fopt)
+        dL_dopacity = mk((P, 1), **fopt)
+        dL_dcov3D = mk((P, 6), **fopt)
+        dL_dsh = mk((P, M, 3), **fopt)
+        dL_dscales = mk((P, 3), **fopt)
+        dL_drotations = mk((P, 4), **fopt)
+        dL_dsemantic = mk((P, S), **fopt)
+        if P == 0:
+            return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations,
+                    dL_dsemantic)
+        scratch = _Grow(dev)
+        keep = []
+        def p(t, n):
+            t, ptr = _fptr(t, n)
+            keep.append(t)
+            return ptr
+        vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
+        check(_native.lib().sgr_backward(
+            P, int(degree), M, int(R), S, p(background, "bg"), W, H, p(means3D, "means3D"), p(sh, "sh"),
+            p(colors, "colors_precomp"), p(semantics, "semantics"), p(alphas, "alpha"), p(scales, "scales"),
+            float(scale_modifier), p(rotations, "rotations"), p(cov3D_precomp, "cov3D_precomp"),
+            p(viewmatrix, "viewmatrix"), p(projmatrix, "projmatrix"), p(campos, "campos"), float(tan_fovx),
+            float(tan_fovy), vp(radii.contiguous()), vp(geomBuffer), vp(binningBuffer), vp(imageBuffer),
+            p(dL_dout_color, "dL_dout_color"), p(dL_dout_depth, "dL_dout_depth"), p(dL_dout_alpha, "dL_dout_alpha"),
+            p(dL_dout_semantic, "dL_dout_semantic"), vp(dL_dmeans2D), vp(dL_dopacity), vp(dL_dcolors), vp(dL_dmeans3D),
+            vp(dL_dcov3D), vp(dL_dsh), vp(dL_dscales), vp(dL_drotations), vp(dL_dsemantic), scratch.cb, None,
+            int(bool(debug)), _stream(dev)))
+    return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations,
+            dL_dsemantic)
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """markVisible (rasterize_points.cu:222-241)."""
+    _dev_check(means3D, "means3D")
+    dev = means3D.device
+    P = means3D.size(0)
+    present = torch.zeros((P,), dtype=torch.bool, device=dev)
+    if P:
+        with torch.cuda.device(dev):
+            m, v, pr = means3D.contiguous(), viewmatrix.contiguous(), projmatrix.contiguous()
+            check(_native.lib().sgr_mark_visible(P, C.c_void_p(m.data_ptr()), C.c_void_p(v.data_ptr()),
+                                                 C.c_void_p(pr.data_ptr()), C.c_void_p(present.data_ptr()),
+                                                 _stream(dev)))
+    return present
+
+
+def rasterize_gaussians_filter(means3D, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
+                               tan_fovx, tan_fovy, image_height, image_width, prefiltered, debug):
+    """RasterizeGaussiansfilterCUDA (rasterize_points.cu:243-307)."""
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    _dev_check(means3D, "means3D")
+    dev = means3D.device
+    P = means3D.size(0)
+    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    means2D = torch.zeros((P, 2), dtype=torch.float32, device=dev)
+    if P:
+        with torch.cuda.device(dev):
+            keep = []
+            def p(t, n):
+                t, ptr = _fptr(t, n)
+                keep.append(t)
+                return ptr
+            check(_native.lib().sgr_visible_filter(
+                P, int(image_width), int(image_height), p(means3D, "means3D"), p(scales, "scales"),
+                float(scale_modifier), p(rotations, "rotations"), p(cov3D_precomp, "cov3D_precomp"),
+                p(viewmatrix, "viewmatrix"), p(projmatrix, "projmatrix"), float(tan_fovx), float(tan_fovy),
+                int(bool(prefiltered)), C.c_void_p(radii.data_ptr()), C.c_void_p(means2D.data_ptr()),
+                int(bool(debug)), _stream(dev)))
+    return radii, means2D
+
+
+def distCUDA2(points):
+    """distCUDA2 (simple-knn/spatial.cu:16-26)."""
+    _dev_check(points, "points")
+    dev = points.device
+    P = points.size(0)
+    means = torch.zeros((P,), dtype=torch.float32, device=dev)
+    if P:
+        with torch.cuda.device(dev):
+            pts = points.contiguous()
+            if pts.dtype != torch.float32:
+                raise SgrError("points must be float32")
+            scratch = _Grow(dev)
+            check(_native.lib().sgr_knn(P, C.c_void_p(pts.data_ptr()), C.c_void_p(means.data_ptr()), scratch.cb, None,
+                                        _stream(dev)))
+            torch.cuda.current_stream(dev).synchronize()  # scratch must outlive the kernels
+    return means
+
+
+_EXPORT = {"depths": (0, torch.float32, lambda P, R, N, T: (P,)), "clamped": (1, torch.uint8, lambda P, R, N, T: (P, 3)),
+           "means2D": (2, torch.float32, lambda P, R, N, T: (P, 2)), "cov3D": (3, torch.float32, lambda P, R, N, T: (P, 6)),
+           "conic_opacity": (4, torch.float32, lambda P, R, N, T: (P, 4)), "rgb": (5, torch.float32, lambda P, R, N, T: (P, 3)),
+           "tiles_touched": (6, torch.int32, lambda P, R, N, T: (P,)), "point_offsets": (7, torch.int32, lambda P, R, N, T: (P,)),
+           "point_list": (8, torch.int32, lambda P, R, N, T: (R,)), "keys": (9, torch.int64, lambda P, R, N, T: (R,)),
+           "ranges": (12, torch.int32, lambda P, R, N, T: (T, 2)), "n_contrib": (13, torch.int32, lambda P, R, N, T: (N,)),
+           "extents": (14, torch.float32, lambda P, R, N, T: (P, 2))}
+
+
+def export_internal(name, P, R, image_height, image_width, geomBuffer, binningBuffer, imageBuffer):
+    """Parity-test introspection (sgr_export_internal): dense copy of one internal array."""
+    which, dtype, shp = _EXPORT[name]
+    H, W = int(image_height), int(image_width)
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    dev = geomBuffer.device
+    out = torch.zeros(shp(P, R, H * W, T), dtype=dtype, device=dev)
+    vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
+    with torch.cuda.device(dev):
+        check(_native.lib().sgr_export_internal(which, P, R, W, H, vp(geomBuffer), vp(binningBuffer), vp(imageBuffer),
+                                                vp(out), _stream(dev)))
+        torch.cuda.current_stream(dev).synchronize()
+    return out

@@ -1,0 +1,79 @@
+"""ctypes loader of libsgr_hip.so (the C ABI declared in include/sgr.h).
+
+The product path has NO fallback: if the library is missing, or a tensor is not on a HIP device,
+this module raises -- it never routes to a CPU implementation (the oracle lives in oracle/ and is
+test infrastructure only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsgr_hip.so")
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
+
+_lib = None
+
+# every symbol include/sgr.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "sgr_last_error", "sgr_version", "sgr_forward", "sgr_backward", "sgr_mark_visible", "sgr_visible_filter",
+    "sgr_knn", "sgr_geometry_bytes", "sgr_binning_bytes", "sgr_image_bytes", "sgr_partial_row_floats",
+    "sgr_export_internal", "sgr_test_scan", "sgr_test_sort", "sgr_test_sort_hist_words", "sgr_test_scan_tmp_words",
+    "sgr_test_wave_sum",
+]
+
+
+class SgrError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SgrError(f"{LIB_PATH} not found: build it with `python -m street_gaussians_amd.build` "
+                           "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.sgr_last_error.restype = C.c_char_p
+        L.sgr_version.restype = C.c_int
+        for n in ("sgr_geometry_bytes", "sgr_binning_bytes", "sgr_test_sort_hist_words", "sgr_test_scan_tmp_words"):
+            getattr(L, n).restype = C.c_size_t
+        L.sgr_geometry_bytes.argtypes = [C.c_int]
+        L.sgr_binning_bytes.argtypes = [C.c_int]
+        L.sgr_image_bytes.restype = C.c_size_t
+        L.sgr_image_bytes.argtypes = [C.c_int, C.c_int]
+        L.sgr_test_sort_hist_words.argtypes = [C.c_uint32]
+        L.sgr_test_scan_tmp_words.argtypes = [C.c_size_t]
+        vp, f, i = C.c_void_p, C.c_float, C.c_int
+        L.sgr_forward.restype = i
+        L.sgr_forward.argtypes = [ALLOC_FN, vp, ALLOC_FN, vp, ALLOC_FN, vp, i, i, i, i, vp, i, i, vp, vp, vp, vp, vp, vp,
+                                  f, vp, vp, vp, vp, vp, f, f, i, vp, vp, vp, vp, vp, i, vp]
+        L.sgr_backward.restype = i
+        L.sgr_backward.argtypes = [i, i, i, i, i, vp, i, i, vp, vp, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, f, f, vp, vp,
+                                   vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ALLOC_FN, vp, i, vp]
+        L.sgr_mark_visible.restype = i
+        L.sgr_mark_visible.argtypes = [i, vp, vp, vp, vp, vp]
+        L.sgr_visible_filter.restype = i
+        L.sgr_visible_filter.argtypes = [i, i, i, vp, vp, f, vp, vp, vp, vp, f, f, i, vp, vp, i, vp]
+        L.sgr_knn.restype = i
+        L.sgr_knn.argtypes = [i, vp, vp, ALLOC_FN, vp, vp]
+        L.sgr_export_internal.restype = i
+        L.sgr_export_internal.argtypes = [i, i, i, i, i, vp, vp, vp, vp, vp]
+        L.sgr_test_scan.restype = i
+        L.sgr_test_scan.argtypes = [vp, vp, C.c_size_t, i, vp, vp]
+        L.sgr_test_sort.restype = i
+        L.sgr_test_sort.argtypes = [vp, vp, vp, vp, C.c_uint32, i, vp, vp, vp]
+        L.sgr_test_wave_sum.restype = i
+        L.sgr_test_wave_sum.argtypes = [vp, vp, vp, i, vp]
+        L.sgr_partial_row_floats.restype = i
+        L.sgr_partial_row_floats.argtypes = [i]
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise SgrError(lib().sgr_last_error().decode())
+    return rc

@@ -1,0 +1,407 @@
+// sgr_api.hip -- host orchestration + C ABI (include/sgr.h) of the MI355X-native rasterizer.
+// Mirrors CudaRasterizer::Rasterizer::{forward,backward,markVisible,visible_filter}
+// (/root/reference/submodules/diff-gaussian-rasterization/cuda_rasterizer/rasterizer_impl.cu:141-506).
+// No torch types; all launches go to the caller's HIP stream.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../../include/sgr.h"
+#include "sgr_math.h"
+
+// launchers implemented in the kernel translation units
+void sgr_launch_mark_visible(int P, const float* means3D, const SgrCam* cam, uint8_t* present, hipStream_t s);
+void sgr_launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, const float* rotations,
+                           const float* opacities, const float* shs, const float* cov3D_precomp,
+                           const float* colors_precomp, const SgrCam* cam, const SgrGeomView& gv, int* radii,
+                           int prefiltered, hipStream_t s);
+void sgr_launch_filter(int P, const float* means3D, const float* scales, const float* rotations,
+                       const float* cov3D_precomp, const SgrCam* cam, const SgrGeomView& gv, int* radii,
+                       float* means2D, int prefiltered, hipStream_t s);
+void sgr_launch_duplicate(int P, const SgrGeomView& gv, const int* radii, uint64_t* keys, uint32_t* vals, int gx,
+                          hipStream_t s);
+void sgr_launch_tile_ranges(int L, const uint64_t* keys, uint2* ranges, hipStream_t s);
+void sgr_launch_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, bool inclusive, hipStream_t s);
+int sgr_launch_sort_pairs(uint64_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
+                          uint32_t* scan_tmp, hipStream_t s);
+void sgr_launch_blend_fwd(bool cull, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W, int H,
+                          int S, const float4* recA, const float4* recB, const float4* recC, const float* semantics,
+                          const float* bg, float* out_color, float* out_depth, float* out_alpha, float* out_semantic,
+                          uint32_t* n_contrib, hipStream_t s);
+int sgr_partial_row_stride(int S);
+void sgr_launch_blend_bwd(bool cull, bool dpp, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
+                          int H, int S, const float* bg, const float4* recA, const float4* recB, const float4* recC,
+                          const uint2* recD, const float* semantics, const float* alphas, const uint32_t* n_contrib,
+                          const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha, const float* dL_dsem,
+                          float* partials, hipStream_t s);
+void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const int* radii, const float* shs,
+                          const float* scales, const float* rotations, const float* cov3D_precomp, const SgrCam* cam,
+                          const SgrGeomView& gv, const float* partials, int row_stride, float* dL_dmean2D,
+                          float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                          float* dL_dscale, float* dL_drot, float* dL_dsemantic, hipStream_t s);
+void sgr_launch_wave_sum_test(const float* in, float* out_dpp, float* out_shfl, int nwaves, hipStream_t s);
+int sgr_knn_impl(int P, const float* points, float* meanDists, sgr_alloc_fn scratch, void* scratch_user, hipStream_t s,
+                 std::string& err);
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return -code;
+}
+
+#define SGR_HIP(call)                                                                            \
+    do {                                                                                         \
+        hipError_t e__ = (call);                                                                 \
+        if (e__ != hipSuccess)                                                                   \
+            return fail(SGR_E_HIP, std::string(#call) + ": " + hipGetErrorString(e__));          \
+    } while (0)
+
+// reference CHECK_CUDA (auxiliary.h:166-173): with debug, synchronise after the stage and report
+#define SGR_STAGE(name)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e__ = hipGetLastError();                                                               \
+        if (e__ == hipSuccess && debug) e__ = hipStreamSynchronize(stream);                               \
+        if (e__ != hipSuccess) return fail(SGR_E_HIP, std::string("stage ") + name + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+static bool env_flag(const char* name) {
+    const char* v = getenv(name);
+    return v && v[0] && v[0] != '0';
+}
+
+// rasterizer_impl.cu:35-50
+static uint32_t getHigherMsb(uint32_t n) {
+    uint32_t msb = sizeof(n) * 4;
+    uint32_t step = msb;
+    while (step > 1) {
+        step /= 2;
+        if (n >> msb) msb += step;
+        else msb -= step;
+    }
+    if (n >> msb) msb++;
+    return msb;
+}
+
+// The camera arrives as three device arrays; a one-wave kernel packs it (plus the host-side scalars)
+// into a device-resident SgrCam so no device->host copy is needed.
+__global__ void sgr_pack_camera_kernel(SgrCam* cam, const float* view, const float* proj, const float* campos,
+                                       float tan_fovx, float tan_fovy, float focal_x, float focal_y, int W, int H,
+                                       int gx, int gy, float scale_modifier) {
+    const int t = threadIdx.x;
+    if (t < 16) {
+        cam->view[t] = view[t];
+        cam->proj[t] = proj ? proj[t] : 0.f;
+    }
+    if (t < 3) cam->campos[t] = campos ? campos[t] : 0.f;
+    if (t == 0) {
+        cam->tan_fovx = tan_fovx; cam->tan_fovy = tan_fovy;
+        cam->focal_x = focal_x; cam->focal_y = focal_y;
+        cam->W = W; cam->H = H; cam->gx = gx; cam->gy = gy;
+        cam->scale_modifier = scale_modifier;
+    }
+}
+
+// the SgrCam lives in the header block of the geometry buffer (words 16.. of the 64-word header)
+static SgrCam* cam_slot(const SgrGeomView& gv) { return reinterpret_cast<SgrCam*>(gv.header + 16); }
+static_assert(sizeof(SgrCam) <= 48 * 4, "SgrCam must fit the geometry header");
+
+static void pack_camera(const SgrGeomView& gv, const float* view, const float* proj, const float* campos,
+                        float tan_fovx, float tan_fovy, int W, int H, float scale_modifier, hipStream_t s) {
+    const float focal_y = H / (2.0f * tan_fovy);  // rasterizer_impl.cu:225-226
+    const float focal_x = W / (2.0f * tan_fovx);
+    const int gx = (W + SGR_BLOCK_X - 1) / SGR_BLOCK_X, gy = (H + SGR_BLOCK_Y - 1) / SGR_BLOCK_Y;
+    sgr_pack_camera_kernel<<<1, 64, 0, s>>>(cam_slot(gv), view, proj, campos, tan_fovx, tan_fovy, focal_x, focal_y, W, H,
+                                            gx, gy, scale_modifier);
+}
+
+extern "C" {
+
+const char* sgr_last_error(void) { return g_err.c_str(); }
+int sgr_version(void) { return 100; }
+
+size_t sgr_geometry_bytes(int P) {
+    return sgr_required([&](char* b, char** e) { sgr_geom_carve(b, (size_t)P, e); });
+}
+size_t sgr_binning_bytes(int R) {
+    return sgr_required([&](char* b, char** e) { sgr_bin_carve(b, (size_t)R, e); });
+}
+size_t sgr_image_bytes(int width, int height) {
+    const size_t T = (size_t)((width + SGR_BLOCK_X - 1) / SGR_BLOCK_X) * ((height + SGR_BLOCK_Y - 1) / SGR_BLOCK_Y);
+    return sgr_required([&](char* b, char** e) { sgr_img_carve(b, (size_t)width * height, T, e); });
+}
+int sgr_partial_row_floats(int S) { return sgr_partial_row_stride(S); }
+
+int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn binning_buffer, void* binning_user,
+                sgr_alloc_fn image_buffer, void* image_user, int P, int D, int M, int S, const float* background,
+                int width, int height, const float* means3D, const float* shs, const float* colors_precomp,
+                const float* semantics, const float* opacities, const float* scales, float scale_modifier,
+                const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                float* out_depth, float* out_alpha, float* out_semantic, int* radii, int debug, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int W = width, H = height;
+    if (P < 0 || W <= 0 || H <= 0) return fail(SGR_E_INVALID, "P, width and height must be positive");
+    const int gx = (W + SGR_BLOCK_X - 1) / SGR_BLOCK_X, gy = (H + SGR_BLOCK_Y - 1) / SGR_BLOCK_Y;
+    if (gx > SGR_MAX_GRID_DIM || gy > SGR_MAX_GRID_DIM)
+        return fail(SGR_E_INVALID, "image larger than 16368 px per side is not supported");
+    if (S < 0 || S > SGR_SEM_MAX) return fail(SGR_E_INVALID, "semantic channels must be in [0, 32]");
+    if (D < 0 || D > 3) return fail(SGR_E_INVALID, "SH degree must be in [0, 3]");
+    const size_t N = (size_t)W * H, T = (size_t)gx * gy;
+
+    if (P == 0) {  // rasterize_points.cu:86: nothing runs, outputs stay at their zero fill
+        SGR_HIP(hipMemsetAsync(out_color, 0, 3 * N * sizeof(float), stream));
+        SGR_HIP(hipMemsetAsync(out_depth, 0, N * sizeof(float), stream));
+        SGR_HIP(hipMemsetAsync(out_alpha, 0, N * sizeof(float), stream));
+        if (S) SGR_HIP(hipMemsetAsync(out_semantic, 0, (size_t)S * N * sizeof(float), stream));
+        return 0;
+    }
+    if (!means3D || !opacities || !viewmatrix || !projmatrix || !background)
+        return fail(SGR_E_INVALID, "means3D, opacities, viewmatrix, projmatrix and background are required");
+    if ((shs == nullptr) == (colors_precomp == nullptr))
+        return fail(SGR_E_INVALID, "provide exactly one of shs / colors_precomp");
+    if (((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr))
+        return fail(SGR_E_INVALID, "provide exactly one of scales+rotations / cov3D_precomp");
+    if (shs && (!cam_pos || M < (D + 1) * (D + 1))) return fail(SGR_E_INVALID, "shs need campos and M >= (D+1)^2");
+    if (S > 0 && !semantics) return fail(SGR_E_INVALID, "S > 0 but semantics is NULL");
+
+    char* gbase = geometry_buffer(sgr_geometry_bytes(P), geometry_user);
+    if (!gbase) return fail(SGR_E_ALLOC, "geometry buffer allocation failed");
+    const SgrGeomView gv = sgr_geom_carve(gbase, (size_t)P);
+    char* ibase = image_buffer(sgr_image_bytes(W, H), image_user);
+    if (!ibase) return fail(SGR_E_ALLOC, "image buffer allocation failed");
+    const SgrImgView iv = sgr_img_carve(ibase, N, T);
+    int* radii_ptr = radii ? radii : gv.internal_radii;  // rasterizer_impl.cu:232-235
+
+    SGR_HIP(hipMemsetAsync(gv.header, 0, 16 * sizeof(uint32_t), stream));
+    SGR_HIP(hipMemsetAsync(iv.ranges, 0, T * sizeof(uint2), stream));  // rasterizer_impl.cu:313
+    pack_camera(gv, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, W, H, scale_modifier, stream);
+    SGR_STAGE("pack_camera");
+
+    sgr_launch_preprocess(P, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
+                          cam_slot(gv), gv, radii_ptr, prefiltered, stream);
+    SGR_STAGE("preprocess");
+
+    // K4 + K5: inclusive scan, then read back num_rendered (+ the prefilter flag) -- the one host sync
+    sgr_launch_scan(gv.tiles_touched, gv.point_offsets, (size_t)P, gv.scan_tmp, true, stream);
+    SGR_STAGE("scan");
+    const size_t nb = ((size_t)P + SGR_SCAN_ITEMS - 1) / SGR_SCAN_ITEMS;
+    uint32_t host_vals[2] = {0, 0};
+    SGR_HIP(hipMemcpyAsync(&host_vals[0], gv.scan_tmp + nb, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    SGR_HIP(hipMemcpyAsync(&host_vals[1], gv.header, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    SGR_HIP(hipStreamSynchronize(stream));
+    if (host_vals[1] & 1u)
+        return fail(SGR_E_PREFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
+    if (host_vals[0] > 0x7fffffffu) return fail(SGR_E_INVALID, "more than 2^31 tile instances");
+    const int R = (int)host_vals[0];
+
+    char* bbase = binning_buffer(sgr_binning_bytes(R), binning_user);
+    if (!bbase) return fail(SGR_E_ALLOC, "binning buffer allocation failed");
+    const SgrBinView bv = sgr_bin_carve(bbase, (size_t)R);
+
+    int cur = 0;
+    if (R > 0) {
+        sgr_launch_duplicate(P, gv, radii_ptr, bv.keys[0], bv.vals[0], gx, stream);
+        SGR_STAGE("duplicate");
+        const int bit = (int)getHigherMsb((uint32_t)T);  // rasterizer_impl.cu:303
+        cur = sgr_launch_sort_pairs(bv.keys, bv.vals, (uint32_t)R, 32 + bit, bv.hist, bv.scan_tmp, stream);
+        SGR_STAGE("sort");
+        sgr_launch_tile_ranges(R, bv.keys[cur], iv.ranges, stream);
+        SGR_STAGE("tile_ranges");
+    }
+    const bool cull = !env_flag("SGR_NO_CULL");
+    sgr_launch_blend_fwd(cull, gx, gy, iv.ranges, bv.vals[cur], W, H, S, gv.recA, gv.recB, gv.recC, semantics,
+                         background, out_color, out_depth, out_alpha, out_semantic, iv.n_contrib, stream);
+    SGR_STAGE("blend_fwd");
+    return R;
+}
+
+// which of the two ping-pong pairs holds the sorted list: one flip per 8-bit pass
+static int sorted_index(int width, int height) {
+    const int gx = (width + SGR_BLOCK_X - 1) / SGR_BLOCK_X, gy = (height + SGR_BLOCK_Y - 1) / SGR_BLOCK_Y;
+    const int end_bit = 32 + (int)getHigherMsb((uint32_t)(gx * gy));
+    return ((end_bit + 7) / 8) & 1;
+}
+
+int sgr_backward(int P, int D, int M, int R, int S, const float* background, int width, int height,
+                 const float* means3D, const float* shs, const float* colors_precomp, const float* semantics,
+                 const float* alphas, const float* scales, float scale_modifier, const float* rotations,
+                 const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+                 float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer,
+                 char* image_buffer, const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dalphas,
+                 const float* dL_dpix_semantic, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
+                 float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                 float* dL_dsemantic, sgr_alloc_fn scratch, void* scratch_user, int debug, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)colors_precomp; (void)scale_modifier; (void)viewmatrix; (void)projmatrix; (void)campos;
+    (void)tan_fovx; (void)tan_fovy;  // already resident in the geometry buffer's camera block
+    if (P <= 0) return 0;
+    const int W = width, H = height;
+    if (S < 0 || S > SGR_SEM_MAX) return fail(SGR_E_INVALID, "semantic channels must be in [0, 32]");
+    if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer))
+        return fail(SGR_E_INVALID, "backward needs the buffers produced by forward");
+    const int gx = (W + SGR_BLOCK_X - 1) / SGR_BLOCK_X, gy = (H + SGR_BLOCK_Y - 1) / SGR_BLOCK_Y;
+    const size_t N = (size_t)W * H, T = (size_t)gx * gy;
+    const SgrGeomView gv = sgr_geom_carve(geom_buffer, (size_t)P);
+    const SgrImgView iv = sgr_img_carve(image_buffer, N, T);
+    const int* radii_ptr = radii ? radii : gv.internal_radii;
+    const int stride = sgr_partial_row_stride(S);
+    float* partials = nullptr;
+    if (R > 0) {
+        const SgrBinView bv = sgr_bin_carve(binning_buffer, (size_t)R);
+        const int cur = sorted_index(W, H);
+        const size_t bytes = (size_t)R * stride * sizeof(float);
+        partials = (float*)scratch(bytes, scratch_user);
+        if (!partials) return fail(SGR_E_ALLOC, "backward scratch allocation failed");
+        SGR_HIP(hipMemsetAsync(partials, 0, bytes, stream));
+        const bool cull = !env_flag("SGR_NO_CULL"), dpp = !env_flag("SGR_NO_DPP");
+        sgr_launch_blend_bwd(cull, dpp, gx, gy, iv.ranges, bv.vals[cur], W, H, S, background, gv.recA, gv.recB, gv.recC,
+                             gv.recD, semantics, alphas, iv.n_contrib, dL_dpix, dL_dpix_depth, dL_dalphas,
+                             dL_dpix_semantic, partials, stream);
+        SGR_STAGE("blend_bwd");
+    }
+    sgr_launch_gauss_bwd(P, D, M, S, means3D, radii_ptr, shs, scales, rotations, cov3D_precomp, cam_slot(gv), gv, partials,
+                         stride, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
+                         dL_dsemantic, stream);
+    SGR_STAGE("gauss_bwd");
+    return 0;
+}
+
+// scratch for the two small entry points below: a camera block only
+struct TmpCam {
+    SgrCam* cam = nullptr;
+    ~TmpCam() { if (cam) (void)hipFree(cam); }
+};
+
+int sgr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                     void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int debug = 0;
+    if (P <= 0) return 0;
+    TmpCam tc;
+    SGR_HIP(hipMalloc((void**)&tc.cam, sizeof(SgrCam)));
+    sgr_pack_camera_kernel<<<1, 64, 0, stream>>>(tc.cam, viewmatrix, projmatrix, nullptr, 1.f, 1.f, 1.f, 1.f, 16, 16, 1, 1,
+                                                 1.f);
+    sgr_launch_mark_visible(P, means3D, tc.cam, present, stream);
+    SGR_STAGE("mark_visible");
+    SGR_HIP(hipStreamSynchronize(stream));  // tc.cam is freed on return
+    return 0;
+}
+
+int sgr_visible_filter(int P, int width, int height, const float* means3D, const float* scales, float scale_modifier,
+                       const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                       const float* projmatrix, float tan_fovx, float tan_fovy, int prefiltered, int* radii,
+                       float* means2D, int debug, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P <= 0) return 0;
+    const int W = width, H = height;
+    const int gx = (W + SGR_BLOCK_X - 1) / SGR_BLOCK_X, gy = (H + SGR_BLOCK_Y - 1) / SGR_BLOCK_Y;
+    if (gx > SGR_MAX_GRID_DIM || gy > SGR_MAX_GRID_DIM) return fail(SGR_E_INVALID, "image too large");
+    if (((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr))
+        return fail(SGR_E_INVALID, "provide exactly one of scales+rotations / cov3D_precomp");
+    TmpCam tc;
+    SGR_HIP(hipMalloc((void**)&tc.cam, sizeof(SgrCam) + 64));
+    uint32_t* flag = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(tc.cam) + sizeof(SgrCam));
+    SGR_HIP(hipMemsetAsync(flag, 0, 4, stream));
+    const float focal_y = H / (2.0f * tan_fovy), focal_x = W / (2.0f * tan_fovx);
+    sgr_pack_camera_kernel<<<1, 64, 0, stream>>>(tc.cam, viewmatrix, projmatrix, nullptr, tan_fovx, tan_fovy, focal_x,
+                                                 focal_y, W, H, gx, gy, scale_modifier);
+    SgrGeomView gv;
+    memset(&gv, 0, sizeof(gv));
+    gv.header = flag;
+    SGR_HIP(hipMemsetAsync(means2D, 0, (size_t)P * 2 * sizeof(float), stream));  // torch::full(0), rasterize_points.cu:271
+    sgr_launch_filter(P, means3D, scales, rotations, cov3D_precomp, tc.cam, gv, radii, means2D, prefiltered, stream);
+    SGR_STAGE("filter");
+    uint32_t hflag = 0;
+    SGR_HIP(hipMemcpyAsync(&hflag, flag, 4, hipMemcpyDeviceToHost, stream));
+    SGR_HIP(hipStreamSynchronize(stream));
+    if (hflag & 1u) return fail(SGR_E_PREFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
+    return 0;
+}
+
+int sgr_knn(int P, const float* points, float* meanDists, sgr_alloc_fn scratch, void* scratch_user, void* stream_) {
+    std::string err;
+    const int rc = sgr_knn_impl(P, points, meanDists, scratch, scratch_user, (hipStream_t)stream_, err);
+    if (rc < 0) g_err = err;
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// introspection
+__global__ void sgr_export_kernel(int which, int P, SgrGeomView gv, void* dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    switch (which) {
+        case 0: ((float*)dst)[i] = gv.recC[i].w; break;
+        case 1: {
+            const uint32_t c = gv.clamped[i];
+            ((uint8_t*)dst)[3 * i] = c & 1u; ((uint8_t*)dst)[3 * i + 1] = (c >> 1) & 1u; ((uint8_t*)dst)[3 * i + 2] = (c >> 2) & 1u;
+        } break;
+        case 2: { const float4 a = gv.recA[i]; ((float*)dst)[2 * i] = a.x; ((float*)dst)[2 * i + 1] = a.y; } break;
+        case 3: for (int k = 0; k < 6; k++) ((float*)dst)[6 * i + k] = gv.cov3D[6 * (size_t)i + k]; break;
+        case 4: ((float4*)dst)[i] = gv.recB[i]; break;
+        case 5: { const float4 c = gv.recC[i]; ((float*)dst)[3 * i] = c.x; ((float*)dst)[3 * i + 1] = c.y; ((float*)dst)[3 * i + 2] = c.z; } break;
+        case 6: ((uint32_t*)dst)[i] = gv.tiles_touched[i]; break;
+        case 7: ((uint32_t*)dst)[i] = gv.point_offsets[i]; break;
+        case 14: { const float4 a = gv.recA[i]; ((float*)dst)[2 * i] = a.z; ((float*)dst)[2 * i + 1] = a.w; } break;
+    }
+}
+
+int sgr_export_internal(int which, int P, int R, int width, int height, char* geom_buffer, char* binning_buffer,
+                        char* image_buffer, void* dst, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int debug = 1;
+    const int gx = (width + SGR_BLOCK_X - 1) / SGR_BLOCK_X, gy = (height + SGR_BLOCK_Y - 1) / SGR_BLOCK_Y;
+    const size_t N = (size_t)width * height, T = (size_t)gx * gy;
+    if (which <= 7 || which == 14) {
+        if (P <= 0) return 0;
+        const SgrGeomView gv = sgr_geom_carve(geom_buffer, (size_t)P);
+        sgr_export_kernel<<<(P + 255) / 256, 256, 0, stream>>>(which, P, gv, dst);
+        SGR_STAGE("export");
+        return 0;
+    }
+    if (which == 8 || which == 9) {
+        if (R <= 0) return 0;
+        const SgrBinView bv = sgr_bin_carve(binning_buffer, (size_t)R);
+        const int cur = sorted_index(width, height);
+        if (which == 8) SGR_HIP(hipMemcpyAsync(dst, bv.vals[cur], (size_t)R * 4, hipMemcpyDeviceToDevice, stream));
+        else SGR_HIP(hipMemcpyAsync(dst, bv.keys[cur], (size_t)R * 8, hipMemcpyDeviceToDevice, stream));
+        return 0;
+    }
+    const SgrImgView iv = sgr_img_carve(image_buffer, N, T);
+    if (which == 12) { SGR_HIP(hipMemcpyAsync(dst, iv.ranges, T * 8, hipMemcpyDeviceToDevice, stream)); return 0; }
+    if (which == 13) { SGR_HIP(hipMemcpyAsync(dst, iv.n_contrib, N * 4, hipMemcpyDeviceToDevice, stream)); return 0; }
+    return fail(SGR_E_INVALID, "unknown internal array");
+}
+
+// ------------------------------------------------------------------------------------------------
+// primitive self-tests
+int sgr_test_scan(const uint32_t* in, uint32_t* out, size_t n, int inclusive, uint32_t* tmp, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int debug = 1;
+    sgr_launch_scan(in, out, n, tmp, inclusive != 0, stream);
+    SGR_STAGE("scan");
+    return 0;
+}
+int sgr_test_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_t* vals1, uint32_t n, int end_bit,
+                  uint32_t* hist, uint32_t* scan_tmp, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int debug = 1;
+    uint64_t* keys[2] = {keys0, keys1};
+    uint32_t* vals[2] = {vals0, vals1};
+    const int cur = sgr_launch_sort_pairs(keys, vals, n, end_bit, hist, scan_tmp, stream);
+    SGR_STAGE("sort");
+    return cur;
+}
+size_t sgr_test_sort_hist_words(uint32_t n) { return (size_t)256 * sgr_sort_blocks(n ? n : 1); }
+size_t sgr_test_scan_tmp_words(size_t n) { return sgr_scan_tmp_count(n ? n : 1); }
+int sgr_test_wave_sum(const float* in, float* out_dpp, float* out_shfl, int nwaves, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int debug = 1;
+    sgr_launch_wave_sum_test(in, out_dpp, out_shfl, nwaves, stream);
+    SGR_STAGE("wave_sum");
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,313 @@
+// sgr_blend_bwd.hip -- K11: backward of the tile compositing on gfx950.  Replaces
+// renderCUDA<3,20> of the reference (backward.cu:415-641), which issues 11+S float atomicAdd per
+// contributing (pixel, Gaussian) pair.
+//
+// MI355X design -- no global atomics at all:
+//   * same quadrant-per-wave / LDS-staged / ballot-culled walk as the forward kernel, back to front;
+//   * the 11+S per-pair gradient terms are summed across the 64 pixels of a wave with DPP
+//     (quad_perm, row_half_mirror, row_mirror, row_bcast15/31: six v_add_f32_dpp per value),
+//     then the (up to four) wave partials of an instance are combined with ds_add_f32 in LDS;
+//   * each (tile, instance) partial row is written ONCE to `partials[u]`, where u is the instance's
+//     index in Gaussian-major order (u = exclusive tile offset of the Gaussian + index of this tile
+//     inside its rect).  Rows of one Gaussian are therefore contiguous, and the per-Gaussian kernel
+//     (sgr_gauss_bwd.hip) reduces them in a fixed order: gradients are bit-reproducible run to run,
+//     unlike the reference's unordered atomics.
+// Row layout (stride = 16 or 32 floats, 64-B aligned): [0..2] dL/dmean2D (x, y, |x|+|y|),
+// [3..5] dL/dconic (x, y, w), [6] dL/dopacity, [7..9] dL/drgb, [10] dL/ddepth, [11..11+S) dL/dsemantic.
+#include "sgr_math.h"
+
+#define SGR_TILE_THREADS 256
+#define SGR_ROW_BASE 11
+
+// Sum over the 64 lanes of a wave; the result is valid in lanes 48..63 (read it from lane 63).
+__device__ __forceinline__ float sgr_wave_sum_dpp(float v) {
+#define SGR_DPP_ADD(ctrl, rmask)                                                                              \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xF, false))
+    SGR_DPP_ADD(0xB1, 0xF);   // quad_perm [1,0,3,2]
+    SGR_DPP_ADD(0x4E, 0xF);   // quad_perm [2,3,0,1]
+    SGR_DPP_ADD(0x141, 0xF);  // row_half_mirror
+    SGR_DPP_ADD(0x140, 0xF);  // row_mirror      -> every lane of a 16-lane row holds the row sum
+    SGR_DPP_ADD(0x142, 0xA);  // row_bcast15     -> rows 1,3 += previous row
+    SGR_DPP_ADD(0x143, 0xC);  // row_bcast31     -> rows 2,3 += rows 0+1
+#undef SGR_DPP_ADD
+    return v;
+}
+
+__device__ __forceinline__ float sgr_wave_sum_shfl(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <bool DPP>
+__device__ __forceinline__ float sgr_wave_sum(float v) {
+    return DPP ? sgr_wave_sum_dpp(v) : sgr_wave_sum_shfl(v);
+}
+
+// self-test of the DPP reduction (sgr_selftest in sgr_api.hip)
+__global__ void sgr_wave_sum_test_kernel(const float* in, float* out_dpp, float* out_shfl) {
+    const float v = in[blockIdx.x * 64 + threadIdx.x];
+    const float a = sgr_wave_sum_dpp(v);
+    const float b = sgr_wave_sum_shfl(v);
+    if (threadIdx.x == 63) {
+        out_dpp[blockIdx.x] = a;
+        out_shfl[blockIdx.x] = b;
+    }
+}
+void sgr_launch_wave_sum_test(const float* in, float* out_dpp, float* out_shfl, int nwaves, hipStream_t s) {
+    sgr_wave_sum_test_kernel<<<nwaves, 64, 0, s>>>(in, out_dpp, out_shfl);
+}
+
+template <int SMAX, bool CULL, bool DPP>
+__global__ void __launch_bounds__(SGR_TILE_THREADS)
+sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int S,
+                     int gx, const float* __restrict__ bg_color, const float4* __restrict__ recA,
+                     const float4* __restrict__ recB, const float4* __restrict__ recC, const uint2* __restrict__ recD,
+                     const float* __restrict__ semantics, const float* __restrict__ alphas,
+                     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
+                     const float* __restrict__ dL_dpixel_depths, const float* __restrict__ dL_dalphas,
+                     const float* __restrict__ dL_dpixel_semantics, float* __restrict__ partials, int row_stride) {
+    constexpr int NS = SMAX > 0 ? SMAX : 1;
+    constexpr int ACCW = (SGR_ROW_BASE + SMAX) | 1;  // odd LDS row stride: conflict-free row-per-lane reads
+    __shared__ float4 sA[SGR_TILE_THREADS];  // {x, y, -, -}
+    __shared__ float4 sB[SGR_TILE_THREADS];  // {qa, qb, qc, opacity}
+    __shared__ float4 sC[SGR_TILE_THREADS];  // {r, g, b, depth}
+    __shared__ uint32_t sU[SGR_TILE_THREADS];
+    __shared__ uint32_t sFlag[SGR_TILE_THREADS];
+    __shared__ uint64_t sBits[4][4];
+    __shared__ int sMax[4];
+    __shared__ float sAcc[SGR_TILE_THREADS * ACCW];
+    __shared__ float sSem[SMAX > 0 ? SGR_TILE_THREADS * SMAX : 1];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t tx = tile % (uint32_t)gx, ty = tile / (uint32_t)gx;
+    const uint32_t px = tx * SGR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
+    const uint32_t py = ty * SGR_BLOCK_Y + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < (uint32_t)W && py < (uint32_t)H;
+    const float pxf = (float)px, pyf = (float)py;
+    const size_t pix_id = (size_t)W * py + px;
+    const size_t plane = (size_t)H * W;
+    const uint2 range = ranges[tile];
+
+    // backward.cu:466-500
+    const float T_final = inside ? (1.0f - alphas[pix_id]) : 0.0f;
+    float T = T_final;
+    const int lastc = inside ? (int)n_contrib[pix_id] : 0;
+    float dLdC0 = 0.f, dLdC1 = 0.f, dLdC2 = 0.f, dLdD = 0.f, dLdA = 0.f;
+    float dLdS[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) dLdS[i] = 0.f;
+    if (inside) {
+        dLdC0 = dL_dpixels[pix_id];
+        dLdC1 = dL_dpixels[plane + pix_id];
+        dLdC2 = dL_dpixels[2 * plane + pix_id];
+        dLdD = dL_dpixel_depths[pix_id];
+        dLdA = dL_dalphas[pix_id];
+        if (SMAX > 0) {
+#pragma unroll
+            for (int i = 0; i < SMAX; i++)
+                if (i < S) dLdS[i] = dL_dpixel_semantics[i * plane + pix_id];
+        }
+    }
+    const float bgdot = bg_color[0] * dLdC0 + bg_color[1] * dLdC1 + bg_color[2] * dLdC2;
+    // d(pixel)/d(ndc) (backward.cu:501-502) with the 1/log2(e) of the pre-scaled conic folded in
+    const float kx = (0.5f * (float)W) / SGR_LOG2E, ky = (0.5f * (float)H) / SGR_LOG2E;
+
+    float accC0 = 0.f, accC1 = 0.f, accC2 = 0.f, lastC0 = 0.f, lastC1 = 0.f, lastC2 = 0.f;
+    float accD = 0.f, lastD = 0.f, accA = 0.f, last_alpha = 0.f;
+    float accS[NS], lastS[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) { accS[i] = 0.f; lastS[i] = 0.f; }
+
+    // highest list position any pixel of the tile blended
+    int mx = lastc;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) sMax[wave] = mx;
+    __syncthreads();
+    const int maxc = max(max(sMax[0], sMax[1]), max(sMax[2], sMax[3]));
+    const float tx0 = (float)(tx * SGR_BLOCK_X), ty0 = (float)(ty * SGR_BLOCK_Y);
+
+    for (int hi = maxc - 1; hi >= 0; hi -= SGR_TILE_THREADS) {
+        // slot t of this batch holds list position hi - t (descending: back to front)
+        __syncthreads();  // previous batch fully consumed (rows written) before LDS is overwritten
+        const int pos = hi - tid;
+        uint32_t mask4 = 0;
+        sFlag[tid] = 0;
+#pragma unroll
+        for (int k = 0; k < ACCW; k++) sAcc[tid * ACCW + k] = 0.f;
+        if (pos >= 0) {
+            const uint32_t g = point_list[range.x + (uint32_t)pos];
+            const float4 a = recA[g];
+            const float4 b = recB[g];
+            const uint2 d = recD[g];
+            sA[tid] = a;
+            sB[tid] = make_float4(-0.5f * SGR_LOG2E * b.x, -SGR_LOG2E * b.y, -0.5f * SGR_LOG2E * b.z, b.w);
+            sC[tid] = recC[g];
+            const uint32_t rx0 = d.y & 1023u, ry0 = (d.y >> 10) & 1023u, rw = d.y >> 20;
+            sU[tid] = d.x + (ty - ry0) * rw + (tx - rx0);
+            if (SMAX > 0) {
+                for (int ch = 0; ch < S; ch++) sSem[tid * SMAX + ch] = semantics[(size_t)g * S + ch];
+            }
+            if (CULL) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float qx0 = tx0 + (float)((q & 1) * 8), qy0 = ty0 + (float)((q >> 1) * 8);
+                    const bool miss = (a.x + a.z < qx0) || (a.x - a.z > qx0 + 7.0f) || (a.y + a.w < qy0) ||
+                                      (a.y - a.w > qy0 + 7.0f);
+                    mask4 |= miss ? 0u : (1u << q);
+                }
+            } else {
+                mask4 = 0xFu;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint64_t m = __ballot((mask4 >> q) & 1u);
+            if (lane == 0) sBits[q][wave] = m;
+        }
+        __syncthreads();
+
+        for (int chunk = 0; chunk < 4; chunk++) {
+            uint64_t m = sBits[wave][chunk];
+            m = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(m >> 32)) << 32) |
+                (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)m);
+            while (m) {
+                const int j = chunk * 64 + (__ffsll((unsigned long long)m) - 1);
+                m &= m - 1;
+                const int posj = hi - j;  // 0-based list position == `contributor` after its decrement
+                const float4 a = sA[j];
+                const float4 q = sB[j];
+                const float dx = a.x - pxf, dy = a.y - pyf;
+                const float power2 = sgr_power2(q.x, q.y, q.z, dx, dy);
+                const float G = __builtin_amdgcn_exp2f(power2);
+                const float alpha = fminf(0.99f, q.w * G);
+                // backward.cu:527-545
+                const bool hit = inside && (posj < lastc) && !(power2 > 0.0f) && !(alpha < SGR_ALPHA_MIN);
+                if (!__any(hit)) continue;
+
+                const float4 c = sC[j];
+                const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
+                const float Tn = T * inv1ma;  // T = T / (1 - alpha)
+                const float w = alpha * Tn;
+                float dopa;
+                float v[SGR_ROW_BASE + NS];
+                {
+                    const float one_m_la = 1.0f - last_alpha;
+                    const float a0 = fmaf(last_alpha, lastC0, one_m_la * accC0);
+                    const float a1 = fmaf(last_alpha, lastC1, one_m_la * accC1);
+                    const float a2 = fmaf(last_alpha, lastC2, one_m_la * accC2);
+                    dopa = (c.x - a0) * dLdC0 + (c.y - a1) * dLdC1 + (c.z - a2) * dLdC2;
+                    const float ad = fmaf(last_alpha, lastD, one_m_la * accD);
+                    dopa = fmaf(c.w - ad, dLdD, dopa);
+                    const float aa = fmaf(one_m_la, accA, last_alpha);
+                    dopa = fmaf(1.0f - aa, dLdA, dopa);
+                    if (SMAX > 0) {
+#pragma unroll
+                        for (int ch = 0; ch < SMAX; ch++) {
+                            if (ch < S) {
+                                const float sv = sSem[j * SMAX + ch];
+                                const float as = fmaf(last_alpha, lastS[ch], one_m_la * accS[ch]);
+                                dopa = fmaf(sv - as, dLdS[ch], dopa);
+                                v[SGR_ROW_BASE + ch] = hit ? w * dLdS[ch] : 0.0f;
+                                accS[ch] = hit ? as : accS[ch];
+                                lastS[ch] = hit ? sv : lastS[ch];
+                            } else {
+                                v[SGR_ROW_BASE + ch] = 0.0f;
+                            }
+                        }
+                    }
+                    if (hit) {
+                        accC0 = a0; accC1 = a1; accC2 = a2;
+                        lastC0 = c.x; lastC1 = c.y; lastC2 = c.z;
+                        accD = ad; lastD = c.w;
+                        accA = aa;
+                        last_alpha = alpha;
+                        T = Tn;
+                    }
+                }
+                dopa *= Tn;
+                dopa = fmaf(-T_final * inv1ma, bgdot, dopa);  // backward.cu:611-614
+                const float dL_dG = q.w * dopa;
+                const float gdx = G * dx, gdy = G * dy;
+                // dG/ddelx = -gdx*A - gdy*B = (2*qa*gdx + qb*gdy)/log2e  (qa = -0.5*log2e*A, qb = -log2e*B)
+                const float gmx = dL_dG * fmaf(2.0f * q.x, gdx, q.y * gdy) * kx;
+                const float gmy = dL_dG * fmaf(2.0f * q.z, gdy, q.y * gdx) * ky;
+                v[0] = hit ? gmx : 0.0f;
+                v[1] = hit ? gmy : 0.0f;
+                v[2] = hit ? fabsf(gmx) + fabsf(gmy) : 0.0f;
+                const float h = -0.5f * dL_dG;
+                v[3] = hit ? h * gdx * dx : 0.0f;
+                v[4] = hit ? h * gdx * dy : 0.0f;
+                v[5] = hit ? h * gdy * dy : 0.0f;
+                v[6] = hit ? G * dopa : 0.0f;
+                v[7] = hit ? w * dLdC0 : 0.0f;
+                v[8] = hit ? w * dLdC1 : 0.0f;
+                v[9] = hit ? w * dLdC2 : 0.0f;
+                v[10] = hit ? w * dLdD : 0.0f;
+#pragma unroll
+                for (int k = 0; k < SGR_ROW_BASE + SMAX; k++) v[k] = sgr_wave_sum<DPP>(v[k]);
+                if (lane == 63) {
+#pragma unroll
+                    for (int k = 0; k < SGR_ROW_BASE + SMAX; k++) atomicAdd(&sAcc[j * ACCW + k], v[k]);
+                    sFlag[j] = 1u;
+                }
+            }
+        }
+        __syncthreads();
+        // one row per touched (tile, instance): plain stores, written exactly once
+        if (sFlag[tid]) {
+            float* row = partials + (size_t)sU[tid] * row_stride;
+            constexpr int NV = (SGR_ROW_BASE + SMAX + 3) / 4;
+#pragma unroll
+            for (int k4 = 0; k4 < NV; k4++) {
+                float4 o;
+                o.x = sAcc[tid * ACCW + 4 * k4];
+                o.y = (4 * k4 + 1 < SGR_ROW_BASE + SMAX) ? sAcc[tid * ACCW + 4 * k4 + 1] : 0.f;
+                o.z = (4 * k4 + 2 < SGR_ROW_BASE + SMAX) ? sAcc[tid * ACCW + 4 * k4 + 2] : 0.f;
+                o.w = (4 * k4 + 3 < SGR_ROW_BASE + SMAX) ? sAcc[tid * ACCW + 4 * k4 + 3] : 0.f;
+                reinterpret_cast<float4*>(row)[k4] = o;
+            }
+        }
+    }
+}
+
+template <int SMAX>
+static void launch_bwd(bool cull, bool dpp, unsigned tiles, hipStream_t s, const uint2* ranges, const uint32_t* point_list,
+                       int W, int H, int S, int gx, const float* bg, const float4* recA, const float4* recB,
+                       const float4* recC, const uint2* recD, const float* semantics, const float* alphas,
+                       const uint32_t* n_contrib, const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha,
+                       const float* dL_dsem, float* partials, int row_stride) {
+#define SGR_GO(C, D)                                                                                                 \
+    sgr_blend_bwd_kernel<SMAX, C, D><<<tiles, SGR_TILE_THREADS, 0, s>>>(ranges, point_list, W, H, S, gx, bg, recA, recB, \
+                                                                       recC, recD, semantics, alphas, n_contrib,    \
+                                                                       dL_dpix, dL_ddepth, dL_dalpha, dL_dsem,      \
+                                                                       partials, row_stride)
+    if (cull && dpp) SGR_GO(true, true);
+    else if (cull) SGR_GO(true, false);
+    else if (dpp) SGR_GO(false, true);
+    else SGR_GO(false, false);
+#undef SGR_GO
+}
+
+// floats per partial row for S semantic channels: the kernel's SMAX bucket writes ceil((11+SMAX)/4) float4
+int sgr_partial_row_stride(int S) { return S <= 4 ? 16 : (S <= 16 ? 32 : 48); }
+
+void sgr_launch_blend_bwd(bool cull, bool dpp, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
+                          int H, int S, const float* bg, const float4* recA, const float4* recB, const float4* recC,
+                          const uint2* recD, const float* semantics, const float* alphas, const uint32_t* n_contrib,
+                          const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha, const float* dL_dsem,
+                          float* partials, hipStream_t s) {
+    const unsigned tiles = (unsigned)gx * (unsigned)gy;
+    if (tiles == 0) return;
+    const int stride = sgr_partial_row_stride(S);
+#define SGR_BWD(N) launch_bwd<N>(cull, dpp, tiles, s, ranges, point_list, W, H, S, gx, bg, recA, recB, recC, recD, \
+                                 semantics, alphas, n_contrib, dL_dpix, dL_ddepth, dL_dalpha, dL_dsem, partials, stride)
+    if (S == 0) SGR_BWD(0);
+    else if (S <= 4) SGR_BWD(4);
+    else if (S <= 8) SGR_BWD(8);
+    else if (S <= 16) SGR_BWD(16);
+    else SGR_BWD(32);
+#undef SGR_BWD
+}

@@ -1,0 +1,177 @@
+// sgr_blend_fwd.hip -- K10: front-to-back alpha compositing of one 16x16 tile per workgroup on
+// gfx950.  Replaces renderCUDA<3> of the reference (forward.cu:340-467).
+//
+// CDNA4 mapping: 256 lanes = 4 wave64; each wave owns one 8x8 pixel QUADRANT of the tile (compact
+// footprint, so a whole wave can skip a splat).  The tile's depth-sorted instance list is staged
+// through LDS 256 instances at a time: every lane gathers one instance (three 16-byte loads),
+// pre-scales the conic (so exp() is one v_exp_f32), and tests the splat's conservative alpha>=1/255
+// bounding box (recA.zw) against the four quadrants.  Four wave ballots turn those tests into one
+// 64-bit survivor mask per (quadrant, 64-instance chunk); each wave then walks only the set bits of
+// its own masks (s_ff1 loop) and reads the survivor's record from LDS as a broadcast.  Semantic
+// channels accumulate in registers (the reference does a global read-modify-write per pair,
+// forward.cu:442-444).  Results are identical to walking the full list: a culled instance can only
+// fail the alpha test for every pixel of the quadrant.
+#include "sgr_math.h"
+
+#define SGR_TILE_THREADS 256
+
+template <int SMAX, bool CULL>
+__global__ void __launch_bounds__(SGR_TILE_THREADS)
+sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int S,
+                     int gx, const float4* __restrict__ recA, const float4* __restrict__ recB,
+                     const float4* __restrict__ recC, const float* __restrict__ semantics,
+                     const float* __restrict__ bg_color, float* __restrict__ out_color, float* __restrict__ out_depth,
+                     float* __restrict__ out_alpha, float* __restrict__ out_semantic, uint32_t* __restrict__ n_contrib) {
+    __shared__ float4 sA[SGR_TILE_THREADS];  // {x, y, -, -}
+    __shared__ float4 sB[SGR_TILE_THREADS];  // {qa, qb, qc, opacity}
+    __shared__ float4 sC[SGR_TILE_THREADS];  // {r, g, b, depth}
+    __shared__ uint64_t sBits[4][4];         // [quadrant][chunk of 64 instances]
+    __shared__ float sSem[SMAX > 0 ? SGR_TILE_THREADS * SMAX : 1];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t tx = tile % (uint32_t)gx, ty = tile / (uint32_t)gx;
+    const uint32_t px = tx * SGR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
+    const uint32_t py = ty * SGR_BLOCK_Y + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < (uint32_t)W && py < (uint32_t)H;
+    const float pxf = (float)px, pyf = (float)py;
+    const uint2 range = ranges[tile];
+
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Wt = 0.f;
+    float sem[SMAX > 0 ? SMAX : 1];
+#pragma unroll
+    for (int i = 0; i < (SMAX > 0 ? SMAX : 1); i++) sem[i] = 0.f;
+    uint32_t last = 0;
+    bool done = !inside;
+
+    // quadrant bounds (pixel centres) used by the staging lanes for the cull test
+    const float tx0 = (float)(tx * SGR_BLOCK_X), ty0 = (float)(ty * SGR_BLOCK_Y);
+
+    for (uint32_t base = range.x; base < range.y; base += SGR_TILE_THREADS) {
+        // tile-wide early exit (forward.cu:394-396); also the barrier that protects LDS reuse
+        if (__syncthreads_and(done)) break;
+
+        const uint32_t idx = base + tid;
+        uint32_t mask4 = 0;
+        if (idx < range.y) {
+            const uint32_t g = point_list[idx];
+            const float4 a = recA[g];
+            const float4 b = recB[g];
+            sA[tid] = a;
+            sB[tid] = make_float4(-0.5f * SGR_LOG2E * b.x, -SGR_LOG2E * b.y, -0.5f * SGR_LOG2E * b.z, b.w);
+            sC[tid] = recC[g];
+            if (SMAX > 0) {
+                for (int ch = 0; ch < S; ch++) sSem[tid * SMAX + ch] = semantics[(size_t)g * S + ch];
+            }
+            if (CULL) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float qx0 = tx0 + (float)((q & 1) * 8), qy0 = ty0 + (float)((q >> 1) * 8);
+                    // written so that NaN extents never cull
+                    const bool miss = (a.x + a.z < qx0) || (a.x - a.z > qx0 + 7.0f) || (a.y + a.w < qy0) ||
+                                      (a.y - a.w > qy0 + 7.0f);
+                    mask4 |= miss ? 0u : (1u << q);
+                }
+            } else {
+                mask4 = 0xFu;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint64_t m = __ballot((mask4 >> q) & 1u);
+            if (lane == 0) sBits[q][wave] = m;
+        }
+        __syncthreads();
+
+        if (!__all(done)) {
+            const uint32_t pos0 = base - range.x;  // list position of slot 0 of this batch
+            for (int chunk = 0; chunk < 4; chunk++) {
+                uint64_t m = sBits[wave][chunk];
+                m = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(m >> 32)) << 32) |
+                    (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)m);
+                while (m) {
+                    const int j = chunk * 64 + (__ffsll((unsigned long long)m) - 1);
+                    m &= m - 1;
+                    const float4 a = sA[j];
+                    const float4 q = sB[j];
+                    const float dx = a.x - pxf, dy = a.y - pyf;
+                    const float power2 = sgr_power2(q.x, q.y, q.z, dx, dy);
+                    const float alpha = fminf(0.99f, q.w * __builtin_amdgcn_exp2f(power2));
+                    // forward.cu:425-430: skip if power > 0 or alpha < 1/255
+                    const bool hit = !done && !(power2 > 0.0f) && !(alpha < SGR_ALPHA_MIN);
+                    if (__any(hit)) {
+                        const float test_T = T * (1.0f - alpha);
+                        const bool stop = hit && (test_T < 0.0001f);  // forward.cu:431-436
+                        const bool blend = hit && !stop;
+                        const float4 c = sC[j];
+                        const float w = blend ? alpha * T : 0.0f;
+                        C0 = fmaf(c.x, w, C0);
+                        C1 = fmaf(c.y, w, C1);
+                        C2 = fmaf(c.z, w, C2);
+                        Dp = fmaf(c.w, w, Dp);
+                        Wt += w;
+                        if (SMAX > 0) {
+#pragma unroll
+                            for (int ch = 0; ch < SMAX; ch++)
+                                if (ch < S) sem[ch] = fmaf(sSem[j * SMAX + ch], w, sem[ch]);
+                        }
+                        T = blend ? test_T : T;
+                        last = blend ? (pos0 + (uint32_t)j + 1u) : last;
+                        if (__any(stop)) {
+                            done = done || stop;
+                            if (__all(done)) { m = 0; chunk = 4; }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (inside) {
+        const size_t pix_id = (size_t)W * py + px;
+        const size_t plane = (size_t)H * W;
+        n_contrib[pix_id] = last;
+        out_color[pix_id] = C0 + T * bg_color[0];
+        out_color[plane + pix_id] = C1 + T * bg_color[1];
+        out_color[2 * plane + pix_id] = C2 + T * bg_color[2];
+        out_alpha[pix_id] = Wt;
+        out_depth[pix_id] = Dp;
+        if (SMAX > 0) {
+#pragma unroll
+            for (int ch = 0; ch < SMAX; ch++)
+                if (ch < S) out_semantic[ch * plane + pix_id] = sem[ch];
+        }
+    }
+}
+
+template <int SMAX>
+static void launch_fwd(bool cull, unsigned tiles, hipStream_t s, const uint2* ranges, const uint32_t* point_list, int W,
+                       int H, int S, int gx, const float4* recA, const float4* recB, const float4* recC,
+                       const float* semantics, const float* bg, float* out_color, float* out_depth, float* out_alpha,
+                       float* out_semantic, uint32_t* n_contrib) {
+    if (cull)
+        sgr_blend_fwd_kernel<SMAX, true><<<tiles, SGR_TILE_THREADS, 0, s>>>(ranges, point_list, W, H, S, gx, recA, recB,
+                                                                           recC, semantics, bg, out_color, out_depth,
+                                                                           out_alpha, out_semantic, n_contrib);
+    else
+        sgr_blend_fwd_kernel<SMAX, false><<<tiles, SGR_TILE_THREADS, 0, s>>>(ranges, point_list, W, H, S, gx, recA, recB,
+                                                                            recC, semantics, bg, out_color, out_depth,
+                                                                            out_alpha, out_semantic, n_contrib);
+}
+
+// S must be <= SGR_SEM_MAX (checked by the caller).
+void sgr_launch_blend_fwd(bool cull, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W, int H,
+                          int S, const float4* recA, const float4* recB, const float4* recC, const float* semantics,
+                          const float* bg, float* out_color, float* out_depth, float* out_alpha, float* out_semantic,
+                          uint32_t* n_contrib, hipStream_t s) {
+    const unsigned tiles = (unsigned)gx * (unsigned)gy;
+    if (tiles == 0) return;
+#define SGR_FWD(N) launch_fwd<N>(cull, tiles, s, ranges, point_list, W, H, S, gx, recA, recB, recC, semantics, bg, \
+                                 out_color, out_depth, out_alpha, out_semantic, n_contrib)
+    if (S == 0) SGR_FWD(0);
+    else if (S <= 4) SGR_FWD(4);
+    else if (S <= 8) SGR_FWD(8);
+    else if (S <= 16) SGR_FWD(16);
+    else SGR_FWD(32);
+#undef SGR_FWD
+}

@@ -1,0 +1,126 @@
+// sgr_common.h -- shared definitions of the MI355X-native Gaussian rasterizer (gfx950 only).
+//
+// Data layout in HBM (all private to the native side; the three byte buffers are only
+// round-tripped through the caller, as in the reference's GeometryState/BinningState/ImageState,
+// /root/reference/submodules/diff-gaussian-rasterization/cuda_rasterizer/rasterizer_impl.h:29-64):
+//
+//   geometry buffer, per Gaussian g (struct-of-float4-arrays so every gather is one 16-B load):
+//     recA[g] = {pix.x, pix.y, hx, hy}      2D mean + conservative half extents of the alpha>=1/255 ellipse
+//     recB[g] = {conic.x, conic.y, conic.z, opacity}
+//     recC[g] = {r, g, b, view depth}
+//     recD[g] = {exclusive tile offset, packed tile rect}   (backward only)
+//     cov3D[6g..], tiles_touched[g], point_offsets[g] (inclusive), clamped[g] (3-bit mask), radii (if not given)
+//   binning buffer: 64-bit keys (tile<<32 | depth bits) and 32-bit Gaussian ids, ping-pong for the
+//     LSD radix sort, plus the per-block digit histograms.
+//   image buffer: n_contrib[H*W], ranges[tiles].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SGR_BLOCK_X 16
+#define SGR_BLOCK_Y 16
+#define SGR_WAVE 64
+#define SGR_MAX_GRID_DIM 1023  // tiles per axis representable in the packed rect (10 bits)
+#define SGR_SEM_MAX 32         // semantic channels supported by the blend kernels
+#define SGR_ROW_BASE_N 11      // non-semantic floats of a partial-gradient row (see sgr_blend_bwd.hip)
+
+#define SGR_ALPHA_MIN (1.0f / 255.0f)
+#define SGR_LOG2E 1.4426950408889634f
+
+struct SgrGeomView {
+    float4* recA;
+    float4* recB;
+    float4* recC;
+    uint2* recD;
+    float* cov3D;
+    uint32_t* tiles_touched;
+    uint32_t* point_offsets;
+    uint32_t* clamped;  // 3-bit mask per Gaussian, one u32 each (keeps stores simple and aligned)
+    int* internal_radii;
+    uint32_t* scan_tmp;   // block sums of the device-wide scan
+    uint32_t* header;     // [0]=error flag, [1]=num_rendered
+};
+
+struct SgrBinView {
+    uint64_t* keys[2];
+    uint32_t* vals[2];
+    uint32_t* hist;      // [256][nblocks] per-pass digit histogram, exclusive-scanned in place
+    uint32_t* scan_tmp;
+    uint32_t* header;    // [0]=index (0/1) of the buffer pair holding the sorted result
+};
+
+struct SgrImgView {
+    uint32_t* n_contrib;
+    uint2* ranges;
+};
+
+static inline size_t sgr_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+template <typename T>
+static inline void sgr_carve(char*& p, T*& out, size_t count) {
+    p = (char*)sgr_align_up((size_t)p, 256);
+    out = (T*)p;
+    p += count * sizeof(T);
+}
+
+#define SGR_SCAN_ITEMS 2048   // elements per block in the device-wide scan
+#define SGR_SORT_ITEMS 2048   // keys per block in the radix sort (256 threads x 8)
+#define SGR_SORT_MAX_PASS 8
+
+static inline size_t sgr_scan_tmp_count(size_t n) { return (n + SGR_SCAN_ITEMS - 1) / SGR_SCAN_ITEMS + 1; }
+
+// Carve the geometry buffer.  base may be (char*)256 to compute the required size: *end - base.
+static inline SgrGeomView sgr_geom_carve(char* base, size_t P, char** end = nullptr) {
+    SgrGeomView v;
+    char* p = base;
+    size_t Pn = P ? P : 1;
+    sgr_carve(p, v.header, 64);
+    sgr_carve(p, v.recA, Pn);
+    sgr_carve(p, v.recB, Pn);
+    sgr_carve(p, v.recC, Pn);
+    sgr_carve(p, v.recD, Pn);
+    sgr_carve(p, v.cov3D, Pn * 6);
+    sgr_carve(p, v.tiles_touched, Pn);
+    sgr_carve(p, v.point_offsets, Pn);
+    sgr_carve(p, v.clamped, Pn);
+    sgr_carve(p, v.internal_radii, Pn);
+    sgr_carve(p, v.scan_tmp, sgr_scan_tmp_count(Pn));
+    if (end) *end = p;
+    return v;
+}
+
+static inline size_t sgr_sort_blocks(size_t R) { return (R + SGR_SORT_ITEMS - 1) / SGR_SORT_ITEMS; }
+
+static inline SgrBinView sgr_bin_carve(char* base, size_t R, char** end = nullptr) {
+    SgrBinView v;
+    char* p = base;
+    size_t Rn = R ? R : 1;
+    size_t nb = sgr_sort_blocks(Rn);
+    size_t nh = (size_t)256 * nb;
+    sgr_carve(p, v.header, 64);
+    sgr_carve(p, v.keys[0], Rn);
+    sgr_carve(p, v.keys[1], Rn);
+    sgr_carve(p, v.vals[0], Rn);
+    sgr_carve(p, v.vals[1], Rn);
+    sgr_carve(p, v.hist, nh);
+    sgr_carve(p, v.scan_tmp, sgr_scan_tmp_count(nh));
+    if (end) *end = p;
+    return v;
+}
+
+static inline SgrImgView sgr_img_carve(char* base, size_t N, size_t T, char** end = nullptr) {
+    SgrImgView v;
+    char* p = base;
+    sgr_carve(p, v.n_contrib, N ? N : 1);
+    sgr_carve(p, v.ranges, T ? T : 1);
+    if (end) *end = p;
+    return v;
+}
+
+template <typename F>
+static inline size_t sgr_required(F carve) {
+    char* end = nullptr;
+    char* base = (char*)4096;
+    carve(base, &end);
+    return (size_t)(end - base) + 256;  // +256: the caller's pointer is re-aligned up to 256 B
+}

@@ -1,0 +1,158 @@
+// sgr_gauss_bwd.hip -- per-Gaussian backward on gfx950: K12 (computeCov2DCUDA) + K13
+// (preprocessCUDA backward) of the reference (backward.cu:144-274, 346-412) fused with the
+// reduction of the per-(tile, instance) partial rows produced by sgr_blend_bwd.hip.
+//
+// One Gaussian per lane.  The rows of Gaussian g are contiguous: partials[offs_excl .. +tiles_touched),
+// 64-B aligned, summed in ascending tile order -> deterministic gradients.  Every output element is
+// written exactly once (zeros for culled Gaussians and for SH coefficients above the active degree),
+// so the caller allocates the gradient tensors uninitialised instead of the reference's eleven
+// torch::zeros (rasterize_points.cu:166-176).
+#include "sgr_math.h"
+
+#define SGR_GB_THREADS 256
+
+template <int SMAX>
+__global__ void __launch_bounds__(SGR_GB_THREADS)
+sgr_gauss_bwd_kernel(int P, int D, int M, int S, const float* __restrict__ means3D, const int* __restrict__ radii,
+                     const float* __restrict__ shs, const float* __restrict__ scales,
+                     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
+                     const SgrCam* __restrict__ camp, SgrGeomView gv, const float* __restrict__ partials, int row_stride, float* __restrict__ dL_dmean2D,
+                     float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
+                     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
+                     float* __restrict__ dL_drot, float* __restrict__ dL_dsemantic) {
+    constexpr int NS = SMAX > 0 ? SMAX : 1;
+    const SgrCam& cam = *camp;
+    const int idx = blockIdx.x * SGR_GB_THREADS + threadIdx.x;
+    if (idx >= P) return;
+    const bool visible = radii[idx] > 0;
+
+    float acc[SGR_ROW_BASE_N + NS];
+#pragma unroll
+    for (int k = 0; k < SGR_ROW_BASE_N + NS; k++) acc[k] = 0.f;
+    if (visible) {
+        const uint32_t u0 = gv.recD[idx].x;
+        const uint32_t n = gv.tiles_touched[idx];
+        constexpr int NV = (SGR_ROW_BASE_N + SMAX + 3) / 4;
+        for (uint32_t i = 0; i < n; i++) {
+            const float4* row = reinterpret_cast<const float4*>(partials + (size_t)(u0 + i) * row_stride);
+#pragma unroll
+            for (int k4 = 0; k4 < NV; k4++) {
+                const float4 t = row[k4];
+                acc[4 * k4] += t.x;
+                if (4 * k4 + 1 < SGR_ROW_BASE_N + SMAX) acc[4 * k4 + 1] += t.y;
+                if (4 * k4 + 2 < SGR_ROW_BASE_N + SMAX) acc[4 * k4 + 2] += t.z;
+                if (4 * k4 + 3 < SGR_ROW_BASE_N + SMAX) acc[4 * k4 + 3] += t.w;
+            }
+        }
+    }
+    // outputs that come straight from the blend backward (backward.cu:568-638)
+    dL_dmean2D[3 * idx + 0] = acc[0];
+    dL_dmean2D[3 * idx + 1] = acc[1];
+    dL_dmean2D[3 * idx + 2] = acc[2];
+    dL_dopacity[idx] = acc[6];
+    dL_dcolor[3 * idx + 0] = acc[7];
+    dL_dcolor[3 * idx + 1] = acc[8];
+    dL_dcolor[3 * idx + 2] = acc[9];
+    if (SMAX > 0) {
+#pragma unroll
+        for (int ch = 0; ch < SMAX; ch++)
+            if (ch < S) dL_dsemantic[(size_t)idx * S + ch] = acc[SGR_ROW_BASE_N + ch];
+    }
+
+    float dmean[3] = {0.f, 0.f, 0.f};
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dscale[3] = {0.f, 0.f, 0.f};
+    float drot[4] = {0.f, 0.f, 0.f, 0.f};
+    const float p[3] = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+    float dRGB[3] = {0.f, 0.f, 0.f};
+    float dir[3] = {0.f, 0.f, 1.f}, dir_orig[3] = {0.f, 0.f, 1.f};
+
+    if (visible) {
+        // K12: conic -> cov3D and the covariance part of dL/dmean (assigned)
+        float cov3D[6];
+        const float* csrc = cov3D_precomp ? cov3D_precomp + 6 * (size_t)idx : gv.cov3D + 6 * (size_t)idx;
+#pragma unroll
+        for (int i = 0; i < 6; i++) cov3D[i] = csrc[i];
+        sgr_cov2d_backward(p, cov3D, cam, acc[3], acc[4], acc[5], dcov, dmean);
+        // K13: projection + depth paths (added)
+        sgr_proj_depth_backward(p, cam, acc[0], acc[1], acc[10], dmean);
+        if (scales != nullptr) {
+            const float sc[3] = {scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]};
+            const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)idx);
+            const float rot[4] = {q.x, q.y, q.z, q.w};
+            sgr_cov3d_backward(sc, cam.scale_modifier, rot, dcov, dscale, drot);
+        }
+        if (shs != nullptr) {
+            const uint32_t cl = gv.clamped[idx];
+            dRGB[0] = (cl & 1u) ? 0.f : acc[7];
+            dRGB[1] = (cl & 2u) ? 0.f : acc[8];
+            dRGB[2] = (cl & 4u) ? 0.f : acc[9];
+            dir_orig[0] = p[0] - cam.campos[0];
+            dir_orig[1] = p[1] - cam.campos[1];
+            dir_orig[2] = p[2] - cam.campos[2];
+            const float len = sqrtf(dir_orig[0] * dir_orig[0] + dir_orig[1] * dir_orig[1] + dir_orig[2] * dir_orig[2]);
+            dir[0] = dir_orig[0] / len;
+            dir[1] = dir_orig[1] / len;
+            dir[2] = dir_orig[2] / len;
+        }
+    }
+
+    if (shs != nullptr) {
+        // dL/dSH[k] = Y_k(dir) * dL/dRGB for k < (D+1)^2, zero above (backward.cu:46-105); the
+        // view-direction path adds dnormvdv(dir_orig, dL/ddir) to dL/dmean (backward.cu:131-138).
+        float* dsh = dL_dsh + (size_t)idx * M * 3;
+        const int ncoef = (D + 1) * (D + 1);
+        if (visible) {
+            float Y[16];
+            sgr_sh_basis(D, dir[0], dir[1], dir[2], Y);
+            const float* sh = shs + (size_t)idx * M * 3;
+            float shl[48];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (k < ncoef) {
+                    shl[3 * k] = sh[3 * k]; shl[3 * k + 1] = sh[3 * k + 1]; shl[3 * k + 2] = sh[3 * k + 2];
+                    dsh[3 * k] = Y[k] * dRGB[0]; dsh[3 * k + 1] = Y[k] * dRGB[1]; dsh[3 * k + 2] = Y[k] * dRGB[2];
+                } else {
+                    shl[3 * k] = 0.f; shl[3 * k + 1] = 0.f; shl[3 * k + 2] = 0.f;
+                }
+            }
+            for (int k = ncoef; k < M; k++) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
+            float ddir[3], dm[3];
+            sgr_sh_dir_backward(D, dir[0], dir[1], dir[2], shl, dRGB, ddir);
+            sgr_dnormvdv(dir_orig, ddir, dm);
+            dmean[0] += dm[0]; dmean[1] += dm[1]; dmean[2] += dm[2];
+        } else {
+            for (int k = 0; k < M * 3; k++) dsh[k] = 0.f;
+        }
+    }
+
+    dL_dmean3D[3 * idx + 0] = dmean[0];
+    dL_dmean3D[3 * idx + 1] = dmean[1];
+    dL_dmean3D[3 * idx + 2] = dmean[2];
+#pragma unroll
+    for (int i = 0; i < 6; i++) dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+    dL_dscale[3 * idx + 0] = dscale[0];
+    dL_dscale[3 * idx + 1] = dscale[1];
+    dL_dscale[3 * idx + 2] = dscale[2];
+    *reinterpret_cast<float4*>(dL_drot + 4 * (size_t)idx) = make_float4(drot[0], drot[1], drot[2], drot[3]);
+}
+
+void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const int* radii, const float* shs,
+                          const float* scales, const float* rotations, const float* cov3D_precomp, const SgrCam* cam,
+                          const SgrGeomView& gv, const float* partials, int row_stride, float* dL_dmean2D,
+                          float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                          float* dL_dscale, float* dL_drot, float* dL_dsemantic, hipStream_t s) {
+    if (P <= 0) return;
+    const unsigned nb = (P + SGR_GB_THREADS - 1) / SGR_GB_THREADS;
+#define SGR_GB(N)                                                                                                     \
+    sgr_gauss_bwd_kernel<N><<<nb, SGR_GB_THREADS, 0, s>>>(P, D, M, S, means3D, radii, shs, scales, rotations,           \
+                                                          cov3D_precomp, cam, gv, partials, row_stride, dL_dmean2D,   \
+                                                          dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,       \
+                                                          dL_dscale, dL_drot, dL_dsemantic)
+    if (S == 0) SGR_GB(0);
+    else if (S <= 4) SGR_GB(4);
+    else if (S <= 8) SGR_GB(8);
+    else if (S <= 16) SGR_GB(16);
+    else SGR_GB(32);
+#undef SGR_GB
+}

@@ -1,0 +1,364 @@
+// sgr_math.h -- per-Gaussian and per-(pixel,Gaussian) maths of the rasterizer, written as
+// __host__ __device__ inline functions so the very same code that the gfx950 kernels run can be
+// unit-tested on the host (tests/host_math, built by hipcc for x86) against the oracle.
+//
+// Everything that decides an INTEGER output (radius, tile rect, tiles_touched, depth sort key) is
+// evaluated with FP contraction off and in the operation order the reference's GLM code has
+// (forward.cu:74-152, auxiliary.h:41-77), with multiplications by literal zeros dropped (exact in
+// IEEE arithmetic), so radii / tiles / keys are bit-reproducible against oracle/sgr_oracle.c.
+#pragma once
+#include "sgr_common.h"
+#include <math.h>
+
+#define SGR_HD __host__ __device__ __forceinline__
+
+struct SgrCam {
+    float view[16];  // viewmatrix, flat (transposed / row-vector form)
+    float proj[16];  // full projection, flat
+    float campos[3];
+    float tan_fovx, tan_fovy, focal_x, focal_y;
+    int W, H;
+    int gx, gy;  // tile grid
+    float scale_modifier;
+};
+
+struct SgrProj {
+    float depth;       // view-space z
+    float px, py;      // pixel-space mean (ndc2Pix)
+    float cov_a, cov_b, cov_c;  // 2D covariance incl. +0.3 low-pass
+    float con_x, con_y, con_z;  // conic
+    int radius;
+    uint32_t rx0, ry0, rx1, ry1;  // tile rect
+    bool ok;
+};
+
+SGR_HD float sgr_ndc2pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
+
+SGR_HD void sgr_get_rect(float px, float py, int max_radius, int gx, int gy, uint32_t& x0, uint32_t& y0, uint32_t& x1,
+                         uint32_t& y1) {
+#pragma clang fp contract(off)
+    // auxiliary.h:46-56 -- float divide then C truncation
+    int a = (int)((px - max_radius) / SGR_BLOCK_X);
+    int b = (int)((py - max_radius) / SGR_BLOCK_Y);
+    int c = (int)((px + max_radius + SGR_BLOCK_X - 1) / SGR_BLOCK_X);
+    int d = (int)((py + max_radius + SGR_BLOCK_Y - 1) / SGR_BLOCK_Y);
+    a = a < 0 ? 0 : a; b = b < 0 ? 0 : b; c = c < 0 ? 0 : c; d = d < 0 ? 0 : d;
+    x0 = (uint32_t)(a > gx ? gx : a);
+    y0 = (uint32_t)(b > gy ? gy : b);
+    x1 = (uint32_t)(c > gx ? gx : c);
+    y1 = (uint32_t)(d > gy ? gy : d);
+}
+
+// forward.cu:118-152
+SGR_HD void sgr_cov3d(const float* scale, float mod, const float* rot, float* cov3D) {
+#pragma clang fp contract(off)
+    const float s0 = mod * scale[0], s1 = mod * scale[1], s2 = mod * scale[2];
+    const float r = rot[0], x = rot[1], y = rot[2], z = rot[3];
+    // GLM column c of R, then M[c][row] = s[row] * R[c][row]
+    const float M00 = s0 * (1.f - 2.f * (y * y + z * z)), M01 = s1 * (2.f * (x * y - r * z)), M02 = s2 * (2.f * (x * z + r * y));
+    const float M10 = s0 * (2.f * (x * y + r * z)), M11 = s1 * (1.f - 2.f * (x * x + z * z)), M12 = s2 * (2.f * (y * z - r * x));
+    const float M20 = s0 * (2.f * (x * z - r * y)), M21 = s1 * (2.f * (y * z + r * x)), M22 = s2 * (1.f - 2.f * (x * x + y * y));
+    // Sigma[c][row] = M[row][0]*M[c][0] + M[row][1]*M[c][1] + M[row][2]*M[c][2]
+    cov3D[0] = M00 * M00 + M01 * M01 + M02 * M02;  // Sigma[0][0]
+    cov3D[1] = M10 * M00 + M11 * M01 + M12 * M02;  // Sigma[0][1]
+    cov3D[2] = M20 * M00 + M21 * M01 + M22 * M02;  // Sigma[0][2]
+    cov3D[3] = M10 * M10 + M11 * M11 + M12 * M12;  // Sigma[1][1]
+    cov3D[4] = M20 * M10 + M21 * M11 + M22 * M12;  // Sigma[1][2]
+    cov3D[5] = M20 * M20 + M21 * M21 + M22 * M22;  // Sigma[2][2]
+}
+
+// forward.cu:155-256 geometry part (everything except SH) for one Gaussian.
+// Returns ok=false where the reference returns early (radius stays 0).
+SGR_HD SgrProj sgr_project(const float* p, const float* cov3D, const SgrCam& cam) {
+#pragma clang fp contract(off)
+    SgrProj o;
+    o.ok = false;
+    o.radius = 0;
+    const float* v = cam.view;
+    const float* m = cam.proj;
+    // auxiliary.h:58-66 / 139-164
+    float tx = v[0] * p[0] + v[4] * p[1] + v[8] * p[2] + v[12];
+    float ty = v[1] * p[0] + v[5] * p[1] + v[9] * p[2] + v[13];
+    const float tz = v[2] * p[0] + v[6] * p[1] + v[10] * p[2] + v[14];
+    o.depth = tz;
+    if (tz <= 0.2f) return o;
+    // auxiliary.h:68-77
+    const float hx = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
+    const float hy = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
+    const float hw = m[3] * p[0] + m[7] * p[1] + m[11] * p[2] + m[15];
+    const float p_w = 1.0f / (hw + 0.0000001f);
+    const float projx = hx * p_w, projy = hy * p_w;
+    // forward.cu:74-113
+    const float limx = 1.3f * cam.tan_fovx;
+    const float limy = 1.3f * cam.tan_fovy;
+    const float txtz = tx / tz;
+    const float tytz = ty / tz;
+    tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+    ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+    const float J00 = cam.focal_x / tz, J02 = -(cam.focal_x * tx) / (tz * tz);
+    const float J11 = cam.focal_y / tz, J12 = -(cam.focal_y * ty) / (tz * tz);
+    const float T00 = v[0] * J00 + v[2] * J02, T01 = v[4] * J00 + v[6] * J02, T02 = v[8] * J00 + v[10] * J02;
+    const float T10 = v[1] * J11 + v[2] * J12, T11 = v[5] * J11 + v[6] * J12, T12 = v[9] * J11 + v[10] * J12;
+    const float c0 = cov3D[0], c1 = cov3D[1], c2 = cov3D[2], c3 = cov3D[3], c4 = cov3D[4], c5 = cov3D[5];
+    const float X00 = T00 * c0 + T01 * c1 + T02 * c2, X10 = T00 * c1 + T01 * c3 + T02 * c4, X20 = T00 * c2 + T01 * c4 + T02 * c5;
+    const float X01 = T10 * c0 + T11 * c1 + T12 * c2, X11 = T10 * c1 + T11 * c3 + T12 * c4, X21 = T10 * c2 + T11 * c4 + T12 * c5;
+    float a = X00 * T00 + X10 * T01 + X20 * T02;
+    const float b = X01 * T00 + X11 * T01 + X21 * T02;
+    float c = X01 * T10 + X11 * T11 + X21 * T12;
+    a += 0.3f;
+    c += 0.3f;
+    o.cov_a = a; o.cov_b = b; o.cov_c = c;
+    const float det = (a * c - b * b);
+    if (det == 0.0f) return o;
+    const float det_inv = 1.f / det;
+    o.con_x = c * det_inv;
+    o.con_y = -b * det_inv;
+    o.con_z = a * det_inv;
+    const float mid = 0.5f * (a + c);
+    const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+    const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+    const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+    o.px = sgr_ndc2pix(projx, cam.W);
+    o.py = sgr_ndc2pix(projy, cam.H);
+    sgr_get_rect(o.px, o.py, (int)my_radius, cam.gx, cam.gy, o.rx0, o.ry0, o.rx1, o.ry1);
+    if ((o.rx1 - o.rx0) * (o.ry1 - o.ry0) == 0) return o;
+    o.radius = (int)my_radius;
+    o.ok = true;
+    return o;
+}
+
+// SH constants, auxiliary.h:22-39
+#define SGR_SH_C0 0.28209479177387814f
+#define SGR_SH_C1 0.4886025119029199f
+#define SGR_SH_C2_0 1.0925484305920792f
+#define SGR_SH_C2_1 -1.0925484305920792f
+#define SGR_SH_C2_2 0.31539156525252005f
+#define SGR_SH_C2_3 -1.0925484305920792f
+#define SGR_SH_C2_4 0.5462742152960396f
+#define SGR_SH_C3_0 -0.5900435899266435f
+#define SGR_SH_C3_1 2.890611442640554f
+#define SGR_SH_C3_2 -0.4570457994644658f
+#define SGR_SH_C3_3 0.3731763325901154f
+#define SGR_SH_C3_4 -0.4570457994644658f
+#define SGR_SH_C3_5 1.445305721320277f
+#define SGR_SH_C3_6 -0.5900435899266435f
+
+// SH basis Y_k(dir) for k < (deg+1)^2, forward.cu:30-59 (basis[0] = C0 etc.; signs folded in)
+SGR_HD void sgr_sh_basis(int deg, float x, float y, float z, float* Y) {
+    Y[0] = SGR_SH_C0;
+    if (deg > 0) {
+        Y[1] = -SGR_SH_C1 * y;
+        Y[2] = SGR_SH_C1 * z;
+        Y[3] = -SGR_SH_C1 * x;
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            Y[4] = SGR_SH_C2_0 * xy;
+            Y[5] = SGR_SH_C2_1 * yz;
+            Y[6] = SGR_SH_C2_2 * (2.0f * zz - xx - yy);
+            Y[7] = SGR_SH_C2_3 * xz;
+            Y[8] = SGR_SH_C2_4 * (xx - yy);
+            if (deg > 2) {
+                Y[9] = SGR_SH_C3_0 * y * (3.0f * xx - yy);
+                Y[10] = SGR_SH_C3_1 * xy * z;
+                Y[11] = SGR_SH_C3_2 * y * (4.0f * zz - xx - yy);
+                Y[12] = SGR_SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+                Y[13] = SGR_SH_C3_4 * x * (4.0f * zz - xx - yy);
+                Y[14] = SGR_SH_C3_5 * z * (xx - yy);
+                Y[15] = SGR_SH_C3_6 * x * (xx - 3.0f * yy);
+            }
+        }
+    }
+}
+
+// Conservative half extents (in pixels) of the region where a Gaussian can reach
+// alpha >= 1/255, i.e. power >= -ln(255*opacity) (forward.cu:428-430).  The region is the ellipse
+// d^T conic d <= 2*tau whose axis-aligned bounding box has half widths sqrt(2*tau*cov_xx),
+// sqrt(2*tau*cov_yy) (conic = cov^-1).  Inflated (tau*1.02+0.05, then +1% +0.25 px) so that fp32
+// rounding of `power` in the blend kernels can never accept a pair outside the box; a negative
+// extent means "can never contribute".  NaN opacity yields NaN extents = "never culled".
+SGR_HD void sgr_extent(float opacity, float cov_a, float cov_c, float& hx, float& hy) {
+    if (opacity < 0.0039f) {  // < 1/255 (with slack): alpha = min(.99, o*G) <= o can never pass
+        hx = -1.0f;
+        hy = -1.0f;
+        return;
+    }
+    float tau = logf(255.0f * opacity);
+    tau = fmaxf(tau, 0.0f) * 1.02f + 0.05f;
+    hx = sqrtf(2.0f * tau * cov_a) * 1.01f + 0.25f;
+    hy = sqrtf(2.0f * tau * cov_c) * 1.01f + 0.25f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-(pixel, Gaussian) evaluation shared by the forward and backward blend kernels.  The conic is
+// pre-scaled when a tile list is staged into LDS:  qa = -0.5*log2e*conic.x, qb = -log2e*conic.y,
+// qc = -0.5*log2e*conic.z, so that  power*log2e = qa*dx*dx + qb*dx*dy + qc*dy*dy  and
+// G = exp(power) = exp2(power*log2e) is a single v_exp_f32.  Explicit fmaf + contraction off: the
+// forward and backward kernels must evaluate bit-identical alpha for the same pair
+// (forward.cu:423-430 vs backward.cu:536-545).
+SGR_HD float sgr_power2(float qa, float qb, float qc, float dx, float dy) {
+#pragma clang fp contract(off)
+    const float u = fmaf(qb, dy, qa * dx);  // qa*dx + qb*dy
+    return fmaf(qc * dy, dy, u * dx);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-Gaussian backward maths (float tolerance only, so contraction is left to the compiler).
+
+// backward.cu:144-274 (computeCov2DCUDA): dL/dconic -> dL/dcov3D[6] and the covariance part of
+// dL/dmean (ASSIGNED).  T/Vrk/W index pairs below are the reference's glm [col][row] pairs.
+SGR_HD void sgr_cov2d_backward(const float* p, const float* cov3D, const SgrCam& cam, float dcx, float dcy, float dcw,
+                               float* dL_dcov, float* dL_dmean) {
+    const float* v = cam.view;
+    float tx = v[0] * p[0] + v[4] * p[1] + v[8] * p[2] + v[12];
+    float ty = v[1] * p[0] + v[5] * p[1] + v[9] * p[2] + v[13];
+    const float tz = v[2] * p[0] + v[6] * p[1] + v[10] * p[2] + v[14];
+    const float limx = 1.3f * cam.tan_fovx, limy = 1.3f * cam.tan_fovy;
+    const float txtz = tx / tz, tytz = ty / tz;
+    tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+    ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+    const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+    const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+    const float h_x = cam.focal_x, h_y = cam.focal_y;
+    const float J00 = h_x / tz, J02 = -(h_x * tx) / (tz * tz), J11 = h_y / tz, J12 = -(h_y * ty) / (tz * tz);
+    const float T00 = v[0] * J00 + v[2] * J02, T01 = v[4] * J00 + v[6] * J02, T02 = v[8] * J00 + v[10] * J02;
+    const float T10 = v[1] * J11 + v[2] * J12, T11 = v[5] * J11 + v[6] * J12, T12 = v[9] * J11 + v[10] * J12;
+    const float V00 = cov3D[0], V01 = cov3D[1], V02 = cov3D[2], V11 = cov3D[3], V12 = cov3D[4], V22 = cov3D[5];
+    // rows of T*Vrk (reused by cov2D and by dL/dT)
+    const float A0x = T00 * V00 + T01 * V01 + T02 * V02, A0y = T00 * V01 + T01 * V11 + T02 * V12, A0z = T00 * V02 + T01 * V12 + T02 * V22;
+    const float A1x = T10 * V00 + T11 * V01 + T12 * V02, A1y = T10 * V01 + T11 * V11 + T12 * V12, A1z = T10 * V02 + T11 * V12 + T12 * V22;
+    const float a = A0x * T00 + A0y * T01 + A0z * T02 + 0.3f;
+    const float b = A1x * T00 + A1y * T01 + A1z * T02;
+    const float c = A1x * T10 + A1y * T11 + A1z * T12 + 0.3f;
+    const float denom = a * c - b * b;
+    float dL_da = 0, dL_db = 0, dL_dc = 0;
+    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    if (denom2inv != 0) {
+        dL_da = denom2inv * (-c * c * dcx + 2 * b * c * dcy + (denom - a * c) * dcw);
+        dL_dc = denom2inv * (-a * a * dcw + 2 * a * b * dcy + (denom - a * c) * dcx);
+        dL_db = denom2inv * 2 * (b * c * dcx - (denom + 2 * b * b) * dcy + a * b * dcw);
+        dL_dcov[0] = (T00 * T00 * dL_da + T00 * T10 * dL_db + T10 * T10 * dL_dc);
+        dL_dcov[3] = (T01 * T01 * dL_da + T01 * T11 * dL_db + T11 * T11 * dL_dc);
+        dL_dcov[5] = (T02 * T02 * dL_da + T02 * T12 * dL_db + T12 * T12 * dL_dc);
+        dL_dcov[1] = 2 * T00 * T01 * dL_da + (T00 * T11 + T01 * T10) * dL_db + 2 * T10 * T11 * dL_dc;
+        dL_dcov[2] = 2 * T00 * T02 * dL_da + (T00 * T12 + T02 * T10) * dL_db + 2 * T10 * T12 * dL_dc;
+        dL_dcov[4] = 2 * T02 * T01 * dL_da + (T01 * T12 + T02 * T11) * dL_db + 2 * T11 * T12 * dL_dc;
+    } else {
+        for (int i = 0; i < 6; i++) dL_dcov[i] = 0;
+    }
+    const float dL_dT00 = 2 * A0x * dL_da + A1x * dL_db;
+    const float dL_dT01 = 2 * A0y * dL_da + A1y * dL_db;
+    const float dL_dT02 = 2 * A0z * dL_da + A1z * dL_db;
+    const float dL_dT10 = 2 * A1x * dL_dc + A0x * dL_db;
+    const float dL_dT11 = 2 * A1y * dL_dc + A0y * dL_db;
+    const float dL_dT12 = 2 * A1z * dL_dc + A0z * dL_db;
+    const float dL_dJ00 = v[0] * dL_dT00 + v[4] * dL_dT01 + v[8] * dL_dT02;
+    const float dL_dJ02 = v[2] * dL_dT00 + v[6] * dL_dT01 + v[10] * dL_dT02;
+    const float dL_dJ11 = v[1] * dL_dT10 + v[5] * dL_dT11 + v[9] * dL_dT12;
+    const float dL_dJ12 = v[2] * dL_dT10 + v[6] * dL_dT11 + v[10] * dL_dT12;
+    const float itz = 1.f / tz, itz2 = itz * itz, itz3 = itz2 * itz;
+    const float dL_dtx = x_grad_mul * -h_x * itz2 * dL_dJ02;
+    const float dL_dty = y_grad_mul * -h_y * itz2 * dL_dJ12;
+    const float dL_dtz = -h_x * itz2 * dL_dJ00 - h_y * itz2 * dL_dJ11 + (2 * h_x * tx) * itz3 * dL_dJ02 +
+                         (2 * h_y * ty) * itz3 * dL_dJ12;
+    // transformVec4x3Transpose (auxiliary.h:89-97)
+    dL_dmean[0] = v[0] * dL_dtx + v[1] * dL_dty + v[2] * dL_dtz;
+    dL_dmean[1] = v[4] * dL_dtx + v[5] * dL_dty + v[6] * dL_dtz;
+    dL_dmean[2] = v[8] * dL_dtx + v[9] * dL_dty + v[10] * dL_dtz;
+}
+
+// backward.cu:371-403: projection and depth paths, ADDED to dL_dmean
+SGR_HD void sgr_proj_depth_backward(const float* m, const SgrCam& cam, float g2x, float g2y, float ddepth,
+                                    float* dL_dmean) {
+    const float* proj = cam.proj;
+    const float* view = cam.view;
+    const float hw = proj[3] * m[0] + proj[7] * m[1] + proj[11] * m[2] + proj[15];
+    const float m_w = 1.0f / (hw + 0.0000001f);
+    const float mul1 = (proj[0] * m[0] + proj[4] * m[1] + proj[8] * m[2] + proj[12]) * m_w * m_w;
+    const float mul2 = (proj[1] * m[0] + proj[5] * m[1] + proj[9] * m[2] + proj[13]) * m_w * m_w;
+    dL_dmean[0] += (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
+    dL_dmean[1] += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
+    dL_dmean[2] += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
+    const float mul3 = view[2] * m[0] + view[6] * m[1] + view[10] * m[2] + view[14];
+    dL_dmean[0] += (view[2] - view[3] * mul3) * ddepth;
+    dL_dmean[1] += (view[6] - view[7] * mul3) * ddepth;
+    dL_dmean[2] += (view[10] - view[11] * mul3) * ddepth;
+}
+
+// backward.cu:20-139: given normalised dir (x,y,z), SH row `sh` (3 floats per coefficient) and the
+// (clamp-masked) dL/dRGB, returns dL/ddir; the caller applies dnormvdv.  dY/d{x,y,z} of the basis
+// functions, coefficient by coefficient.
+SGR_HD void sgr_sh_dir_backward(int deg, float x, float y, float z, const float* sh, const float* dRGB, float* dL_ddir) {
+    float dx[3] = {0, 0, 0}, dy[3] = {0, 0, 0}, dz[3] = {0, 0, 0};
+#define SGR_S(k, ch) sh[3 * (k) + (ch)]
+    for (int ch = 0; ch < 3; ch++) {
+        if (deg > 0) {
+            dx[ch] = -SGR_SH_C1 * SGR_S(3, ch);
+            dy[ch] = -SGR_SH_C1 * SGR_S(1, ch);
+            dz[ch] = SGR_SH_C1 * SGR_S(2, ch);
+            if (deg > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                dx[ch] += SGR_SH_C2_0 * y * SGR_S(4, ch) + SGR_SH_C2_2 * 2.f * -x * SGR_S(6, ch) + SGR_SH_C2_3 * z * SGR_S(7, ch) +
+                          SGR_SH_C2_4 * 2.f * x * SGR_S(8, ch);
+                dy[ch] += SGR_SH_C2_0 * x * SGR_S(4, ch) + SGR_SH_C2_1 * z * SGR_S(5, ch) + SGR_SH_C2_2 * 2.f * -y * SGR_S(6, ch) +
+                          SGR_SH_C2_4 * 2.f * -y * SGR_S(8, ch);
+                dz[ch] += SGR_SH_C2_1 * y * SGR_S(5, ch) + SGR_SH_C2_2 * 2.f * 2.f * z * SGR_S(6, ch) + SGR_SH_C2_3 * x * SGR_S(7, ch);
+                if (deg > 2) {
+                    dx[ch] += (SGR_SH_C3_0 * SGR_S(9, ch) * 3.f * 2.f * xy + SGR_SH_C3_1 * SGR_S(10, ch) * yz +
+                               SGR_SH_C3_2 * SGR_S(11, ch) * -2.f * xy + SGR_SH_C3_3 * SGR_S(12, ch) * -3.f * 2.f * xz +
+                               SGR_SH_C3_4 * SGR_S(13, ch) * (-3.f * xx + 4.f * zz - yy) + SGR_SH_C3_5 * SGR_S(14, ch) * 2.f * xz +
+                               SGR_SH_C3_6 * SGR_S(15, ch) * 3.f * (xx - yy));
+                    dy[ch] += (SGR_SH_C3_0 * SGR_S(9, ch) * 3.f * (xx - yy) + SGR_SH_C3_1 * SGR_S(10, ch) * xz +
+                               SGR_SH_C3_2 * SGR_S(11, ch) * (-3.f * yy + 4.f * zz - xx) + SGR_SH_C3_3 * SGR_S(12, ch) * -3.f * 2.f * yz +
+                               SGR_SH_C3_4 * SGR_S(13, ch) * -2.f * xy + SGR_SH_C3_5 * SGR_S(14, ch) * -2.f * yz +
+                               SGR_SH_C3_6 * SGR_S(15, ch) * -3.f * 2.f * xy);
+                    dz[ch] += (SGR_SH_C3_1 * SGR_S(10, ch) * xy + SGR_SH_C3_2 * SGR_S(11, ch) * 4.f * 2.f * yz +
+                               SGR_SH_C3_3 * SGR_S(12, ch) * 3.f * (2.f * zz - xx - yy) + SGR_SH_C3_4 * SGR_S(13, ch) * 4.f * 2.f * xz +
+                               SGR_SH_C3_5 * SGR_S(14, ch) * (xx - yy));
+                }
+            }
+        }
+    }
+#undef SGR_S
+    dL_ddir[0] = dx[0] * dRGB[0] + dx[1] * dRGB[1] + dx[2] * dRGB[2];
+    dL_ddir[1] = dy[0] * dRGB[0] + dy[1] * dRGB[1] + dy[2] * dRGB[2];
+    dL_ddir[2] = dz[0] * dRGB[0] + dz[1] * dRGB[1] + dz[2] * dRGB[2];
+}
+
+// auxiliary.h:107-117
+SGR_HD void sgr_dnormvdv(const float* v, const float* dv, float* out) {
+    const float sum2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    out[0] = ((+sum2 - v[0] * v[0]) * dv[0] - v[1] * v[0] * dv[1] - v[2] * v[0] * dv[2]) * invsum32;
+    out[1] = (-v[0] * v[1] * dv[0] + (sum2 - v[1] * v[1]) * dv[1] - v[2] * v[1] * dv[2]) * invsum32;
+    out[2] = (-v[0] * v[2] * dv[0] - v[1] * v[2] * dv[1] + (sum2 - v[2] * v[2]) * dv[2]) * invsum32;
+}
+
+// backward.cu:278-341 (computeCov3D backward).  R/M/dM are indexed [col][row] like the glm code.
+SGR_HD void sgr_cov3d_backward(const float* scale, float mod, const float* rot, const float* dL_dcov3D, float* dL_dscale,
+                               float* dL_drot) {
+    const float r = rot[0], x = rot[1], y = rot[2], z = rot[3];
+    const float R[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+                           {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+                           {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
+    const float s[3] = {mod * scale[0], mod * scale[1], mod * scale[2]};
+    float M2[3][3];  // 2*M, M[c][row] = s[row]*R[c][row]
+    for (int c = 0; c < 3; c++)
+        for (int k = 0; k < 3; k++) M2[c][k] = 2.0f * (s[k] * R[c][k]);
+    const float dS[3][3] = {{dL_dcov3D[0], 0.5f * dL_dcov3D[1], 0.5f * dL_dcov3D[2]},
+                            {0.5f * dL_dcov3D[1], dL_dcov3D[3], 0.5f * dL_dcov3D[4]},
+                            {0.5f * dL_dcov3D[2], 0.5f * dL_dcov3D[4], dL_dcov3D[5]}};
+    float dM[3][3];  // dM[c][row] = sum_k M2[k][row] * dS[c][k]
+    for (int c = 0; c < 3; c++)
+        for (int k = 0; k < 3; k++) dM[c][k] = M2[0][k] * dS[c][0] + M2[1][k] * dS[c][1] + M2[2][k] * dS[c][2];
+    // Rt[i][k] = R[k][i], dMt[i][k] = dM[k][i]; dL_dscale[i] = dot(Rt[i], dMt[i])
+    for (int i = 0; i < 3; i++) dL_dscale[i] = R[0][i] * dM[0][i] + R[1][i] * dM[1][i] + R[2][i] * dM[2][i];
+#define SGR_MT(i, j) (s[i] * dM[j][i])
+    dL_drot[0] = 2 * z * (SGR_MT(0, 1) - SGR_MT(1, 0)) + 2 * y * (SGR_MT(2, 0) - SGR_MT(0, 2)) + 2 * x * (SGR_MT(1, 2) - SGR_MT(2, 1));
+    dL_drot[1] = 2 * y * (SGR_MT(1, 0) + SGR_MT(0, 1)) + 2 * z * (SGR_MT(2, 0) + SGR_MT(0, 2)) + 2 * r * (SGR_MT(1, 2) - SGR_MT(2, 1)) -
+                 4 * x * (SGR_MT(2, 2) + SGR_MT(1, 1));
+    dL_drot[2] = 2 * x * (SGR_MT(1, 0) + SGR_MT(0, 1)) + 2 * r * (SGR_MT(2, 0) - SGR_MT(0, 2)) + 2 * z * (SGR_MT(1, 2) + SGR_MT(2, 1)) -
+                 4 * y * (SGR_MT(2, 2) + SGR_MT(0, 0));
+    dL_drot[3] = 2 * r * (SGR_MT(0, 1) - SGR_MT(1, 0)) + 2 * x * (SGR_MT(2, 0) + SGR_MT(0, 2)) + 2 * y * (SGR_MT(1, 2) + SGR_MT(2, 1)) -
+                 4 * z * (SGR_MT(1, 1) + SGR_MT(0, 0));
+#undef SGR_MT
+}

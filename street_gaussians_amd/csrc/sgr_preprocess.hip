@@ -1,0 +1,222 @@
+// sgr_preprocess.hip -- per-Gaussian forward stage for gfx950:
+//   K1 mark_visible, K2 preprocess (cull + EWA projection + SH->RGB), K3 visible_filter,
+//   K6 duplicate-with-keys.
+// Replaces checkFrustum / preprocessCUDA / filter_preprocessCUDA / duplicateWithKeys of the reference
+// (rasterizer_impl.cu:54-111, forward.cu:155-334).  One Gaussian per lane, 256-lane workgroups; the
+// outputs are packed into three float4 records per Gaussian so that the tile kernels gather each
+// instance with three 16-byte loads.
+#include "sgr_math.h"
+
+#define SGR_PRE_THREADS 256
+
+__device__ __forceinline__ uint32_t sgr_pack_rect(uint32_t x0, uint32_t y0, uint32_t w) {
+    return x0 | (y0 << 10) | (w << 20);
+}
+
+// ---- K1 -------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(SGR_PRE_THREADS)
+sgr_mark_visible_kernel(int P, const float* __restrict__ means3D, const SgrCam* __restrict__ camp, uint8_t* __restrict__ present) {
+#pragma clang fp contract(off)
+    const SgrCam& cam = *camp;
+    const int idx = blockIdx.x * SGR_PRE_THREADS + threadIdx.x;
+    if (idx >= P) return;
+    const float* v = cam.view;
+    const float x = means3D[3 * idx], y = means3D[3 * idx + 1], z = means3D[3 * idx + 2];
+    const float tz = v[2] * x + v[6] * y + v[10] * z + v[14];
+    present[idx] = tz <= 0.2f ? 0 : 1;
+}
+
+// ---- K2 / K3 ----------------------------------------------------------------------------------
+template <bool FILTER>
+__global__ void __launch_bounds__(SGR_PRE_THREADS)
+sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
+                      const float* __restrict__ rotations, const float* __restrict__ opacities,
+                      const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
+                      const float* __restrict__ colors_precomp, const SgrCam* __restrict__ camp, SgrGeomView gv,
+                      int* __restrict__ radii, float* __restrict__ filter_means2D, int prefiltered) {
+    const SgrCam& cam = *camp;
+    const int idx = blockIdx.x * SGR_PRE_THREADS + threadIdx.x;
+    if (idx >= P) return;
+
+    const float p[3] = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+    float tz;
+    {
+#pragma clang fp contract(off)
+        const float* v = cam.view;
+        tz = v[2] * p[0] + v[6] * p[1] + v[10] * p[2] + v[14];
+    }
+    SgrProj pr;
+    pr.ok = false;
+    if (tz > 0.2f) {
+        float cov3D[6];
+        if (cov3D_precomp != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) cov3D[i] = cov3D_precomp[6 * (size_t)idx + i];
+        } else {
+            const float sc[3] = {scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]};
+            const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)idx);
+            const float rot[4] = {q.x, q.y, q.z, q.w};
+            sgr_cov3d(sc, cam.scale_modifier, rot, cov3D);
+            if (!FILTER) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) gv.cov3D[6 * (size_t)idx + i] = cov3D[i];
+            }
+        }
+        pr = sgr_project(p, cov3D, cam);
+    } else if (prefiltered) {
+        if (gv.header) atomicOr(&gv.header[0], 1u);  // reference: printf + __trap() (auxiliary.h:156-161); we raise on the host
+    }
+
+    if (!pr.ok) {
+        radii[idx] = 0;
+        if (!FILTER) gv.tiles_touched[idx] = 0;
+        return;
+    }
+    if (FILTER) {
+        radii[idx] = pr.radius;
+        filter_means2D[2 * idx] = pr.px;
+        filter_means2D[2 * idx + 1] = pr.py;
+        return;
+    }
+
+    // colour: precomputed, or SH -> RGB (forward.cu:20-71)
+    float rgb[3];
+    uint32_t clamped = 0;
+    if (colors_precomp != nullptr) {
+        rgb[0] = colors_precomp[3 * idx];
+        rgb[1] = colors_precomp[3 * idx + 1];
+        rgb[2] = colors_precomp[3 * idx + 2];
+    } else {
+#pragma clang fp contract(off)
+        float dx = p[0] - cam.campos[0], dy = p[1] - cam.campos[1], dz = p[2] - cam.campos[2];
+        const float t0 = dx * dx, t1 = dy * dy, t2 = dz * dz;
+        const float len = sqrtf(t0 + t1 + t2);
+        dx = dx / len; dy = dy / len; dz = dz / len;
+        float Y[16];
+        sgr_sh_basis(D, dx, dy, dz, Y);
+        const int ncoef = (D + 1) * (D + 1);
+        const float* sh = shs + (size_t)idx * M * 3;
+        float r = 0.f, g = 0.f, b = 0.f;
+        if (((M * 3) & 3) == 0) {
+            // row stride is a multiple of 16 B: stream the row as float4 (12 loads at SH degree 3)
+            const float4* sh4 = reinterpret_cast<const float4*>(sh);
+            const int n4 = (ncoef * 3 + 3) >> 2;
+            float buf[48];
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                if (i < n4) {
+                    const float4 t = sh4[i];
+                    buf[4 * i] = t.x; buf[4 * i + 1] = t.y; buf[4 * i + 2] = t.z; buf[4 * i + 3] = t.w;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (k < ncoef) {
+                    if (k == 0) { r = Y[0] * buf[0]; g = Y[0] * buf[1]; b = Y[0] * buf[2]; }
+                    else { r = r + Y[k] * buf[3 * k]; g = g + Y[k] * buf[3 * k + 1]; b = b + Y[k] * buf[3 * k + 2]; }
+                }
+            }
+        } else {
+            for (int k = 0; k < ncoef; k++) {
+                if (k == 0) { r = Y[0] * sh[0]; g = Y[0] * sh[1]; b = Y[0] * sh[2]; }
+                else { r = r + Y[k] * sh[3 * k]; g = g + Y[k] * sh[3 * k + 1]; b = b + Y[k] * sh[3 * k + 2]; }
+            }
+        }
+        r += 0.5f; g += 0.5f; b += 0.5f;
+        clamped = (r < 0 ? 1u : 0u) | (g < 0 ? 2u : 0u) | (b < 0 ? 4u : 0u);
+        rgb[0] = fmaxf(r, 0.0f); rgb[1] = fmaxf(g, 0.0f); rgb[2] = fmaxf(b, 0.0f);
+    }
+
+    const float opacity = opacities[idx];
+    float hx, hy;
+    sgr_extent(opacity, pr.cov_a, pr.cov_c, hx, hy);
+    const uint32_t w = pr.rx1 - pr.rx0, h = pr.ry1 - pr.ry0;
+    gv.recA[idx] = make_float4(pr.px, pr.py, hx, hy);
+    gv.recB[idx] = make_float4(pr.con_x, pr.con_y, pr.con_z, opacity);
+    gv.recC[idx] = make_float4(rgb[0], rgb[1], rgb[2], pr.depth);
+    gv.recD[idx] = make_uint2(0u, sgr_pack_rect(pr.rx0, pr.ry0, w));
+    gv.clamped[idx] = clamped;
+    gv.tiles_touched[idx] = w * h;
+    radii[idx] = pr.radius;
+}
+
+// ---- K6: one (key, value) per overlapped tile, row-major tile order (rasterizer_impl.cu:70-111) ----
+__global__ void __launch_bounds__(SGR_PRE_THREADS)
+sgr_duplicate_kernel(int P, SgrGeomView gv, const int* __restrict__ radii, uint64_t* __restrict__ keys,
+                     uint32_t* __restrict__ vals, int gx) {
+    const int idx = blockIdx.x * SGR_PRE_THREADS + threadIdx.x;
+    if (idx >= P) return;
+    if (!(radii[idx] > 0)) return;
+    uint32_t off = (idx == 0) ? 0u : gv.point_offsets[idx - 1];
+    const uint32_t n = gv.tiles_touched[idx];
+    uint2 d = gv.recD[idx];
+    d.x = off;
+    gv.recD[idx] = d;
+    const uint32_t x0 = d.y & 1023u, y0 = (d.y >> 10) & 1023u, w = d.y >> 20;
+    const uint32_t h = n / w;
+    const uint64_t depth_bits = (uint64_t)__float_as_uint(gv.recC[idx].w);
+    for (uint32_t y = y0; y < y0 + h; y++) {
+        for (uint32_t x = x0; x < x0 + w; x++) {
+            uint64_t key = (uint64_t)(y * (uint32_t)gx + x);
+            key <<= 32;
+            key |= depth_bits;
+            keys[off] = key;
+            vals[off] = (uint32_t)idx;
+            off++;
+        }
+    }
+}
+
+// ---- K9: tile ranges from the sorted keys (rasterizer_impl.cu:116-138) ------------------------
+__global__ void __launch_bounds__(256)
+sgr_tile_ranges_kernel(int L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= L) return;
+    const uint32_t currtile = (uint32_t)(keys[idx] >> 32);
+    if (idx == 0) {
+        ranges[currtile].x = 0;
+    } else {
+        const uint32_t prevtile = (uint32_t)(keys[idx - 1] >> 32);
+        if (currtile != prevtile) {
+            ranges[prevtile].y = idx;
+            ranges[currtile].x = idx;
+        }
+    }
+    if (idx == L - 1) ranges[currtile].y = L;
+}
+
+// ---- host launchers ---------------------------------------------------------------------------
+void sgr_launch_mark_visible(int P, const float* means3D, const SgrCam* cam, uint8_t* present, hipStream_t s) {
+    if (P <= 0) return;
+    sgr_mark_visible_kernel<<<(P + SGR_PRE_THREADS - 1) / SGR_PRE_THREADS, SGR_PRE_THREADS, 0, s>>>(P, means3D, cam, present);
+}
+
+void sgr_launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, const float* rotations,
+                           const float* opacities, const float* shs, const float* cov3D_precomp,
+                           const float* colors_precomp, const SgrCam* cam, const SgrGeomView& gv, int* radii,
+                           int prefiltered, hipStream_t s) {
+    if (P <= 0) return;
+    sgr_preprocess_kernel<false><<<(P + SGR_PRE_THREADS - 1) / SGR_PRE_THREADS, SGR_PRE_THREADS, 0, s>>>(
+        P, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, cam, gv, radii, nullptr,
+        prefiltered);
+}
+
+void sgr_launch_filter(int P, const float* means3D, const float* scales, const float* rotations,
+                       const float* cov3D_precomp, const SgrCam* cam, const SgrGeomView& gv, int* radii,
+                       float* means2D, int prefiltered, hipStream_t s) {
+    if (P <= 0) return;
+    sgr_preprocess_kernel<true><<<(P + SGR_PRE_THREADS - 1) / SGR_PRE_THREADS, SGR_PRE_THREADS, 0, s>>>(
+        P, 0, 0, means3D, scales, rotations, nullptr, nullptr, cov3D_precomp, nullptr, cam, gv, radii, means2D,
+        prefiltered);
+}
+
+void sgr_launch_duplicate(int P, const SgrGeomView& gv, const int* radii, uint64_t* keys, uint32_t* vals, int gx,
+                          hipStream_t s) {
+    if (P <= 0) return;
+    sgr_duplicate_kernel<<<(P + SGR_PRE_THREADS - 1) / SGR_PRE_THREADS, SGR_PRE_THREADS, 0, s>>>(P, gv, radii, keys, vals, gx);
+}
+
+void sgr_launch_tile_ranges(int L, const uint64_t* keys, uint2* ranges, hipStream_t s) {
+    if (L <= 0) return;
+    sgr_tile_ranges_kernel<<<(L + 255) / 256, 256, 0, s>>>(L, keys, ranges);
+}

@@ -1,0 +1,200 @@
+// sgr_scan_sort.hip -- hand-written device-wide prefix scan (K4) and stable LSD radix sort of
+// (u64 key, u32 value) pairs (K7) for gfx950, replacing cub::DeviceScan::InclusiveSum and
+// cub::DeviceRadixSort::SortPairs (rasterizer_impl.cu:280,306-311) and, with 32-bit keys widened
+// to 64, simple-knn's Morton sort (simple_knn.cu:210-213).
+//
+// Scan: reduce-then-scan over 2048-element blocks; wave64 shuffles inside a block.
+// Sort: 8-bit digits.  Per pass: an LDS-privatised per-block digit histogram, one exclusive scan of
+// the [digit][block] table, and a scatter that ranks its 2048-key block with a wave64
+// ballot-match (8 ballots per key give the set of lanes sharing the digit; popcount of the lower
+// lanes is the stable rank) and per-wave LDS digit counters -- no atomics, fully deterministic.
+#include "sgr_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// wave / block primitives
+__device__ __forceinline__ uint32_t sgr_wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread over a 256-thread block; returns block total in `total`
+__device__ __forceinline__ uint32_t sgr_block_excl_scan256(uint32_t v, uint32_t* lds4, uint32_t& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t inc = sgr_wave_incl_scan(v, lane);
+    if (lane == 63) lds4[wave] = inc;
+    __syncthreads();
+    const uint32_t w0 = lds4[0], w1 = lds4[1], w2 = lds4[2], w3 = lds4[3];
+    __syncthreads();
+    const uint32_t base = (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);
+    total = w0 + w1 + w2 + w3;
+    return base + inc - v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// scan kernels: ITEMS = 2048 per block = 256 threads x 8 consecutive elements
+__global__ void __launch_bounds__(256) sgr_scan_reduce_kernel(const uint32_t* __restrict__ in, size_t n,
+                                                              uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t lds4[4];
+    const size_t base = (size_t)blockIdx.x * SGR_SCAN_ITEMS + (size_t)threadIdx.x * 8;
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if (base + i < n) s += in[base + i];
+    uint32_t total;
+    sgr_block_excl_scan256(s, lds4, total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of block_sums[0..nb) in place; block_sums[nb] = grand total
+__global__ void __launch_bounds__(256) sgr_scan_spine_kernel(uint32_t* __restrict__ block_sums, size_t nb) {
+    __shared__ uint32_t lds4[4];
+    uint32_t carry = 0;
+    for (size_t start = 0; start < nb; start += 256) {
+        const size_t i = start + threadIdx.x;
+        const uint32_t v = i < nb ? block_sums[i] : 0;
+        uint32_t total;
+        const uint32_t ex = sgr_block_excl_scan256(v, lds4, total);
+        if (i < nb) block_sums[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) block_sums[nb] = carry;
+}
+
+template <bool INCLUSIVE>
+__global__ void __launch_bounds__(256) sgr_scan_final_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                             size_t n, const uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t lds4[4];
+    const size_t base = (size_t)blockIdx.x * SGR_SCAN_ITEMS + (size_t)threadIdx.x * 8;
+    uint32_t v[8];
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        v[i] = (base + i < n) ? in[base + i] : 0;
+        s += v[i];
+    }
+    uint32_t total;
+    uint32_t run = sgr_block_excl_scan256(s, lds4, total) + block_sums[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (INCLUSIVE) run += v[i];
+        if (base + i < n) out[base + i] = run;
+        if (!INCLUSIVE) run += v[i];
+    }
+}
+
+// out may alias in.  tmp needs sgr_scan_tmp_count(n) words; tmp[nblocks] receives the grand total.
+void sgr_launch_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, bool inclusive, hipStream_t s) {
+    if (n == 0) return;
+    const size_t nb = (n + SGR_SCAN_ITEMS - 1) / SGR_SCAN_ITEMS;
+    sgr_scan_reduce_kernel<<<(unsigned)nb, 256, 0, s>>>(in, n, tmp);
+    sgr_scan_spine_kernel<<<1, 256, 0, s>>>(tmp, nb);
+    if (inclusive) sgr_scan_final_kernel<true><<<(unsigned)nb, 256, 0, s>>>(in, out, n, tmp);
+    else sgr_scan_final_kernel<false><<<(unsigned)nb, 256, 0, s>>>(in, out, n, tmp);
+}
+
+// ------------------------------------------------------------------------------------------------
+// radix sort
+// block b owns keys [b*2048, (b+1)*2048); wave w of the block owns 512 consecutive keys, read in 8
+// steps of 64 (lane l <-> key base + w*512 + step*64 + l), so memory order == (wave, step, lane).
+__global__ void __launch_bounds__(256)
+sgr_sort_hist_kernel(const uint64_t* __restrict__ keys, uint32_t n, int shift, uint32_t nblocks,
+                     uint32_t* __restrict__ hist) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * SGR_SORT_ITEMS;
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const uint32_t i = base + s * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];  // [digit][block]
+}
+
+__global__ void __launch_bounds__(256)
+sgr_sort_scatter_kernel(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin, uint64_t* __restrict__ kout,
+                        uint32_t* __restrict__ vout, uint32_t n, int shift, uint32_t nblocks,
+                        const uint32_t* __restrict__ hist_scanned) {
+    __shared__ uint32_t cnt[4][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int w = 0; w < 4; w++) cnt[w][tid] = 0;
+    __syncthreads();
+
+    const uint32_t base = blockIdx.x * SGR_SORT_ITEMS + wave * 512;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    uint64_t key[8];
+    uint32_t val[8], rnk[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const uint32_t i = base + s * 64 + lane;
+        const bool valid = i < n;
+        key[s] = valid ? kin[i] : 0ull;
+        val[s] = valid ? vin[i] : 0u;
+        const uint32_t d = (uint32_t)(key[s] >> shift) & 255u;
+        uint64_t m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t bal = __ballot(valid && bit);
+            m &= bit ? bal : ~bal;
+        }
+        const uint32_t prefix = __popcll(m & lt_mask);
+        const uint32_t count = __popcll(m);
+        uint32_t prev = 0;
+        if (valid && prefix == 0) {  // lowest lane of each digit group: bump this wave's counter
+            prev = cnt[wave][d];
+            cnt[wave][d] = prev + count;
+        }
+        const int leader = m ? (__ffsll((unsigned long long)m) - 1) : lane;
+        prev = __shfl(prev, leader, 64);
+        rnk[s] = prev + prefix;
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    {
+        const uint32_t c0 = cnt[0][tid], c1 = cnt[1][tid], c2 = cnt[2][tid];
+        const uint32_t g = hist_scanned[(size_t)tid * nblocks + blockIdx.x];
+        __syncthreads();
+        cnt[0][tid] = g;
+        cnt[1][tid] = g + c0;
+        cnt[2][tid] = g + c0 + c1;
+        cnt[3][tid] = g + c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const uint32_t i = base + s * 64 + lane;
+        if (i < n) {
+            const uint32_t d = (uint32_t)(key[s] >> shift) & 255u;
+            const uint32_t pos = cnt[wave][d] + rnk[s];
+            kout[pos] = key[s];
+            vout[pos] = val[s];
+        }
+    }
+}
+
+// Sorts n pairs on key bits [0, end_bit).  keys[0]/vals[0] hold the input; returns the index (0/1)
+// of the pair of buffers that holds the sorted output.  hist: 256*nblocks words (+ scan_tmp).
+// The per-block digit histogram depends on where the previous pass left the keys, so it is
+// recomputed before every scatter pass.
+int sgr_launch_sort_pairs(uint64_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
+                          uint32_t* scan_tmp, hipStream_t s) {
+    if (n == 0) return 0;
+    const int npass = (end_bit + 7) / 8;
+    const uint32_t nblocks = (n + SGR_SORT_ITEMS - 1) / SGR_SORT_ITEMS;
+    int cur = 0;
+    for (int p = 0; p < npass; p++) {
+        sgr_sort_hist_kernel<<<nblocks, 256, 0, s>>>(keys[cur], n, 8 * p, nblocks, hist);
+        sgr_launch_scan(hist, hist, (size_t)256 * nblocks, scan_tmp, false, s);
+        sgr_sort_scatter_kernel<<<nblocks, 256, 0, s>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, 8 * p,
+                                                        nblocks, hist);
+        cur ^= 1;
+    }
+    return cur;
+}

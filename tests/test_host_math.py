@@ -1,0 +1,115 @@
+"""The maths header the gfx950 kernels run (street_gaussians_amd/csrc/sgr_math.h), compiled for the
+host, against the oracle: integer outputs and the geometry floats must be BIT-EXACT (contraction is
+off on both sides), per-Gaussian gradients within 1e-4.  No GPU needed."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, oracle_kwargs, small_case
+from oracle import oracle
+from street_gaussians_amd import synthetic as syn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "host_math", "host_math.hip")
+HDR = os.path.join(HERE, "..", "street_gaussians_amd", "csrc", "sgr_math.h")
+LIB = os.path.join(HERE, "_build", "libsgr_hostmath.so")
+
+
+@pytest.fixture(scope="module")
+def hm():
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-x", "hip", "--cuda-host-only", "-O2", "-fPIC", "-shared",
+                               "-std=c++17", SRC, "-o", LIB])
+    L = C.CDLL(LIB)
+    L.hm_power2.restype = C.c_float
+    L.hm_power2.argtypes = [C.c_float] * 5
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f(t):
+    return np.ascontiguousarray(t.detach().cpu().numpy() if hasattr(t, "detach") else t, dtype=np.float32)
+
+
+@pytest.mark.parametrize("deg,margin,scale_px", [(3, 1.1, 0.01), (1, 1.7, 0.03), (0, 1.1, 0.002)])
+def test_forward_geometry_bit_exact_and_backward_close(hm, deg, margin, scale_px):
+    cam = syn.make_camera(200, 120, fx=210.0, yaw_deg=7.0, translation=(0.1, -0.05, 0.3))
+    sc = syn.make_scene(5000, cam, S=0, seed=11, margin=margin, zmin=0.15, zmax=30.0, scale_px=scale_px)
+    sc.shs[::3, 0, :] -= 2.5  # some clamped colours
+    fw = oracle.forward(**oracle_kwargs(cam, sc, deg=deg))
+    P, M = sc.P, sc.shs.shape[1]
+    W, H = cam.image_width, cam.image_height
+    means, scales, rots, opac, shs = map(_f, (sc.means3D, sc.scales, sc.rotations, sc.opacities, sc.shs))
+    view, proj, campos = map(_f, (cam.viewmatrix, cam.projmatrix, cam.campos))
+    radii = np.zeros(P, np.int32); m2d = np.zeros((P, 2), np.float32); depths = np.zeros(P, np.float32)
+    conic = np.zeros((P, 3), np.float32); cov3D = np.zeros((P, 6), np.float32); tiles = np.zeros(P, np.uint32)
+    rgb = np.zeros((P, 3), np.float32); clamped = np.zeros((P, 3), np.uint8); ext = np.zeros((P, 2), np.float32)
+    hm.hm_forward(P, deg, M, _p(means), _p(scales), _p(rots), _p(opac), _p(shs), _p(view), _p(proj), _p(campos),
+                  C.c_float(cam.tanfovx), C.c_float(cam.tanfovy), W, H, C.c_float(1.0), _p(radii), _p(m2d), _p(depths),
+                  _p(conic), _p(cov3D), _p(tiles), _p(rgb), _p(clamped), _p(ext))
+    vis = fw.radii > 0
+    assert vis.sum() > 1000 and (~vis).sum() > 10
+    assert (radii == fw.radii).all()
+    assert (tiles == fw.tiles_touched).all()
+    assert (m2d[vis] == fw.means2D[vis]).all()
+    assert (depths[vis] == fw.depths[vis]).all()
+    assert (conic[vis] == fw.conic_opacity[vis, :3]).all()
+    front = depths > 0.2
+    assert (cov3D[front] == fw.cov3D[front]).all()
+    assert (clamped[vis] == fw.clamped[vis]).all() and fw.clamped.sum() > 0
+    assert np.abs(rgb[vis] - fw.rgb[vis]).max() <= 1e-6
+
+    # conservative extents: every (pixel, Gaussian) pair the oracle's blend accepts lies inside the box
+    pl, rg = fw.point_list, fw.ranges
+    gx = (W + 15) // 16
+    worst = 0.0
+    for t in range(rg.shape[0]):
+        ids = pl[rg[t, 0]:rg[t, 1]]
+        if len(ids) == 0:
+            continue
+        ty, tx = divmod(t, gx)
+        ys, xs = np.meshgrid(np.arange(ty * 16, min(ty * 16 + 16, H)), np.arange(tx * 16, min(tx * 16 + 16, W)), indexing="ij")
+        dx = fw.means2D[ids, 0][:, None, None] - xs[None].astype(np.float32)
+        dy = fw.means2D[ids, 1][:, None, None] - ys[None].astype(np.float32)
+        co = fw.conic_opacity[ids]
+        power = -0.5 * (co[:, 0, None, None] * dx * dx + co[:, 2, None, None] * dy * dy) - co[:, 1, None, None] * dx * dy
+        alpha = np.minimum(0.99, co[:, 3, None, None] * np.exp(power))
+        acc = (power <= 0) & (alpha >= 1.0 / 255.0)
+        outside = (np.abs(dx) > ext[ids, 0][:, None, None]) | (np.abs(dy) > ext[ids, 1][:, None, None])
+        assert not (acc & outside).any()
+        if acc.any():
+            worst = max(worst, (np.abs(dx)[acc] / ext[ids, 0][:, None, None].repeat(dx.shape[1], 1).repeat(dx.shape[2], 2)[acc]).max())
+    assert 0.5 < worst <= 1.0  # the box is conservative but not vacuous
+
+    wts = syn.loss_weights(cam)
+    g = oracle.backward(fw, wts["color"], wts["depth"], wts["alpha"], None)
+    dmean3D = np.zeros((P, 3), np.float32); dcov = np.zeros((P, 6), np.float32); dscale = np.zeros((P, 3), np.float32)
+    drot = np.zeros((P, 4), np.float32); dsh = np.zeros((P, M, 3), np.float32)
+    hm.hm_backward(P, deg, M, _p(means), _p(scales), _p(rots), _p(shs), _p(fw.cov3D), _p(fw.clamped), _p(fw.radii),
+                   _p(view), _p(proj), _p(campos), C.c_float(cam.tanfovx), C.c_float(cam.tanfovy), W, H, C.c_float(1.0),
+                   _p(g["means2D"]), _p(g["conic"].reshape(P, 4)), _p(g["colors"]), _p(g["depths"].reshape(P)),
+                   _p(dmean3D), _p(dcov), _p(dscale), _p(drot), _p(dsh))
+    for name, a, b in [("means3D", dmean3D, g["means3D"]), ("cov3D", dcov, g["cov3D"]), ("scales", dscale, g["scales"]),
+                       ("rotations", drot, g["rotations"]), ("sh", dsh, g["sh"])]:
+        assert_close(a, b, rel=1e-4, floor=1e-6, name=name)
+    fw.free()
+
+
+def test_power2_matches_reference_expression(hm):
+    rng = np.random.default_rng(0)
+    LOG2E = np.float32(1.4426950408889634)
+    for _ in range(2000):
+        A, C_, B = rng.uniform(0.001, 3.0), rng.uniform(0.001, 3.0), rng.uniform(-1, 1)
+        dx, dy = rng.uniform(-20, 20, 2)
+        ref = (-0.5 * (A * dx * dx + C_ * dy * dy) - B * dx * dy) * 1.4426950408889634
+        qa, qb, qc = np.float32(-0.5) * LOG2E * np.float32(A), -LOG2E * np.float32(B), np.float32(-0.5) * LOG2E * np.float32(C_)
+        got = hm.hm_power2(C.c_float(qa), C.c_float(qb), C.c_float(qc), C.c_float(dx), C.c_float(dy))
+        assert abs(got - ref) <= 2e-6 * max(1.0, A * dx * dx + C_ * dy * dy + abs(B * dx * dy))
