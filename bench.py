@@ -1,0 +1,237 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X-native Gaussian rasterizer.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): train iters/s (rasterizer forward + backward) at 1M synthetic Gaussians, 1920x1280,
+SH degree 3.  One "step" = one `GaussianRasterizer(...)` forward plus `.backward()` of a scalar loss that touches
+colour, depth and alpha with dense random per-pixel weights, inputs resident in HBM.  With N > 1 every rank renders
+its own camera view of the replicated Gaussian set (weak scaling: per-GPU work fixed) and the per-Gaussian gradients
+are all-reduced over RCCL each step (street_gaussians_amd/multiview.py).  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline     -- the dominant kernel (blend backward): algorithmic bytes per launch (SURVEY.md 8d B_blend_b)
+                  divided by its mean duration measured with HIP events on the launch stream (sgr_profile_*),
+                  against the 8 TB/s HBM peak; "stages_ms" lists every stage, "pairs_per_s" the honest unit for
+                  this ALU/LDS-bound kernel.
+  cpu_baseline -- the C oracle (a line-by-line port of the reference algorithm; the reference has no CPU path)
+                  on the host's cores, on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from street_gaussians_amd import synthetic as syn  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+STAGES = ["preprocess", "scan", "duplicate", "sort", "tile_ranges", "blend_fwd", "partials_memset", "blend_bwd",
+          "gauss_bwd"]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1280)
+    ap.add_argument("--semantics", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-gaussians", type=int, default=0, help="override the CPU sample size")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, cam, sc):
+    """Times the oracle (port of the reference algorithm) on a bounded sample: the same scene and camera but
+    only the central 1/16 of the image (480x320 window at the same focal length), so depth complexity per pixel
+    is the workload's.  Preprocess still visits all P Gaussians, like the reference would."""
+    from oracle import oracle
+    Ws, Hs = max(16, args.width // 4), max(16, args.height // 4)
+    fx = args.width / (2.0 * cam.tanfovx)
+    cams = syn.make_camera(Ws, Hs, fx=fx)
+    w = syn.loss_weights(cams, S=0)
+    kw = dict(means3D=sc.means3D, opacities=sc.opacities, viewmatrix=cams.viewmatrix, projmatrix=cams.projmatrix,
+              campos=cams.campos, bg=torch.zeros(3), tanfovx=cams.tanfovx, tanfovy=cams.tanfovy, image_height=Hs,
+              image_width=Ws, sh_degree=3, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+    best = None
+    for _ in range(2):
+        t0 = time.time()
+        fw = oracle.forward(internals=False, **kw)
+        oracle.backward(fw, w["color"], w["depth"], w["alpha"], None, parallel=True)
+        dt = time.time() - t0
+        R = fw.num_rendered
+        fw.free()
+        best = dt if best is None else min(best, dt)
+        if dt > 20:
+            break
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": round(1.0 / best, 4), "unit": "iters/s on the sample", "cores": cores, "kind": "port",
+            "sample": f"oracle fwd+bwd (OpenMP), all {sc.P} Gaussians, central {Ws}x{Hs} window = 1/16 of the "
+                      f"{args.width}x{args.height} pixels (R={R}); full-frame rate ~ value/16",
+            "seconds": round(best, 3)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from street_gaussians_amd import _native, multiview
+
+    # identical Gaussians on every rank (seed 0); rank r renders view r (yawed r*5 degrees)
+    cam0 = syn.make_camera(args.width, args.height, fx=2050.0 * args.width / 1920.0)
+    scene = syn.make_scene(args.gaussians, cam0, sh_degree_max=3, S=args.semantics, seed=0)
+    cam = syn.make_camera(args.width, args.height, fx=2050.0 * args.width / 1920.0, yaw_deg=5.0 * rank)
+    S = args.semantics
+    params = {k: getattr(scene, k).to(dev).requires_grad_(True)
+              for k in ["means3D", "scales", "rotations", "opacities", "shs"]}
+    if S:
+        params["semantics"] = scene.semantics.to(dev).requires_grad_(True)
+    means2D = torch.zeros(scene.P, 3, device=dev, requires_grad=True)
+    w = {k: v.to(dev) for k, v in syn.loss_weights(cam, S=S, seed=1 + rank).items()}
+    st = GaussianRasterizationSettings(
+        image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+        bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=cam.viewmatrix.to(dev),
+        projmatrix=cam.projmatrix.to(dev), sh_degree=3, campos=cam.campos.to(dev), prefiltered=False, debug=False)
+    rast = GaussianRasterizer(st)
+    reducer = multiview.GradReducer(list(params.values()) + [means2D]) if world > 1 else None
+    stats = {}
+
+    def step():
+        for p in list(params.values()) + [means2D]:
+            p.grad = None
+        color, radii, depth, alpha, sem = rast(params["means3D"], means2D, params["opacities"], shs=params["shs"],
+                                               scales=params["scales"], rotations=params["rotations"],
+                                               semantics=params.get("semantics"))
+        loss = (color * w["color"]).sum() + (depth * w["depth"]).sum() + (alpha * w["alpha"]).sum()
+        if S:
+            loss = loss + (sem * w["semantic"]).sum()
+        loss.backward()
+        if reducer is not None:
+            reducer.all_reduce()
+        stats["radii"] = radii
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    L = _native.lib()
+    L.sgr_profile_enable(1)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    sums = (C.c_double * 9)()
+    counts = (C.c_int * 9)()
+    L.sgr_profile_read(sums, counts)
+    L.sgr_profile_enable(0)
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    # workload statistics (R/P and V/P must be reported with every number)
+    V = int((stats["radii"] > 0).sum().item())
+    from street_gaussians_amd import _C as native
+    out = native.rasterize_gaussians(st.bg, params["means3D"].detach(), torch.Tensor([]),
+                                     torch.zeros(scene.P, 0, device=dev), params["opacities"].detach(),
+                                     params["scales"].detach(), params["rotations"].detach(), 1.0, torch.Tensor([]),
+                                     st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy, st.image_height,
+                                     st.image_width, params["shs"].detach(), 3, st.campos, False, False)
+    R = int(out[0])
+    n_contrib = native.export_internal("n_contrib", scene.P, R, args.height, args.width, out[6], out[7], out[8])
+    pairs_blended = int(n_contrib.to(torch.int64).sum().item())  # upper bound of pairs walked per pixel
+    N = args.width * args.height
+
+    if rank == 0:
+        stage_ms = {STAGES[i]: (sums[i] / counts[i] if counts[i] else None) for i in range(9)}
+        bwd_ms = stage_ms["blend_bwd"]
+        # B_blend_b = (44+4S)*R + (28+4S)*N + (48+4S)*V   algorithmic bytes per launch
+        algo_bytes = (44 + 4 * S) * R + (28 + 4 * S) * N + (48 + 4 * S) * V
+        achieved = algo_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms else None
+        fwd_ms = stage_ms["blend_fwd"]
+        fwd_bytes = (44 + 4 * S) * R + (24 + 4 * S) * N
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_blend_bwd.json")
+        if os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile))
+                if tj.get("gaussians") == args.gaussians and tj.get("width") == args.width:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "train iters/s (fwd+bwd) @1M Gaussians 1920x1280 SH3",
+            "value": round(world * args.steps / dt, 3),
+            "unit": "iters/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.gaussians} synthetic Gaussians (SURVEY 8d recipe, seed 0), "
+                                   f"{args.width}x{args.height}, SH degree 3, S={S} semantic channels, "
+                                   f"rasterizer forward+backward, one camera view per GPU",
+                       "gaussians": args.gaussians, "width": args.width, "height": args.height, "sh_degree": 3,
+                       "semantic_channels": S, "views_per_step": world, "num_rendered_R": R, "visible_V": V,
+                       "R_over_P": round(R / args.gaussians, 3), "V_over_P": round(V / args.gaussians, 3),
+                       "parallelism": f"view-dp{world}" + (" + RCCL all-reduce of Gaussian grads" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "kernel": "sgr_blend_bwd_kernel",
+                         "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "kernel_ms": round(bwd_ms, 4) if bwd_ms else None,
+                         "blend_fwd": {"kernel_ms": round(fwd_ms, 4) if fwd_ms else None,
+                                       "achieved": round(fwd_bytes / (fwd_ms * 1e-3) / 1e9, 2) if fwd_ms else None,
+                                       "algorithmic_bytes_per_launch": fwd_bytes},
+                         "stages_ms": {k: (round(v, 4) if v is not None else None) for k, v in stage_ms.items()},
+                         "sum_n_contrib_pairs": pairs_blended,
+                         "note": "blend kernels are VALU/exp/LDS bound (SURVEY 8d); HBM fraction is reported as the "
+                                 "metric demands, stage times are HIP-event means over the timed region"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                line["cpu_baseline"] = cpu_baseline(args, cam0, scene)
+            except Exception as ex:  # the baseline is a reported extra; never lose the GPU number over it
+                line["cpu_baseline"] = {"value": None, "unit": "iters/s", "cores": os.cpu_count(), "kind": "port",
+                                        "sample": f"failed: {ex}"}
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

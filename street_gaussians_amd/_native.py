@@ -21,7 +21,7 @@ SYMBOLS = [
     "sgr_last_error", "sgr_version", "sgr_forward", "sgr_backward", "sgr_mark_visible", "sgr_visible_filter",
     "sgr_knn", "sgr_geometry_bytes", "sgr_binning_bytes", "sgr_image_bytes", "sgr_partial_row_floats",
     "sgr_export_internal", "sgr_test_scan", "sgr_test_sort", "sgr_test_sort_hist_words", "sgr_test_scan_tmp_words",
-    "sgr_test_wave_sum",
+    "sgr_test_wave_sum", "sgr_profile_enable", "sgr_profile_read",
 ]
 
 
@@ -67,6 +67,10 @@ def lib():
         L.sgr_test_sort.argtypes = [vp, vp, vp, vp, C.c_uint32, i, vp, vp, vp]
         L.sgr_test_wave_sum.restype = i
         L.sgr_test_wave_sum.argtypes = [vp, vp, vp, i, vp]
+        L.sgr_profile_enable.restype = i
+        L.sgr_profile_enable.argtypes = [i]
+        L.sgr_profile_read.restype = i
+        L.sgr_profile_read.argtypes = [vp, vp]
         L.sgr_partial_row_floats.restype = i
         L.sgr_partial_row_floats.argtypes = [i]
         _lib = L

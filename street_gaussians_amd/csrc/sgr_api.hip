@@ -46,6 +46,30 @@ int sgr_knn_impl(int P, const float* points, float* meanDists, sgr_alloc_fn scra
 
 static thread_local std::string g_err;
 
+// ---- optional per-stage timing with HIP events on the caller's stream (sgr_profile_*) -------------------
+// stages: 0 preprocess(+camera pack, memsets) 1 scan 2 duplicate 3 sort 4 tile_ranges 5 blend_fwd
+//         6 partials memset 7 blend_bwd 8 gauss_bwd
+#define SGR_PROF_STAGES 9
+#define SGR_PROF_SLOTS 512
+struct SgrProf {
+    bool on = false;
+    int n = 0;  // recorded (begin,end) pairs
+    hipEvent_t ev[SGR_PROF_SLOTS][2];
+    int stage[SGR_PROF_SLOTS];
+    bool created = false;
+};
+static SgrProf g_prof;
+static void prof_begin(int stage, hipStream_t s) {
+    if (!g_prof.on || g_prof.n >= SGR_PROF_SLOTS) return;
+    g_prof.stage[g_prof.n] = stage;
+    (void)hipEventRecord(g_prof.ev[g_prof.n][0], s);
+}
+static void prof_end(hipStream_t s) {
+    if (!g_prof.on || g_prof.n >= SGR_PROF_SLOTS) return;
+    (void)hipEventRecord(g_prof.ev[g_prof.n][1], s);
+    g_prof.n++;
+}
+
 static int fail(int code, const std::string& msg) {
     g_err = msg;
     return -code;
@@ -174,6 +198,7 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     const SgrImgView iv = sgr_img_carve(ibase, N, T);
     int* radii_ptr = radii ? radii : gv.internal_radii;  // rasterizer_impl.cu:232-235
 
+    prof_begin(0, stream);
     SGR_HIP(hipMemsetAsync(gv.header, 0, 16 * sizeof(uint32_t), stream));
     SGR_HIP(hipMemsetAsync(iv.ranges, 0, T * sizeof(uint2), stream));  // rasterizer_impl.cu:313
     pack_camera(gv, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, W, H, scale_modifier, stream);
@@ -182,10 +207,13 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     sgr_launch_preprocess(P, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
                           cam_slot(gv), gv, radii_ptr, prefiltered, stream);
     SGR_STAGE("preprocess");
+    prof_end(stream);
 
     // K4 + K5: inclusive scan, then read back num_rendered (+ the prefilter flag) -- the one host sync
+    prof_begin(1, stream);
     sgr_launch_scan(gv.tiles_touched, gv.point_offsets, (size_t)P, gv.scan_tmp, true, stream);
     SGR_STAGE("scan");
+    prof_end(stream);
     const size_t nb = ((size_t)P + SGR_SCAN_ITEMS - 1) / SGR_SCAN_ITEMS;
     uint32_t host_vals[2] = {0, 0};
     SGR_HIP(hipMemcpyAsync(&host_vals[0], gv.scan_tmp + nb, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -202,18 +230,26 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
 
     int cur = 0;
     if (R > 0) {
+        prof_begin(2, stream);
         sgr_launch_duplicate(P, gv, radii_ptr, bv.keys[0], bv.vals[0], gx, stream);
         SGR_STAGE("duplicate");
+        prof_end(stream);
+        prof_begin(3, stream);
         const int bit = (int)getHigherMsb((uint32_t)T);  // rasterizer_impl.cu:303
         cur = sgr_launch_sort_pairs(bv.keys, bv.vals, (uint32_t)R, 32 + bit, bv.hist, bv.scan_tmp, stream);
         SGR_STAGE("sort");
+        prof_end(stream);
+        prof_begin(4, stream);
         sgr_launch_tile_ranges(R, bv.keys[cur], iv.ranges, stream);
         SGR_STAGE("tile_ranges");
+        prof_end(stream);
     }
+    prof_begin(5, stream);
     const bool cull = !env_flag("SGR_NO_CULL");
     sgr_launch_blend_fwd(cull, gx, gy, iv.ranges, bv.vals[cur], W, H, S, gv.recA, gv.recB, gv.recC, semantics,
                          background, out_color, out_depth, out_alpha, out_semantic, iv.n_contrib, stream);
     SGR_STAGE("blend_fwd");
+    prof_end(stream);
     return R;
 }
 
@@ -254,18 +290,52 @@ int sgr_backward(int P, int D, int M, int R, int S, const float* background, int
         const size_t bytes = (size_t)R * stride * sizeof(float);
         partials = (float*)scratch(bytes, scratch_user);
         if (!partials) return fail(SGR_E_ALLOC, "backward scratch allocation failed");
+        prof_begin(6, stream);
         SGR_HIP(hipMemsetAsync(partials, 0, bytes, stream));
+        prof_end(stream);
+        prof_begin(7, stream);
         const bool cull = !env_flag("SGR_NO_CULL"), dpp = !env_flag("SGR_NO_DPP");
         sgr_launch_blend_bwd(cull, dpp, gx, gy, iv.ranges, bv.vals[cur], W, H, S, background, gv.recA, gv.recB, gv.recC,
                              gv.recD, semantics, alphas, iv.n_contrib, dL_dpix, dL_dpix_depth, dL_dalphas,
                              dL_dpix_semantic, partials, stream);
         SGR_STAGE("blend_bwd");
+        prof_end(stream);
     }
+    prof_begin(8, stream);
     sgr_launch_gauss_bwd(P, D, M, S, means3D, radii_ptr, shs, scales, rotations, cov3D_precomp, cam_slot(gv), gv, partials,
                          stride, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
                          dL_dsemantic, stream);
     SGR_STAGE("gauss_bwd");
+    prof_end(stream);
     return 0;
+}
+
+int sgr_profile_enable(int on) {
+    if (on && !g_prof.created) {
+        for (int i = 0; i < SGR_PROF_SLOTS; i++)
+            for (int k = 0; k < 2; k++)
+                if (hipEventCreate(&g_prof.ev[i][k]) != hipSuccess) return fail(SGR_E_HIP, "hipEventCreate failed");
+        g_prof.created = true;
+    }
+    g_prof.on = on != 0;
+    g_prof.n = 0;
+    return 0;
+}
+
+// Sums the recorded stage durations (ms) since sgr_profile_enable(1) and resets the recorder.
+int sgr_profile_read(double* sum_ms, int* counts) {
+    for (int i = 0; i < SGR_PROF_STAGES; i++) { sum_ms[i] = 0.0; counts[i] = 0; }
+    if (!g_prof.created) return 0;
+    SGR_HIP(hipDeviceSynchronize());
+    for (int i = 0; i < g_prof.n; i++) {
+        float ms = 0.f;
+        SGR_HIP(hipEventElapsedTime(&ms, g_prof.ev[i][0], g_prof.ev[i][1]));
+        sum_ms[g_prof.stage[i]] += ms;
+        counts[g_prof.stage[i]]++;
+    }
+    const int n = g_prof.n;
+    g_prof.n = 0;
+    return n;
 }
 
 // scratch for the two small entry points below: a camera block only

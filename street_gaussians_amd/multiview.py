@@ -1,0 +1,86 @@
+"""Multi-GPU use of the rasterizer: camera views shard across ranks, Gaussians are replicated.
+
+The reference is single-process / single-GPU; this module is what BASELINE.json's north_star
+adds: each rank runs an independent ``rasterizer(...)`` + ``.backward()`` for its own view (no data-path
+collective), then ONE exchange step sums the per-Gaussian parameter gradients over RCCL/xGMI
+(`torch.distributed` backend "nccl" is RCCL on ROCm).  Gradients are packed into a single contiguous fp32
+bucket so a step issues one large collective (236 B per Gaussian at SH degree 3) instead of
+one per tensor; on the 8-GPU xGMI mesh a reduce-scatter + all-gather pair keeps all seven links busy, so that
+is what ``mode="rs_ag"`` issues explicitly (the default lets RCCL choose).
+
+Also combines the densification statistics the training loop derives from the rasterizer outputs
+(/root/reference/lib/models/street_gaussian_model.py:551-571): sums for the view-space gradient accumulators,
+max for the screen radii.  Works with the gloo backend on CPU tensors (tests/test_multiview_gloo.py).
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    """All-reduce (sum) of the ``.grad`` of a fixed list of parameters through one flat bucket."""
+
+    def __init__(self, params: Iterable[torch.Tensor], group: Optional[dist.ProcessGroup] = None, mode: str = "all_reduce",
+                 average: bool = False):
+        self.params: List[torch.Tensor] = list(params)
+        self.group = group
+        self.mode = mode
+        self.average = average
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._numel = [p.numel() for p in self.params]
+        total = sum(self._numel)
+        pad = (-total) % max(self.world, 1)  # reduce_scatter needs equal shards
+        ref = self.params[0]
+        self.flat = torch.zeros(total + pad, dtype=torch.float32, device=ref.device)
+        self._views = []
+        off = 0
+        for p, n in zip(self.params, self._numel):
+            self._views.append(self.flat[off:off + n].view(p.shape))
+            off += n
+
+    @property
+    def nbytes(self) -> int:
+        return self.flat.numel() * 4
+
+    def all_reduce(self) -> None:
+        """Sum gradients over all ranks; ``p.grad`` is replaced by a view of the reduced bucket."""
+        if self.world == 1:
+            return
+        grads = [p.grad if p.grad is not None else torch.zeros_like(v) for p, v in zip(self.params, self._views)]
+        torch._foreach_copy_(self._views, grads)
+        if self.mode == "rs_ag":
+            shard = self.flat.numel() // self.world
+            rank = dist.get_rank(self.group)
+            mine = self.flat[rank * shard:(rank + 1) * shard]
+            dist.reduce_scatter_tensor(mine, self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_gather_into_tensor(self.flat, mine.clone(), group=self.group)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        if self.average:
+            self.flat.div_(self.world)
+        for p, v in zip(self.params, self._views):
+            p.grad = v
+
+
+def reduce_densification_stats(xyz_gradient_accum: torch.Tensor, denom: torch.Tensor, max_radii2D: torch.Tensor,
+                               group: Optional[dist.ProcessGroup] = None) -> None:
+    """In-place combination of the per-view densification statistics across ranks: sums for the gradient-norm
+    accumulators and their denominators, max for the radii."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    packed = torch.cat([xyz_gradient_accum.reshape(-1).float(), denom.reshape(-1).float()])
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    n = xyz_gradient_accum.numel()
+    xyz_gradient_accum.copy_(packed[:n].view_as(xyz_gradient_accum))
+    denom.copy_(packed[n:].view_as(denom))
+    dist.all_reduce(max_radii2D, op=dist.ReduceOp.MAX, group=group)
+
+
+def view_for_rank(views: list, step: int, rank: Optional[int] = None, world: Optional[int] = None):
+    """Round-robin view assignment: at step s rank r renders view (s*world + r) mod len(views)."""
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    return views[(step * world + rank) % len(views)]

@@ -1,0 +1,98 @@
+"""Helpers shared by the `-m gpu` parity tests: run the HIP path through the drop-in API and pull
+its internal arrays out through the C ABI."""
+import numpy as np
+import torch
+
+from street_gaussians_amd import _C
+
+
+def dev(t):
+    return None if t is None else t.detach().to("cuda").contiguous()
+
+
+def settings(cam, deg=3, bg=None, scale_modifier=1.0, debug=False, prefiltered=False):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    bg = torch.zeros(3) if bg is None else bg
+    return GaussianRasterizationSettings(
+        image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+        bg=dev(bg.float()), scale_modifier=scale_modifier, viewmatrix=dev(cam.viewmatrix), projmatrix=dev(cam.projmatrix),
+        sh_degree=deg, campos=dev(cam.campos), prefiltered=prefiltered, debug=debug)
+
+
+def raw_forward(kw):
+    """kw: the oracle-style keyword dict (tests/helpers.oracle_kwargs).  Calls the native forward and
+    returns (outputs dict, internals getter)."""
+    e = torch.Tensor([])
+    g = lambda k: dev(kw[k]) if kw.get(k) is not None else e
+    P = kw["means3D"].shape[0]
+    sem = dev(kw["semantics"]) if kw.get("semantics") is not None else torch.zeros(P, 0, device="cuda")
+    out = _C.rasterize_gaussians(dev(kw["bg"].float()), g("means3D"), g("colors_precomp"), sem, g("opacities"),
+                                 g("scales"), g("rotations"), kw.get("scale_modifier", 1.0), g("cov3D_precomp"),
+                                 g("viewmatrix"), g("projmatrix"), kw["tanfovx"], kw["tanfovy"], kw["image_height"],
+                                 kw["image_width"], g("shs"), kw["sh_degree"], g("campos"), False, True)
+    R, color, depth, alpha, semantic, radii, gb, bb, ib = out
+    res = dict(R=R, color=color, depth=depth, alpha=alpha, semantic=semantic, radii=radii, geom=gb, binning=bb, img=ib)
+
+    def internal(name):
+        return _C.export_internal(name, P, R, kw["image_height"], kw["image_width"], gb, bb, ib)
+    return res, internal
+
+
+def raw_backward(kw, res, wts):
+    e = torch.Tensor([])
+    g = lambda k: dev(kw[k]) if kw.get(k) is not None else e
+    P = kw["means3D"].shape[0]
+    sem = dev(kw["semantics"]) if kw.get("semantics") is not None else torch.zeros(P, 0, device="cuda")
+    S = sem.shape[1]
+    H, W = kw["image_height"], kw["image_width"]
+    gsem = dev(wts["semantic"].float()) if S else torch.zeros(0, H, W, device="cuda")
+    outs = _C.rasterize_gaussians_backward(
+        dev(kw["bg"].float()), g("means3D"), res["radii"], g("colors_precomp"), g("scales"), g("rotations"),
+        kw.get("scale_modifier", 1.0), g("cov3D_precomp"), g("viewmatrix"), g("projmatrix"), kw["tanfovx"],
+        kw["tanfovy"], dev(wts["color"].float()), dev(wts["depth"].float()), dev(wts["alpha"].float()), gsem, g("shs"),
+        kw["sh_degree"], g("campos"), res["geom"], res["R"], res["binning"], res["img"], res["alpha"], sem, True)
+    names = ["means2D", "colors", "opacity", "means3D", "cov3D", "sh", "scales", "rotations", "semantics"]
+    return dict(zip(names, outs))
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def image_close(a, b, rel=1e-4, name="", max_outliers=None, outlier_cap=0.05):
+    """Float images: |a-b| <= rel*max(|a|,|b|,floor).  A handful of pixels may differ by one
+    alpha-threshold flip (exp() differs in the last ulp between v_exp_f32 and libm, SURVEY 7
+    "Transcendentals"); they are counted, bounded and reported."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    if a.size == 0:
+        return 0
+    scale = max(np.abs(b).max(), 1e-12)
+    tol = rel * np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-2 * scale)
+    bad = np.abs(a - b) > tol
+    nbad = int(bad.sum())
+    if max_outliers is None:
+        max_outliers = max(3, int(3e-5 * a.size))
+    if nbad:
+        worst = np.abs(a - b)[bad].max()
+        assert nbad <= max_outliers, f"{name}: {nbad}/{a.size} elements outside rel={rel}; worst abs err {worst}"
+        assert worst <= outlier_cap * scale, f"{name}: outlier error {worst} exceeds one-flip bound {outlier_cap * scale}"
+    return nbad
+
+
+def grad_close(a, b, rel=1e-4, name="", max_outlier_frac=2e-3, floor_frac=1e-4):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    if a.size == 0:
+        return
+    scale = max(np.abs(b).max(), 1e-30)
+    tol = rel * np.maximum(np.maximum(np.abs(a), np.abs(b)), floor_frac * scale / rel * rel)
+    tol = np.maximum(tol, rel * floor_frac * scale * 10)
+    bad = np.abs(a - b) > tol
+    frac = bad.mean()
+    assert frac <= max_outlier_frac, (f"{name}: {bad.sum()}/{a.size} outside rel={rel} "
+                                      f"(worst abs {np.abs(a - b).max()} at scale {scale})")
+    # even the outliers stay small relative to the tensor's scale
+    assert np.abs(a - b).max() <= 2e-2 * scale, f"{name}: worst abs {np.abs(a - b).max()} vs scale {scale}"

@@ -1,0 +1,34 @@
+"""Pins the C oracle against the golden fixtures (outputs of the reference's own kernels on MI355X,
+tests/golden/README.md).  CPU only."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from gpu_utils import grad_close, image_close
+from oracle import oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FILES = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", FILES or [None])
+def test_oracle_reproduces_reference_kernels(path):
+    if path is None:
+        pytest.skip("no golden fixtures committed yet")
+    from golden.make_golden import GRADS, load_case
+    kw, wts, gold = load_case(path)
+    fw = oracle.forward(**kw)
+    assert fw.num_rendered == int(gold["num_rendered"])
+    assert (fw.radii == gold["radii"]).all()
+    assert (fw.tiles_touched == gold["tiles_touched"]).all()
+    assert (fw.point_list == gold["point_list"]).all()
+    assert (fw.ranges == gold["ranges"]).all()
+    for k in ["color", "depth", "alpha", "semantic"]:
+        image_close(getattr(fw, k), gold[k], name=k)
+    assert (fw.n_contrib != gold["n_contrib"].reshape(fw.n_contrib.shape)).mean() <= 1e-3
+    g = oracle.backward(fw, wts["color"], wts["depth"], wts["alpha"], wts["semantic"])
+    for k in GRADS:
+        grad_close(g[k], gold["g_" + k].reshape(g[k].shape), name=k)
+    fw.free()

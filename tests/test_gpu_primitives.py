@@ -1,0 +1,81 @@
+"""GPU tests of the hand-written primitives (scan, stable radix sort, DPP wave reduction) through the
+C ABI self-test entry points (include/sgr.h)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from street_gaussians_amd import _native
+    return _native.lib(), _native.check
+
+
+def _vp(t):
+    return C.c_void_p(t.data_ptr())
+
+
+@pytest.mark.parametrize("n", [1, 7, 2047, 2048, 2049, 100000, 4 * 1024 * 1024 + 5])
+@pytest.mark.parametrize("inclusive", [0, 1])
+def test_scan(n, inclusive):
+    L, check = _lib()
+    g = torch.Generator().manual_seed(n)
+    x = torch.randint(0, 50, (n,), generator=g, dtype=torch.int32)
+    xd = x.cuda()
+    out = torch.zeros_like(xd)
+    tmp = torch.zeros(L.sgr_test_scan_tmp_words(n), dtype=torch.int32, device="cuda")
+    check(L.sgr_test_scan(_vp(xd), _vp(out), n, inclusive, _vp(tmp), None))
+    torch.cuda.synchronize()
+    ref = np.cumsum(x.numpy().astype(np.int64))
+    if not inclusive:
+        ref = ref - x.numpy()
+    assert (out.cpu().numpy().astype(np.int64) == ref).all()
+    # in place
+    check(L.sgr_test_scan(_vp(xd), _vp(xd), n, inclusive, _vp(tmp), None))
+    torch.cuda.synchronize()
+    assert (xd.cpu().numpy().astype(np.int64) == ref).all()
+
+
+@pytest.mark.parametrize("n,end_bit,dup", [(1, 46, False), (100, 46, True), (2048, 46, True), (2049, 40, False),
+                                           (70001, 46, True), (3_000_000, 46, False), (1_000_003, 32, True),
+                                           (500_000, 41, True)])
+def test_sort_pairs_stable(n, end_bit, dup):
+    L, check = _lib()
+    rng = np.random.default_rng(n)
+    hi = 1 << end_bit
+    if dup:  # few distinct keys -> stability is exercised
+        keys = rng.integers(0, 97, n, dtype=np.uint64) * np.uint64(hi // 128 + 1)
+    else:
+        keys = rng.integers(0, hi, n, dtype=np.uint64)
+    vals = np.arange(n, dtype=np.uint32)
+    k0 = torch.from_numpy(keys.view(np.int64)).cuda()
+    v0 = torch.from_numpy(vals.view(np.int32)).cuda()
+    k1, v1 = torch.zeros_like(k0), torch.zeros_like(v0)
+    hist = torch.zeros(L.sgr_test_sort_hist_words(n), dtype=torch.int32, device="cuda")
+    tmp = torch.zeros(L.sgr_test_scan_tmp_words(hist.numel()), dtype=torch.int32, device="cuda")
+    cur = check(L.sgr_test_sort(_vp(k0), _vp(k1), _vp(v0), _vp(v1), n, end_bit, _vp(hist), _vp(tmp), None))
+    torch.cuda.synchronize()
+    ks = (k1 if cur else k0).cpu().numpy().view(np.uint64)
+    vs = (v1 if cur else v0).cpu().numpy().view(np.uint32)
+    order = np.argsort(keys, kind="stable")
+    assert (ks == keys[order]).all()
+    assert (vs == vals[order]).all()
+
+
+def test_wave_sum_dpp_equals_shuffle():
+    L, check = _lib()
+    nw = 257
+    g = torch.Generator().manual_seed(0)
+    # integers: every summation order is exact, so DPP, shuffle and numpy must agree bit for bit
+    x = torch.randint(-1000, 1000, (nw * 64,), generator=g).float()
+    xd = x.cuda()
+    a = torch.zeros(nw, device="cuda")
+    b = torch.zeros(nw, device="cuda")
+    check(L.sgr_test_wave_sum(_vp(xd), _vp(a), _vp(b), nw, None))
+    torch.cuda.synchronize()
+    ref = x.reshape(nw, 64).sum(1).numpy()
+    assert (a.cpu().numpy() == ref).all()
+    assert (b.cpu().numpy() == ref).all()
