@@ -30,7 +30,7 @@ void sgr_launch_blend_fwd(bool cull, int gx, int gy, const uint2* ranges, const 
                           const float* bg, float* out_color, float* out_depth, float* out_alpha, float* out_semantic,
                           uint32_t* n_contrib, hipStream_t s);
 int sgr_partial_row_stride(int S);
-void sgr_launch_blend_bwd(bool cull, bool dpp, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
+void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
                           int H, int S, const float* bg, const float4* recA, const float4* recB, const float4* recC,
                           const uint2* recD, const float* semantics, const float* alphas, const uint32_t* n_contrib,
                           const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha, const float* dL_dsem,
@@ -45,6 +45,11 @@ int sgr_knn_impl(int P, const float* points, float* meanDists, sgr_alloc_fn scra
                  std::string& err);
 
 static thread_local std::string g_err;
+
+static bool env_flag(const char* name) {
+    const char* v = getenv(name);
+    return v && v[0] && v[0] != '0';
+}
 
 // ---- optional per-stage timing with HIP events on the caller's stream (sgr_profile_*) -------------------
 // stages: 0 preprocess(+camera pack, memsets) 1 scan 2 duplicate 3 sort 4 tile_ranges 5 blend_fwd
@@ -85,15 +90,11 @@ static int fail(int code, const std::string& msg) {
 // reference CHECK_CUDA (auxiliary.h:166-173): with debug, synchronise after the stage and report
 #define SGR_STAGE(name)                                                                                   \
     do {                                                                                                  \
+        if (debug && env_flag("SGR_TRACE")) { fprintf(stderr, "[sgr] stage %s launched\n", name); fflush(stderr); } \
         hipError_t e__ = hipGetLastError();                                                               \
         if (e__ == hipSuccess && debug) e__ = hipStreamSynchronize(stream);                               \
         if (e__ != hipSuccess) return fail(SGR_E_HIP, std::string("stage ") + name + ": " + hipGetErrorString(e__)); \
     } while (0)
-
-static bool env_flag(const char* name) {
-    const char* v = getenv(name);
-    return v && v[0] && v[0] != '0';
-}
 
 // rasterizer_impl.cu:35-50
 static uint32_t getHigherMsb(uint32_t n) {
@@ -294,8 +295,8 @@ int sgr_backward(int P, int D, int M, int R, int S, const float* background, int
         SGR_HIP(hipMemsetAsync(partials, 0, bytes, stream));
         prof_end(stream);
         prof_begin(7, stream);
-        const bool cull = !env_flag("SGR_NO_CULL"), dpp = !env_flag("SGR_NO_DPP");
-        sgr_launch_blend_bwd(cull, dpp, gx, gy, iv.ranges, bv.vals[cur], W, H, S, background, gv.recA, gv.recB, gv.recC,
+        const bool cull = !env_flag("SGR_NO_CULL"), dpp = !env_flag("SGR_NO_DPP"), det = !env_flag("SGR_NO_DET");
+        sgr_launch_blend_bwd(cull, dpp, det, gx, gy, iv.ranges, bv.vals[cur], W, H, S, background, gv.recA, gv.recB, gv.recC,
                              gv.recD, semantics, alphas, iv.n_contrib, dL_dpix, dL_dpix_depth, dL_dalphas,
                              dL_dpix_semantic, partials, stream);
         SGR_STAGE("blend_bwd");

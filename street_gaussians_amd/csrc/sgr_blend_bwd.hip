@@ -58,7 +58,7 @@ void sgr_launch_wave_sum_test(const float* in, float* out_dpp, float* out_shfl, 
     sgr_wave_sum_test_kernel<<<nwaves, 64, 0, s>>>(in, out_dpp, out_shfl);
 }
 
-template <int SMAX, bool CULL, bool DPP>
+template <int SMAX, bool CULL, bool DPP, bool DET>
 __global__ void __launch_bounds__(SGR_TILE_THREADS)
 sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int S,
                      int gx, const float* __restrict__ bg_color, const float4* __restrict__ recA,
@@ -73,10 +73,12 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
     __shared__ float4 sB[SGR_TILE_THREADS];  // {qa, qb, qc, opacity}
     __shared__ float4 sC[SGR_TILE_THREADS];  // {r, g, b, depth}
     __shared__ uint32_t sU[SGR_TILE_THREADS];
-    __shared__ uint32_t sFlag[SGR_TILE_THREADS];
+    __shared__ uint32_t sFlag[SGR_TILE_THREADS];  // DET: one byte per wave (bit set = that wave stored a partial)
     __shared__ uint64_t sBits[4][4];
     __shared__ int sMax[4];
-    __shared__ float sAcc[SGR_TILE_THREADS * ACCW];
+    // DET: one accumulator row per (wave, slot), written with plain stores and summed in wave order when the
+    // row is flushed -> bit-reproducible.  !DET: one row per slot, the four waves combine with ds_add_f32.
+    __shared__ float sAcc[(DET ? 4 : 1) * SGR_TILE_THREADS * ACCW];
     __shared__ float sSem[SMAX > 0 ? SGR_TILE_THREADS * SMAX : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -135,8 +137,10 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
         const int pos = hi - tid;
         uint32_t mask4 = 0;
         sFlag[tid] = 0;
+        if (!DET) {
 #pragma unroll
-        for (int k = 0; k < ACCW; k++) sAcc[tid * ACCW + k] = 0.f;
+            for (int k = 0; k < ACCW; k++) sAcc[tid * ACCW + k] = 0.f;
+        }
         if (pos >= 0) {
             const uint32_t g = point_list[range.x + (uint32_t)pos];
             const float4 a = recA[g];
@@ -171,8 +175,7 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
 
         for (int chunk = 0; chunk < 4; chunk++) {
             uint64_t m = sBits[wave][chunk];
-            m = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(m >> 32)) << 32) |
-                (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)m);
+            m = sgr_uniform_u64(m);
             while (m) {
                 const int j = chunk * 64 + (__ffsll((unsigned long long)m) - 1);
                 m &= m - 1;
@@ -188,7 +191,9 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                 if (!__any(hit)) continue;
 
                 const float4 c = sC[j];
-                const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
+                const float oma = 1.0f - alpha;
+                float inv1ma = __builtin_amdgcn_rcpf(oma);
+                inv1ma = fmaf(fmaf(-oma, inv1ma, 1.0f), inv1ma, inv1ma);  // Newton step: T recovery compounds per layer
                 const float Tn = T * inv1ma;  // T = T / (1 - alpha)
                 const float w = alpha * Tn;
                 float dopa;
@@ -249,41 +254,67 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
 #pragma unroll
                 for (int k = 0; k < SGR_ROW_BASE + SMAX; k++) v[k] = sgr_wave_sum<DPP>(v[k]);
                 if (lane == 63) {
+                    if (DET) {
+                        float* dst = &sAcc[(wave * SGR_TILE_THREADS + j) * ACCW];
 #pragma unroll
-                    for (int k = 0; k < SGR_ROW_BASE + SMAX; k++) atomicAdd(&sAcc[j * ACCW + k], v[k]);
-                    sFlag[j] = 1u;
+                        for (int k = 0; k < SGR_ROW_BASE + SMAX; k++) dst[k] = v[k];
+                        reinterpret_cast<uint8_t*>(sFlag)[4 * j + wave] = 1;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < SGR_ROW_BASE + SMAX; k++) atomicAdd(&sAcc[j * ACCW + k], v[k]);
+                        sFlag[j] = 1u;
+                    }
                 }
             }
         }
         __syncthreads();
         // one row per touched (tile, instance): plain stores, written exactly once
-        if (sFlag[tid]) {
+        const uint32_t flags = sFlag[tid];
+        if (flags) {
             float* row = partials + (size_t)sU[tid] * row_stride;
             constexpr int NV = (SGR_ROW_BASE + SMAX + 3) / 4;
+            float r[4 * NV];
 #pragma unroll
-            for (int k4 = 0; k4 < NV; k4++) {
-                float4 o;
-                o.x = sAcc[tid * ACCW + 4 * k4];
-                o.y = (4 * k4 + 1 < SGR_ROW_BASE + SMAX) ? sAcc[tid * ACCW + 4 * k4 + 1] : 0.f;
-                o.z = (4 * k4 + 2 < SGR_ROW_BASE + SMAX) ? sAcc[tid * ACCW + 4 * k4 + 2] : 0.f;
-                o.w = (4 * k4 + 3 < SGR_ROW_BASE + SMAX) ? sAcc[tid * ACCW + 4 * k4 + 3] : 0.f;
-                reinterpret_cast<float4*>(row)[k4] = o;
+            for (int k = 0; k < 4 * NV; k++) r[k] = 0.f;
+            if (DET) {
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    if ((flags >> (8 * w)) & 0xffu) {
+                        const float* src = &sAcc[(w * SGR_TILE_THREADS + tid) * ACCW];
+#pragma unroll
+                        for (int k = 0; k < SGR_ROW_BASE + SMAX; k++) r[k] += src[k];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < SGR_ROW_BASE + SMAX; k++) r[k] = sAcc[tid * ACCW + k];
             }
+#pragma unroll
+            for (int k4 = 0; k4 < NV; k4++)
+                reinterpret_cast<float4*>(row)[k4] = make_float4(r[4 * k4], r[4 * k4 + 1], r[4 * k4 + 2], r[4 * k4 + 3]);
         }
     }
 }
 
 template <int SMAX>
-static void launch_bwd(bool cull, bool dpp, unsigned tiles, hipStream_t s, const uint2* ranges, const uint32_t* point_list,
+static void launch_bwd(bool cull, bool dpp, bool det, unsigned tiles, hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                        int W, int H, int S, int gx, const float* bg, const float4* recA, const float4* recB,
                        const float4* recC, const uint2* recD, const float* semantics, const float* alphas,
                        const uint32_t* n_contrib, const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha,
                        const float* dL_dsem, float* partials, int row_stride) {
+    // per-wave accumulators (deterministic) need 4*256*ACCW floats of LDS: used up to 16 semantic channels
+    constexpr bool kDet = SMAX <= 16;
 #define SGR_GO(C, D)                                                                                                 \
-    sgr_blend_bwd_kernel<SMAX, C, D><<<tiles, SGR_TILE_THREADS, 0, s>>>(ranges, point_list, W, H, S, gx, bg, recA, recB, \
-                                                                       recC, recD, semantics, alphas, n_contrib,    \
-                                                                       dL_dpix, dL_ddepth, dL_dalpha, dL_dsem,      \
-                                                                       partials, row_stride)
+    do {                                                                                                             \
+        if (kDet && det)                                                                                             \
+            sgr_blend_bwd_kernel<SMAX, C, D, kDet><<<tiles, SGR_TILE_THREADS, 0, s>>>(                                \
+                ranges, point_list, W, H, S, gx, bg, recA, recB, recC, recD, semantics, alphas, n_contrib, dL_dpix,    \
+                dL_ddepth, dL_dalpha, dL_dsem, partials, row_stride);                                                 \
+        else                                                                                                         \
+            sgr_blend_bwd_kernel<SMAX, C, D, false><<<tiles, SGR_TILE_THREADS, 0, s>>>(                               \
+                ranges, point_list, W, H, S, gx, bg, recA, recB, recC, recD, semantics, alphas, n_contrib, dL_dpix,    \
+                dL_ddepth, dL_dalpha, dL_dsem, partials, row_stride);                                                 \
+    } while (0)
     if (cull && dpp) SGR_GO(true, true);
     else if (cull) SGR_GO(true, false);
     else if (dpp) SGR_GO(false, true);
@@ -294,7 +325,7 @@ static void launch_bwd(bool cull, bool dpp, unsigned tiles, hipStream_t s, const
 // floats per partial row for S semantic channels: the kernel's SMAX bucket writes ceil((11+SMAX)/4) float4
 int sgr_partial_row_stride(int S) { return S <= 4 ? 16 : (S <= 16 ? 32 : 48); }
 
-void sgr_launch_blend_bwd(bool cull, bool dpp, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
+void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
                           int H, int S, const float* bg, const float4* recA, const float4* recB, const float4* recC,
                           const uint2* recD, const float* semantics, const float* alphas, const uint32_t* n_contrib,
                           const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha, const float* dL_dsem,
@@ -302,7 +333,7 @@ void sgr_launch_blend_bwd(bool cull, bool dpp, int gx, int gy, const uint2* rang
     const unsigned tiles = (unsigned)gx * (unsigned)gy;
     if (tiles == 0) return;
     const int stride = sgr_partial_row_stride(S);
-#define SGR_BWD(N) launch_bwd<N>(cull, dpp, tiles, s, ranges, point_list, W, H, S, gx, bg, recA, recB, recC, recD, \
+#define SGR_BWD(N) launch_bwd<N>(cull, dpp, det, tiles, s, ranges, point_list, W, H, S, gx, bg, recA, recB, recC, recD, \
                                  semantics, alphas, n_contrib, dL_dpix, dL_ddepth, dL_dalpha, dL_dsem, partials, stride)
     if (S == 0) SGR_BWD(0);
     else if (S <= 4) SGR_BWD(4);

@@ -87,8 +87,7 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
             const uint32_t pos0 = base - range.x;  // list position of slot 0 of this batch
             for (int chunk = 0; chunk < 4; chunk++) {
                 uint64_t m = sBits[wave][chunk];
-                m = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(m >> 32)) << 32) |
-                    (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)m);
+                m = sgr_uniform_u64(m);
                 while (m) {
                     const int j = chunk * 64 + (__ffsll((unsigned long long)m) - 1);
                     m &= m - 1;

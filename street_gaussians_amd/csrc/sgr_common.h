@@ -124,3 +124,13 @@ static inline size_t sgr_required(F carve) {
     carve(base, &end);
     return (size_t)(end - base) + 256;  // +256: the caller's pointer is re-aligned up to 256 B
 }
+
+#ifdef __HIPCC__
+// Move a wave-uniform 64-bit value into SGPRs.  __builtin_amdgcn_readfirstlane returns a SIGNED int:
+// each half must go through uint32_t, otherwise bit 31 of the low word sign-extends over the high word.
+__device__ __forceinline__ uint64_t sgr_uniform_u64(uint64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | (uint64_t)lo;
+}
+#endif

@@ -93,10 +93,21 @@ def test_backward_matches_oracle(name):
     ref = oracle.backward(fw, wts["color"], wts["depth"], wts["alpha"], wts["semantic"])
     res, _ = raw_forward(kw)
     g = raw_backward(kw, res, wts)
-    tol = 2e-3 if name == "dense_saturating" else 1e-4  # fp32 T/(1-alpha) recovery noise, see test_oracle.py
+    # dense_saturating: T is recovered by repeated division by (1-alpha)=0.01 in fp32 (backward.cu:547), which
+    # amplifies rounding differences of the reference algorithm itself (see tests/test_oracle.py)
+    tol, af = (2e-3, 2e-4) if name == "dense_saturating" else (1e-4, 2e-6)
+    mags = _color_mag(fw, wts) if name == "huge_splats" else {}
     for k in ["means2D", "colors", "opacity", "means3D", "cov3D", "sh", "scales", "rotations", "semantics"]:
-        grad_close(npy(g[k]).reshape(ref[k].shape), ref[k], rel=tol, name=f"{name}:{k}")
+        grad_close(npy(g[k]).reshape(ref[k].shape), ref[k], rel=tol, abs_frac=af, name=f"{name}:{k}", mag=mags.get(k))
     fw.free()
+
+
+def _color_mag(fw, wts):
+    """sum_pix w*|dL/dC| per Gaussian = the sum of |terms| behind dL/drgb (and, through Y_k(dir), dL/dSH): the
+    oracle's backward run with absolute-valued colour weights and nothing else."""
+    z = {k: torch.zeros_like(v) for k, v in wts.items()}
+    gabs = oracle.backward(fw, wts["color"].abs(), z["depth"], z["alpha"], z["semantic"])
+    return {"colors": gabs["colors"], "sh": np.abs(gabs["sh"]) + gabs["colors"][:, None, :] * 0.3}
 
 
 @pytest.mark.parametrize("name", ["mid_20k_sem3", "huge_splats"])
@@ -116,13 +127,13 @@ def test_culling_is_invisible_and_backward_is_deterministic(name, monkeypatch):
         assert torch.equal(res_a[k], res_b[k]), f"cull changed {k}"
     assert torch.equal(int_a("n_contrib"), int_b("n_contrib"))
     g_b = raw_backward(kw, res_b, wts)
-    for k in g_a:
-        grad_close(npy(g_a[k]), npy(g_b[k]), rel=1e-5, name=f"cull:{k}", max_outlier_frac=0.0)
+    for k in g_a:  # same pairs, same order: the cull must not change the gradients at all
+        assert torch.equal(g_a[k], g_b[k]), f"cull changed dL/d{k}"
     monkeypatch.delenv("SGR_NO_CULL")
     monkeypatch.setenv("SGR_NO_DPP", "1")
     g_c = raw_backward(kw, res_a, wts)
-    for k in g_a:
-        grad_close(npy(g_a[k]), npy(g_c[k]), rel=1e-5, name=f"dpp:{k}", max_outlier_frac=0.0)
+    for k in g_a:  # different summation order inside a wave: equal up to fp32 rounding
+        grad_close(npy(g_a[k]), npy(g_c[k]), rel=1e-4, abs_frac=2e-5, name=f"dpp:{k}", max_outlier_frac=0.0)
 
 
 def test_precomputed_colors_and_cov3D():
@@ -284,9 +295,11 @@ def test_against_reference_kernels(name):
     gref = ref.backward(rf, wts["color"], wts["depth"], wts["alpha"], wts["semantic"])
     gor = oracle.backward(fw, wts["color"], wts["depth"], wts["alpha"], wts["semantic"])
     g = raw_backward(kw, res, wts)
+    mags = _color_mag(fw, wts) if name == "huge_splats" else {}
     for k in ["means2D", "colors", "opacity", "means3D", "cov3D", "sh", "scales", "rotations", "semantics"]:
-        grad_close(npy(g[k]).reshape(gor[k].shape), npy(gref[k]).reshape(gor[k].shape), name=f"hip vs ref {k}")
-        grad_close(gor[k], npy(gref[k]).reshape(gor[k].shape), name=f"oracle vs ref {k}")
+        grad_close(npy(g[k]).reshape(gor[k].shape), npy(gref[k]).reshape(gor[k].shape), name=f"hip vs ref {k}",
+                   mag=mags.get(k))
+        grad_close(gor[k], npy(gref[k]).reshape(gor[k].shape), name=f"oracle vs ref {k}", mag=mags.get(k))
     rf.free()
     fw.free()
 
@@ -315,8 +328,9 @@ def test_golden_fixture(path):
     for k in ["color", "depth", "alpha", "semantic"]:
         image_close(npy(res[k]), gold[k], name=f"golden {k}")
     g = raw_backward(kw, res, wts)
+    rel, af = (2e-3, 2e-4) if "dense" in os.path.basename(path) else (1e-4, 2e-6)  # see tests/test_golden_cpu.py
     for k in ["means2D", "colors", "opacity", "means3D", "cov3D", "sh", "scales", "rotations", "semantics"]:
-        grad_close(npy(g[k]).reshape(gold["g_" + k].shape), gold["g_" + k], name=f"golden {k}")
+        grad_close(npy(g[k]).reshape(gold["g_" + k].shape), gold["g_" + k], rel=rel, abs_frac=af, name=f"golden {k}")
 
 
 # ---------------------------------------------------------------------------------------------------
