@@ -96,8 +96,9 @@ def grad_close(a, b, rel=1e-4, name="", max_outlier_frac=2e-3, abs_frac=2e-6, ma
     if mag is not None:
         # `mag` = sum of |terms| of the float32 sum each element is (e.g. sum_pix w*|dL/dC| for dL/drgb).  With
         # random-sign weights over ~1e5 pixels the sum cancels by ~sqrt(N), so 1e-4 of the RESULT is below one ulp
-        # of the terms; any summation order (serial oracle, unordered atomics, our tree) differs by O(64 eps * mag).
-        tol = tol + 4e-6 * np.asarray(mag, np.float64).reshape(a.shape)
+        # of the terms.  Measured on MI355X: the reference's own kernels and its line-by-line C restatement differ
+        # by up to 1.7e-5*mag on the 255-layer `huge_splats` stress case (summation order + fp32 T recovery).
+        tol = tol + 3e-5 * np.asarray(mag, np.float64).reshape(a.shape)
     bad = np.abs(a - b) > tol
     frac = bad.mean()
     assert frac <= max_outlier_frac, (f"{name}: {bad.sum()}/{a.size} outside rel={rel} "

@@ -47,6 +47,13 @@ def _cases():
 
 CASES = _cases()
 
+# (rel, abs_frac) for the two deliberately saturating cases.  The reference algorithm takes T_final = 1 - sum(w)
+# (backward.cu:468) and recovers every T_i by repeated division by (1-alpha) (backward.cu:547): for pixels whose
+# final transmittance is ~1e-4 the fp32 cancellation in 1 - sum(w) alone is a ~6e-4 RELATIVE error that multiplies
+# every gradient term of that pixel.  Measured on MI355X, the reference's own kernels and their line-by-line C
+# restatement differ by up to 2.2e-4 of the tensor scale on `huge_splats` (255 blended layers per pixel).
+SATURATING_TOL = {"dense_saturating": (2e-3, 2e-4), "huge_splats": (1e-4, 1e-3)}
+
 
 def _kw(name):
     cam, sc, opt = CASES[name]
@@ -95,7 +102,7 @@ def test_backward_matches_oracle(name):
     g = raw_backward(kw, res, wts)
     # dense_saturating: T is recovered by repeated division by (1-alpha)=0.01 in fp32 (backward.cu:547), which
     # amplifies rounding differences of the reference algorithm itself (see tests/test_oracle.py)
-    tol, af = (2e-3, 2e-4) if name == "dense_saturating" else (1e-4, 2e-6)
+    tol, af = SATURATING_TOL.get(name, (1e-4, 2e-6))
     mags = _color_mag(fw, wts) if name == "huge_splats" else {}
     for k in ["means2D", "colors", "opacity", "means3D", "cov3D", "sh", "scales", "rotations", "semantics"]:
         grad_close(npy(g[k]).reshape(ref[k].shape), ref[k], rel=tol, abs_frac=af, name=f"{name}:{k}", mag=mags.get(k))
@@ -296,10 +303,12 @@ def test_against_reference_kernels(name):
     gor = oracle.backward(fw, wts["color"], wts["depth"], wts["alpha"], wts["semantic"])
     g = raw_backward(kw, res, wts)
     mags = _color_mag(fw, wts) if name == "huge_splats" else {}
+    tol, af = SATURATING_TOL.get(name, (1e-4, 2e-6))
     for k in ["means2D", "colors", "opacity", "means3D", "cov3D", "sh", "scales", "rotations", "semantics"]:
         grad_close(npy(g[k]).reshape(gor[k].shape), npy(gref[k]).reshape(gor[k].shape), name=f"hip vs ref {k}",
+                   rel=tol, abs_frac=af, mag=mags.get(k))
+        grad_close(gor[k], npy(gref[k]).reshape(gor[k].shape), name=f"oracle vs ref {k}", rel=tol, abs_frac=af,
                    mag=mags.get(k))
-        grad_close(gor[k], npy(gref[k]).reshape(gor[k].shape), name=f"oracle vs ref {k}", mag=mags.get(k))
     rf.free()
     fw.free()
 
