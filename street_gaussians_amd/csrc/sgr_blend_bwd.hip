@@ -44,13 +44,36 @@ __device__ __forceinline__ float sgr_wave_sum(float v) {
     return DPP ? sgr_wave_sum_dpp(v) : sgr_wave_sum_shfl(v);
 }
 
+// Four wave sums at once, written as v_add_f32_dpp so that each step is ONE instruction (hipcc lowers the
+// update_dpp builtin to v_mov 0 + v_mov_dpp + (SLP-packed) v_pk_add_f32 = 3 instructions per step).  The four
+// chains are interleaved, so every DPP read is >= 3 instructions behind the write of its register (the
+// "VALU write -> DPP read" hazard needs 2 wait states and nothing pads the inside of an asm statement); the
+// leading s_nop covers values produced just before the statement.  Results are valid in lanes 48..63.
+#define SGR_DPP4(ctrl)                                                                             \
+    "v_add_f32_dpp %0, %0, %0 " ctrl "\n\tv_add_f32_dpp %1, %1, %1 " ctrl "\n\tv_add_f32_dpp %2, %2, %2 " ctrl \
+    "\n\tv_add_f32_dpp %3, %3, %3 " ctrl "\n\t"
+__device__ __forceinline__ void sgr_wave_sum4(float& a, float& b, float& c, float& d) {
+    asm volatile("s_nop 1\n\t" SGR_DPP4("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 SGR_DPP4("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 SGR_DPP4("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 SGR_DPP4("row_mirror row_mask:0xf bank_mask:0xf")
+                 SGR_DPP4("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 SGR_DPP4("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 0"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+#undef SGR_DPP4
+
 // self-test of the DPP reduction (sgr_selftest in sgr_api.hip)
 __global__ void sgr_wave_sum_test_kernel(const float* in, float* out_dpp, float* out_shfl) {
     const float v = in[blockIdx.x * 64 + threadIdx.x];
-    const float a = sgr_wave_sum_dpp(v);
+    float a = v, a1 = 2.f * v, a2 = -v, a3 = v + 1.f;
+    sgr_wave_sum4(a, a1, a2, a3);
     const float b = sgr_wave_sum_shfl(v);
+    const float c = sgr_wave_sum_dpp(v);
     if (threadIdx.x == 63) {
-        out_dpp[blockIdx.x] = a;
+        // all four asm chains and the builtin version must agree with the shuffle tree
+        const bool ok = (a1 == 2.f * a) && (a2 == -a) && (a3 == a + 64.f) && (c == a);
+        out_dpp[blockIdx.x] = ok ? a : __builtin_nanf("");
         out_shfl[blockIdx.x] = b;
     }
 }
@@ -68,7 +91,8 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                      const float* __restrict__ dL_dpixel_depths, const float* __restrict__ dL_dalphas,
                      const float* __restrict__ dL_dpixel_semantics, float* __restrict__ partials, int row_stride) {
     constexpr int NS = SMAX > 0 ? SMAX : 1;
-    constexpr int ACCW = (SGR_ROW_BASE + SMAX) | 1;  // odd LDS row stride: conflict-free row-per-lane reads
+    constexpr int NVAL = (SGR_ROW_BASE + SMAX + 3) / 4 * 4;  // values per row, padded to float4s
+    constexpr int ACCW = NVAL;                                 // LDS row stride (16-B aligned rows)
     __shared__ float4 sA[SGR_TILE_THREADS];  // {x, y, -, -}
     __shared__ float4 sB[SGR_TILE_THREADS];  // {qa, qb, qc, opacity}
     __shared__ float4 sC[SGR_TILE_THREADS];  // {r, g, b, depth}
@@ -78,7 +102,7 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
     __shared__ int sMax[4];
     // DET: one accumulator row per (wave, slot), written with plain stores and summed in wave order when the
     // row is flushed -> bit-reproducible.  !DET: one row per slot, the four waves combine with ds_add_f32.
-    __shared__ float sAcc[(DET ? 4 : 1) * SGR_TILE_THREADS * ACCW];
+    __shared__ __attribute__((aligned(16))) float sAcc[(DET ? 4 : 1) * SGR_TILE_THREADS * ACCW];
     __shared__ float sSem[SMAX > 0 ? SGR_TILE_THREADS * SMAX : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -197,7 +221,10 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                 const float Tn = T * inv1ma;  // T = T / (1 - alpha)
                 const float w = alpha * Tn;
                 float dopa;
-                float v[SGR_ROW_BASE + NS];
+                float v[NVAL];
+#pragma unroll
+                for (int k = 0; k < NVAL; k++) v[k] = 0.0f;
+                const float wm = hit ? w : 0.0f;  // every output below is a product with wm or dopa: mask those two
                 {
                     const float one_m_la = 1.0f - last_alpha;
                     const float a0 = fmaf(last_alpha, lastC0, one_m_la * accC0);
@@ -215,11 +242,9 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                                 const float sv = sSem[j * SMAX + ch];
                                 const float as = fmaf(last_alpha, lastS[ch], one_m_la * accS[ch]);
                                 dopa = fmaf(sv - as, dLdS[ch], dopa);
-                                v[SGR_ROW_BASE + ch] = hit ? w * dLdS[ch] : 0.0f;
+                                v[SGR_ROW_BASE + ch] = wm * dLdS[ch];
                                 accS[ch] = hit ? as : accS[ch];
                                 lastS[ch] = hit ? sv : lastS[ch];
-                            } else {
-                                v[SGR_ROW_BASE + ch] = 0.0f;
                             }
                         }
                     }
@@ -234,30 +259,37 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                 }
                 dopa *= Tn;
                 dopa = fmaf(-T_final * inv1ma, bgdot, dopa);  // backward.cu:611-614
+                dopa = hit ? dopa : 0.0f;
                 const float dL_dG = q.w * dopa;
                 const float gdx = G * dx, gdy = G * dy;
                 // dG/ddelx = -gdx*A - gdy*B = (2*qa*gdx + qb*gdy)/log2e  (qa = -0.5*log2e*A, qb = -log2e*B)
                 const float gmx = dL_dG * fmaf(2.0f * q.x, gdx, q.y * gdy) * kx;
                 const float gmy = dL_dG * fmaf(2.0f * q.z, gdy, q.y * gdx) * ky;
-                v[0] = hit ? gmx : 0.0f;
-                v[1] = hit ? gmy : 0.0f;
-                v[2] = hit ? fabsf(gmx) + fabsf(gmy) : 0.0f;
+                v[0] = gmx;
+                v[1] = gmy;
+                v[2] = fabsf(gmx) + fabsf(gmy);
                 const float h = -0.5f * dL_dG;
-                v[3] = hit ? h * gdx * dx : 0.0f;
-                v[4] = hit ? h * gdx * dy : 0.0f;
-                v[5] = hit ? h * gdy * dy : 0.0f;
-                v[6] = hit ? G * dopa : 0.0f;
-                v[7] = hit ? w * dLdC0 : 0.0f;
-                v[8] = hit ? w * dLdC1 : 0.0f;
-                v[9] = hit ? w * dLdC2 : 0.0f;
-                v[10] = hit ? w * dLdD : 0.0f;
+                v[3] = h * gdx * dx;
+                v[4] = h * gdx * dy;
+                v[5] = h * gdy * dy;
+                v[6] = G * dopa;
+                v[7] = wm * dLdC0;
+                v[8] = wm * dLdC1;
+                v[9] = wm * dLdC2;
+                v[10] = wm * dLdD;
+                if (DPP) {
 #pragma unroll
-                for (int k = 0; k < SGR_ROW_BASE + SMAX; k++) v[k] = sgr_wave_sum<DPP>(v[k]);
+                    for (int k = 0; k < NVAL; k += 4) sgr_wave_sum4(v[k], v[k + 1], v[k + 2], v[k + 3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NVAL; k++) v[k] = sgr_wave_sum_shfl(v[k]);
+                }
                 if (lane == 63) {
                     if (DET) {
-                        float* dst = &sAcc[(wave * SGR_TILE_THREADS + j) * ACCW];
+                        float4* dst = reinterpret_cast<float4*>(&sAcc[(wave * SGR_TILE_THREADS + j) * ACCW]);
 #pragma unroll
-                        for (int k = 0; k < SGR_ROW_BASE + SMAX; k++) dst[k] = v[k];
+                        for (int k4 = 0; k4 < NVAL / 4; k4++)
+                            dst[k4] = make_float4(v[4 * k4], v[4 * k4 + 1], v[4 * k4 + 2], v[4 * k4 + 3]);
                         reinterpret_cast<uint8_t*>(sFlag)[4 * j + wave] = 1;
                     } else {
 #pragma unroll
@@ -271,27 +303,29 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
         // one row per touched (tile, instance): plain stores, written exactly once
         const uint32_t flags = sFlag[tid];
         if (flags) {
-            float* row = partials + (size_t)sU[tid] * row_stride;
-            constexpr int NV = (SGR_ROW_BASE + SMAX + 3) / 4;
-            float r[4 * NV];
+            float4* row = reinterpret_cast<float4*>(partials + (size_t)sU[tid] * row_stride);
+            float4 r[NVAL / 4];
 #pragma unroll
-            for (int k = 0; k < 4 * NV; k++) r[k] = 0.f;
+            for (int k4 = 0; k4 < NVAL / 4; k4++) r[k4] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (DET) {
 #pragma unroll
                 for (int w = 0; w < 4; w++) {
                     if ((flags >> (8 * w)) & 0xffu) {
-                        const float* src = &sAcc[(w * SGR_TILE_THREADS + tid) * ACCW];
+                        const float4* src = reinterpret_cast<const float4*>(&sAcc[(w * SGR_TILE_THREADS + tid) * ACCW]);
 #pragma unroll
-                        for (int k = 0; k < SGR_ROW_BASE + SMAX; k++) r[k] += src[k];
+                        for (int k4 = 0; k4 < NVAL / 4; k4++) {
+                            const float4 t = src[k4];
+                            r[k4].x += t.x; r[k4].y += t.y; r[k4].z += t.z; r[k4].w += t.w;
+                        }
                     }
                 }
             } else {
+                const float4* src = reinterpret_cast<const float4*>(&sAcc[tid * ACCW]);
 #pragma unroll
-                for (int k = 0; k < SGR_ROW_BASE + SMAX; k++) r[k] = sAcc[tid * ACCW + k];
+                for (int k4 = 0; k4 < NVAL / 4; k4++) r[k4] = src[k4];
             }
 #pragma unroll
-            for (int k4 = 0; k4 < NV; k4++)
-                reinterpret_cast<float4*>(row)[k4] = make_float4(r[4 * k4], r[4 * k4 + 1], r[4 * k4 + 2], r[4 * k4 + 3]);
+            for (int k4 = 0; k4 < NVAL / 4; k4++) row[k4] = r[k4];
         }
     }
 }
