@@ -26,18 +26,17 @@ void sgr_launch_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp,
 int sgr_launch_sort_pairs(uint64_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
                           uint32_t* scan_tmp, hipStream_t s);
 void sgr_launch_blend_fwd(bool cull, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W, int H,
-                          int S, const float4* recA, const float4* recB, const float4* recC, const float* semantics,
-                          const float* bg, float* out_color, float* out_depth, float* out_alpha, float* out_semantic,
-                          uint32_t* n_contrib, hipStream_t s);
+                          int S, const float4* rec, const float* semantics, const float* bg, float* out_color,
+                          float* out_depth, float* out_alpha, float* out_semantic, uint32_t* n_contrib, hipStream_t s);
 int sgr_partial_row_stride(int S);
 void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
-                          int H, int S, const float* bg, const float4* recA, const float4* recB, const float4* recC,
-                          const uint2* recD, const float* semantics, const float* alphas, const uint32_t* n_contrib,
-                          const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha, const float* dL_dsem,
-                          float* partials, hipStream_t s);
+                          int H, int S, const float* bg, const float4* rec, const float* semantics, const float* alphas,
+                          const uint32_t* n_contrib, const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha,
+                          const float* dL_dsem, float* partials, uint8_t* touched, hipStream_t s);
 void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const int* radii, const float* shs,
                           const float* scales, const float* rotations, const float* cov3D_precomp, const SgrCam* cam,
-                          const SgrGeomView& gv, const float* partials, int row_stride, float* dL_dmean2D,
+                          const SgrGeomView& gv, const float* partials, int row_stride, const uint8_t* touched,
+                          float* dL_dmean2D,
                           float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
                           float* dL_dscale, float* dL_drot, float* dL_dsemantic, hipStream_t s);
 void sgr_launch_wave_sum_test(const float* in, float* out_dpp, float* out_shfl, int nwaves, hipStream_t s);
@@ -247,7 +246,7 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     }
     prof_begin(5, stream);
     const bool cull = !env_flag("SGR_NO_CULL");
-    sgr_launch_blend_fwd(cull, gx, gy, iv.ranges, bv.vals[cur], W, H, S, gv.recA, gv.recB, gv.recC, semantics,
+    sgr_launch_blend_fwd(cull, gx, gy, iv.ranges, bv.vals[cur], W, H, S, gv.rec, semantics,
                          background, out_color, out_depth, out_alpha, out_semantic, iv.n_contrib, stream);
     SGR_STAGE("blend_fwd");
     prof_end(stream);
@@ -285,26 +284,28 @@ int sgr_backward(int P, int D, int M, int R, int S, const float* background, int
     const int* radii_ptr = radii ? radii : gv.internal_radii;
     const int stride = sgr_partial_row_stride(S);
     float* partials = nullptr;
+    uint8_t* touched = nullptr;
     if (R > 0) {
         const SgrBinView bv = sgr_bin_carve(binning_buffer, (size_t)R);
         const int cur = sorted_index(W, H);
-        const size_t bytes = (size_t)R * stride * sizeof(float);
-        partials = (float*)scratch(bytes, scratch_user);
+        const size_t bytes = sgr_align_up((size_t)R * stride * sizeof(float), 256);
+        partials = (float*)scratch(bytes + (size_t)R, scratch_user);
         if (!partials) return fail(SGR_E_ALLOC, "backward scratch allocation failed");
+        touched = reinterpret_cast<uint8_t*>(partials) + bytes;  // one byte per (tile, instance) row
         prof_begin(6, stream);
-        SGR_HIP(hipMemsetAsync(partials, 0, bytes, stream));
+        SGR_HIP(hipMemsetAsync(touched, 0, (size_t)R, stream));  // rows themselves are never cleared
         prof_end(stream);
         prof_begin(7, stream);
         const bool cull = !env_flag("SGR_NO_CULL"), dpp = !env_flag("SGR_NO_DPP"), det = !env_flag("SGR_NO_DET");
-        sgr_launch_blend_bwd(cull, dpp, det, gx, gy, iv.ranges, bv.vals[cur], W, H, S, background, gv.recA, gv.recB, gv.recC,
-                             gv.recD, semantics, alphas, iv.n_contrib, dL_dpix, dL_dpix_depth, dL_dalphas,
-                             dL_dpix_semantic, partials, stream);
+        sgr_launch_blend_bwd(cull, dpp, det, gx, gy, iv.ranges, bv.vals[cur], W, H, S, background, gv.rec, semantics,
+                             alphas, iv.n_contrib, dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, partials, touched,
+                             stream);
         SGR_STAGE("blend_bwd");
         prof_end(stream);
     }
     prof_begin(8, stream);
     sgr_launch_gauss_bwd(P, D, M, S, means3D, radii_ptr, shs, scales, rotations, cov3D_precomp, cam_slot(gv), gv, partials,
-                         stride, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
+                         stride, touched, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
                          dL_dsemantic, stream);
     SGR_STAGE("gauss_bwd");
     prof_end(stream);
@@ -404,18 +405,18 @@ __global__ void sgr_export_kernel(int which, int P, SgrGeomView gv, void* dst) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
     switch (which) {
-        case 0: ((float*)dst)[i] = gv.recC[i].w; break;
+        case 0: ((float*)dst)[i] = gv.rec[4 * (size_t)i + 2].w; break;
         case 1: {
             const uint32_t c = gv.clamped[i];
             ((uint8_t*)dst)[3 * i] = c & 1u; ((uint8_t*)dst)[3 * i + 1] = (c >> 1) & 1u; ((uint8_t*)dst)[3 * i + 2] = (c >> 2) & 1u;
         } break;
-        case 2: { const float4 a = gv.recA[i]; ((float*)dst)[2 * i] = a.x; ((float*)dst)[2 * i + 1] = a.y; } break;
+        case 2: { const float4 a = gv.rec[4 * (size_t)i]; ((float*)dst)[2 * i] = a.x; ((float*)dst)[2 * i + 1] = a.y; } break;
         case 3: for (int k = 0; k < 6; k++) ((float*)dst)[6 * i + k] = gv.cov3D[6 * (size_t)i + k]; break;
-        case 4: ((float4*)dst)[i] = gv.recB[i]; break;
-        case 5: { const float4 c = gv.recC[i]; ((float*)dst)[3 * i] = c.x; ((float*)dst)[3 * i + 1] = c.y; ((float*)dst)[3 * i + 2] = c.z; } break;
+        case 4: ((float4*)dst)[i] = gv.rec[4 * (size_t)i + 1]; break;
+        case 5: { const float4 c = gv.rec[4 * (size_t)i + 2]; ((float*)dst)[3 * i] = c.x; ((float*)dst)[3 * i + 1] = c.y; ((float*)dst)[3 * i + 2] = c.z; } break;
         case 6: ((uint32_t*)dst)[i] = gv.tiles_touched[i]; break;
         case 7: ((uint32_t*)dst)[i] = gv.point_offsets[i]; break;
-        case 14: { const float4 a = gv.recA[i]; ((float*)dst)[2 * i] = a.z; ((float*)dst)[2 * i + 1] = a.w; } break;
+        case 14: { const float4 a = gv.rec[4 * (size_t)i]; ((float*)dst)[2 * i] = a.z; ((float*)dst)[2 * i + 1] = a.w; } break;
     }
 }
 

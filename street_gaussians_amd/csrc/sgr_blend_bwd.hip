@@ -84,12 +84,12 @@ void sgr_launch_wave_sum_test(const float* in, float* out_dpp, float* out_shfl, 
 template <int SMAX, bool CULL, bool DPP, bool DET>
 __global__ void __launch_bounds__(SGR_TILE_THREADS)
 sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int S,
-                     int gx, const float* __restrict__ bg_color, const float4* __restrict__ recA,
-                     const float4* __restrict__ recB, const float4* __restrict__ recC, const uint2* __restrict__ recD,
+                     int gx, const float* __restrict__ bg_color, const float4* __restrict__ rec,
                      const float* __restrict__ semantics, const float* __restrict__ alphas,
                      const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
                      const float* __restrict__ dL_dpixel_depths, const float* __restrict__ dL_dalphas,
-                     const float* __restrict__ dL_dpixel_semantics, float* __restrict__ partials, int row_stride) {
+                     const float* __restrict__ dL_dpixel_semantics, float* __restrict__ partials, int row_stride,
+                     uint8_t* __restrict__ touched) {
     constexpr int NS = SMAX > 0 ? SMAX : 1;
     constexpr int NVAL = (SGR_ROW_BASE + SMAX + 3) / 4 * 4;  // values per row, padded to float4s
     constexpr int ACCW = NVAL;                                 // LDS row stride (16-B aligned rows)
@@ -167,14 +167,16 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
         }
         if (pos >= 0) {
             const uint32_t g = point_list[range.x + (uint32_t)pos];
-            const float4 a = recA[g];
-            const float4 b = recB[g];
-            const uint2 d = recD[g];
+            const float4* r = rec + 4 * (size_t)g;  // one 64-byte line
+            const float4 a = r[0];
+            const float4 b = r[1];
+            const float4 d4 = r[3];
             sA[tid] = a;
             sB[tid] = make_float4(-0.5f * SGR_LOG2E * b.x, -SGR_LOG2E * b.y, -0.5f * SGR_LOG2E * b.z, b.w);
-            sC[tid] = recC[g];
-            const uint32_t rx0 = d.y & 1023u, ry0 = (d.y >> 10) & 1023u, rw = d.y >> 20;
-            sU[tid] = d.x + (ty - ry0) * rw + (tx - rx0);
+            sC[tid] = r[2];
+            const uint32_t dy_ = __float_as_uint(d4.y);
+            const uint32_t rx0 = dy_ & 1023u, ry0 = (dy_ >> 10) & 1023u, rw = dy_ >> 20;
+            sU[tid] = __float_as_uint(d4.x) + (ty - ry0) * rw + (tx - rx0);
             if (SMAX > 0) {
                 for (int ch = 0; ch < S; ch++) sSem[tid * SMAX + ch] = semantics[(size_t)g * S + ch];
             }
@@ -303,7 +305,9 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
         // one row per touched (tile, instance): plain stores, written exactly once
         const uint32_t flags = sFlag[tid];
         if (flags) {
-            float4* row = reinterpret_cast<float4*>(partials + (size_t)sU[tid] * row_stride);
+            const uint32_t u = sU[tid];
+            touched[u] = 1;  // the per-Gaussian reduction only reads rows that were written (no 64 B/instance memset)
+            float4* row = reinterpret_cast<float4*>(partials + (size_t)u * row_stride);
             float4 r[NVAL / 4];
 #pragma unroll
             for (int k4 = 0; k4 < NVAL / 4; k4++) r[k4] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -332,22 +336,22 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
 
 template <int SMAX>
 static void launch_bwd(bool cull, bool dpp, bool det, unsigned tiles, hipStream_t s, const uint2* ranges, const uint32_t* point_list,
-                       int W, int H, int S, int gx, const float* bg, const float4* recA, const float4* recB,
-                       const float4* recC, const uint2* recD, const float* semantics, const float* alphas,
+                       int W, int H, int S, int gx, const float* bg, const float4* rec, const float* semantics,
+                       const float* alphas,
                        const uint32_t* n_contrib, const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha,
-                       const float* dL_dsem, float* partials, int row_stride) {
+                       const float* dL_dsem, float* partials, int row_stride, uint8_t* touched) {
     // per-wave accumulators (deterministic) need 4*256*ACCW floats of LDS: used up to 16 semantic channels
     constexpr bool kDet = SMAX <= 16;
 #define SGR_GO(C, D)                                                                                                 \
     do {                                                                                                             \
         if (kDet && det)                                                                                             \
             sgr_blend_bwd_kernel<SMAX, C, D, kDet><<<tiles, SGR_TILE_THREADS, 0, s>>>(                                \
-                ranges, point_list, W, H, S, gx, bg, recA, recB, recC, recD, semantics, alphas, n_contrib, dL_dpix,    \
-                dL_ddepth, dL_dalpha, dL_dsem, partials, row_stride);                                                 \
+                ranges, point_list, W, H, S, gx, bg, rec, semantics, alphas, n_contrib, dL_dpix, dL_ddepth,            \
+                dL_dalpha, dL_dsem, partials, row_stride, touched);                                                   \
         else                                                                                                         \
             sgr_blend_bwd_kernel<SMAX, C, D, false><<<tiles, SGR_TILE_THREADS, 0, s>>>(                               \
-                ranges, point_list, W, H, S, gx, bg, recA, recB, recC, recD, semantics, alphas, n_contrib, dL_dpix,    \
-                dL_ddepth, dL_dalpha, dL_dsem, partials, row_stride);                                                 \
+                ranges, point_list, W, H, S, gx, bg, rec, semantics, alphas, n_contrib, dL_dpix, dL_ddepth,            \
+                dL_dalpha, dL_dsem, partials, row_stride, touched);                                                   \
     } while (0)
     if (cull && dpp) SGR_GO(true, true);
     else if (cull) SGR_GO(true, false);
@@ -360,15 +364,14 @@ static void launch_bwd(bool cull, bool dpp, bool det, unsigned tiles, hipStream_
 int sgr_partial_row_stride(int S) { return S <= 4 ? 16 : (S <= 16 ? 32 : 48); }
 
 void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
-                          int H, int S, const float* bg, const float4* recA, const float4* recB, const float4* recC,
-                          const uint2* recD, const float* semantics, const float* alphas, const uint32_t* n_contrib,
+                          int H, int S, const float* bg, const float4* rec, const float* semantics, const float* alphas, const uint32_t* n_contrib,
                           const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha, const float* dL_dsem,
-                          float* partials, hipStream_t s) {
+                          float* partials, uint8_t* touched, hipStream_t s) {
     const unsigned tiles = (unsigned)gx * (unsigned)gy;
     if (tiles == 0) return;
     const int stride = sgr_partial_row_stride(S);
-#define SGR_BWD(N) launch_bwd<N>(cull, dpp, det, tiles, s, ranges, point_list, W, H, S, gx, bg, recA, recB, recC, recD, \
-                                 semantics, alphas, n_contrib, dL_dpix, dL_ddepth, dL_dalpha, dL_dsem, partials, stride)
+#define SGR_BWD(N) launch_bwd<N>(cull, dpp, det, tiles, s, ranges, point_list, W, H, S, gx, bg, rec, semantics, alphas, \
+                                 n_contrib, dL_dpix, dL_ddepth, dL_dalpha, dL_dsem, partials, stride, touched)
     if (S == 0) SGR_BWD(0);
     else if (S <= 4) SGR_BWD(4);
     else if (S <= 8) SGR_BWD(8);

@@ -18,8 +18,7 @@
 template <int SMAX, bool CULL>
 __global__ void __launch_bounds__(SGR_TILE_THREADS)
 sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int S,
-                     int gx, const float4* __restrict__ recA, const float4* __restrict__ recB,
-                     const float4* __restrict__ recC, const float* __restrict__ semantics,
+                     int gx, const float4* __restrict__ rec, const float* __restrict__ semantics,
                      const float* __restrict__ bg_color, float* __restrict__ out_color, float* __restrict__ out_depth,
                      float* __restrict__ out_alpha, float* __restrict__ out_semantic, uint32_t* __restrict__ n_contrib) {
     __shared__ float4 sA[SGR_TILE_THREADS];  // {x, y, -, -}
@@ -55,11 +54,12 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
         uint32_t mask4 = 0;
         if (idx < range.y) {
             const uint32_t g = point_list[idx];
-            const float4 a = recA[g];
-            const float4 b = recB[g];
+            const float4* r = rec + 4 * (size_t)g;  // one 64-byte line
+            const float4 a = r[0];
+            const float4 b = r[1];
             sA[tid] = a;
             sB[tid] = make_float4(-0.5f * SGR_LOG2E * b.x, -SGR_LOG2E * b.y, -0.5f * SGR_LOG2E * b.z, b.w);
-            sC[tid] = recC[g];
+            sC[tid] = r[2];
             if (SMAX > 0) {
                 for (int ch = 0; ch < S; ch++) sSem[tid * SMAX + ch] = semantics[(size_t)g * S + ch];
             }
@@ -145,27 +145,26 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
 
 template <int SMAX>
 static void launch_fwd(bool cull, unsigned tiles, hipStream_t s, const uint2* ranges, const uint32_t* point_list, int W,
-                       int H, int S, int gx, const float4* recA, const float4* recB, const float4* recC,
-                       const float* semantics, const float* bg, float* out_color, float* out_depth, float* out_alpha,
+                       int H, int S, int gx, const float4* rec, const float* semantics, const float* bg, float* out_color, float* out_depth, float* out_alpha,
                        float* out_semantic, uint32_t* n_contrib) {
     if (cull)
-        sgr_blend_fwd_kernel<SMAX, true><<<tiles, SGR_TILE_THREADS, 0, s>>>(ranges, point_list, W, H, S, gx, recA, recB,
-                                                                           recC, semantics, bg, out_color, out_depth,
-                                                                           out_alpha, out_semantic, n_contrib);
+        sgr_blend_fwd_kernel<SMAX, true><<<tiles, SGR_TILE_THREADS, 0, s>>>(ranges, point_list, W, H, S, gx, rec, semantics,
+                                                                           bg, out_color, out_depth, out_alpha,
+                                                                           out_semantic, n_contrib);
     else
-        sgr_blend_fwd_kernel<SMAX, false><<<tiles, SGR_TILE_THREADS, 0, s>>>(ranges, point_list, W, H, S, gx, recA, recB,
-                                                                            recC, semantics, bg, out_color, out_depth,
-                                                                            out_alpha, out_semantic, n_contrib);
+        sgr_blend_fwd_kernel<SMAX, false><<<tiles, SGR_TILE_THREADS, 0, s>>>(ranges, point_list, W, H, S, gx, rec, semantics,
+                                                                            bg, out_color, out_depth, out_alpha,
+                                                                            out_semantic, n_contrib);
 }
 
 // S must be <= SGR_SEM_MAX (checked by the caller).
 void sgr_launch_blend_fwd(bool cull, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W, int H,
-                          int S, const float4* recA, const float4* recB, const float4* recC, const float* semantics,
+                          int S, const float4* rec, const float* semantics,
                           const float* bg, float* out_color, float* out_depth, float* out_alpha, float* out_semantic,
                           uint32_t* n_contrib, hipStream_t s) {
     const unsigned tiles = (unsigned)gx * (unsigned)gy;
     if (tiles == 0) return;
-#define SGR_FWD(N) launch_fwd<N>(cull, tiles, s, ranges, point_list, W, H, S, gx, recA, recB, recC, semantics, bg, \
+#define SGR_FWD(N) launch_fwd<N>(cull, tiles, s, ranges, point_list, W, H, S, gx, rec, semantics, bg, \
                                  out_color, out_depth, out_alpha, out_semantic, n_contrib)
     if (S == 0) SGR_FWD(0);
     else if (S <= 4) SGR_FWD(4);

@@ -5,10 +5,12 @@
 // /root/reference/submodules/diff-gaussian-rasterization/cuda_rasterizer/rasterizer_impl.h:29-64):
 //
 //   geometry buffer, per Gaussian g (struct-of-float4-arrays so every gather is one 16-B load):
-//     recA[g] = {pix.x, pix.y, hx, hy}      2D mean + conservative half extents of the alpha>=1/255 ellipse
-//     recB[g] = {conic.x, conic.y, conic.z, opacity}
-//     recC[g] = {r, g, b, view depth}
-//     recD[g] = {exclusive tile offset, packed tile rect}   (backward only)
+//     rec[4g+0] = {pix.x, pix.y, hx, hy}      2D mean + conservative half extents of the alpha>=1/255 ellipse
+//     rec[4g+1] = {conic.x, conic.y, conic.z, opacity}
+//     rec[4g+2] = {r, g, b, view depth}
+//     rec[4g+3] = {bits: exclusive tile offset, bits: packed tile rect, -, -}   (backward only)
+//     -> ONE 64-byte, 64-byte-aligned record per Gaussian: a tile kernel's gather of an instance touches
+//        a single cache line (three separate arrays cost three lines per instance: measured 2-4x over-fetch)
 //     cov3D[6g..], tiles_touched[g], point_offsets[g] (inclusive), clamped[g] (3-bit mask), radii (if not given)
 //   binning buffer: 64-bit keys (tile<<32 | depth bits) and 32-bit Gaussian ids, ping-pong for the
 //     LSD radix sort, plus the per-block digit histograms.
@@ -28,10 +30,7 @@
 #define SGR_LOG2E 1.4426950408889634f
 
 struct SgrGeomView {
-    float4* recA;
-    float4* recB;
-    float4* recC;
-    uint2* recD;
+    float4* rec;  // [4P]
     float* cov3D;
     uint32_t* tiles_touched;
     uint32_t* point_offsets;
@@ -75,10 +74,7 @@ static inline SgrGeomView sgr_geom_carve(char* base, size_t P, char** end = null
     char* p = base;
     size_t Pn = P ? P : 1;
     sgr_carve(p, v.header, 64);
-    sgr_carve(p, v.recA, Pn);
-    sgr_carve(p, v.recB, Pn);
-    sgr_carve(p, v.recC, Pn);
-    sgr_carve(p, v.recD, Pn);
+    sgr_carve(p, v.rec, Pn * 4);
     sgr_carve(p, v.cov3D, Pn * 6);
     sgr_carve(p, v.tiles_touched, Pn);
     sgr_carve(p, v.point_offsets, Pn);

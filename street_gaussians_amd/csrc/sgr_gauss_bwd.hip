@@ -16,7 +16,8 @@ __global__ void __launch_bounds__(SGR_GB_THREADS)
 sgr_gauss_bwd_kernel(int P, int D, int M, int S, const float* __restrict__ means3D, const int* __restrict__ radii,
                      const float* __restrict__ shs, const float* __restrict__ scales,
                      const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
-                     const SgrCam* __restrict__ camp, SgrGeomView gv, const float* __restrict__ partials, int row_stride, float* __restrict__ dL_dmean2D,
+                     const SgrCam* __restrict__ camp, SgrGeomView gv, const float* __restrict__ partials, int row_stride,
+                     const uint8_t* __restrict__ touched, float* __restrict__ dL_dmean2D,
                      float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
                      float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
                      float* __restrict__ dL_drot, float* __restrict__ dL_dsemantic) {
@@ -30,10 +31,11 @@ sgr_gauss_bwd_kernel(int P, int D, int M, int S, const float* __restrict__ means
 #pragma unroll
     for (int k = 0; k < SGR_ROW_BASE_N + NS; k++) acc[k] = 0.f;
     if (visible) {
-        const uint32_t u0 = gv.recD[idx].x;
+        const uint32_t u0 = __float_as_uint(gv.rec[4 * (size_t)idx + 3].x);
         const uint32_t n = gv.tiles_touched[idx];
         constexpr int NV = (SGR_ROW_BASE_N + SMAX + 3) / 4;
         for (uint32_t i = 0; i < n; i++) {
+            if (!touched[u0 + i]) continue;  // row never written by the blend backward
             const float4* row = reinterpret_cast<const float4*>(partials + (size_t)(u0 + i) * row_stride);
 #pragma unroll
             for (int k4 = 0; k4 < NV; k4++) {
@@ -139,14 +141,16 @@ sgr_gauss_bwd_kernel(int P, int D, int M, int S, const float* __restrict__ means
 
 void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const int* radii, const float* shs,
                           const float* scales, const float* rotations, const float* cov3D_precomp, const SgrCam* cam,
-                          const SgrGeomView& gv, const float* partials, int row_stride, float* dL_dmean2D,
+                          const SgrGeomView& gv, const float* partials, int row_stride, const uint8_t* touched,
+                          float* dL_dmean2D,
                           float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
                           float* dL_dscale, float* dL_drot, float* dL_dsemantic, hipStream_t s) {
     if (P <= 0) return;
     const unsigned nb = (P + SGR_GB_THREADS - 1) / SGR_GB_THREADS;
 #define SGR_GB(N)                                                                                                     \
     sgr_gauss_bwd_kernel<N><<<nb, SGR_GB_THREADS, 0, s>>>(P, D, M, S, means3D, radii, shs, scales, rotations,           \
-                                                          cov3D_precomp, cam, gv, partials, row_stride, dL_dmean2D,   \
+                                                          cov3D_precomp, cam, gv, partials, row_stride, touched,      \
+                                                          dL_dmean2D,                                              \
                                                           dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,       \
                                                           dL_dscale, dL_drot, dL_dsemantic)
     if (S == 0) SGR_GB(0);

@@ -131,10 +131,11 @@ sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     float hx, hy;
     sgr_extent(opacity, pr.cov_a, pr.cov_c, hx, hy);
     const uint32_t w = pr.rx1 - pr.rx0, h = pr.ry1 - pr.ry0;
-    gv.recA[idx] = make_float4(pr.px, pr.py, hx, hy);
-    gv.recB[idx] = make_float4(pr.con_x, pr.con_y, pr.con_z, opacity);
-    gv.recC[idx] = make_float4(rgb[0], rgb[1], rgb[2], pr.depth);
-    gv.recD[idx] = make_uint2(0u, sgr_pack_rect(pr.rx0, pr.ry0, w));
+    float4* rec = gv.rec + 4 * (size_t)idx;
+    rec[0] = make_float4(pr.px, pr.py, hx, hy);
+    rec[1] = make_float4(pr.con_x, pr.con_y, pr.con_z, opacity);
+    rec[2] = make_float4(rgb[0], rgb[1], rgb[2], pr.depth);
+    rec[3] = make_float4(0.f, __uint_as_float(sgr_pack_rect(pr.rx0, pr.ry0, w)), 0.f, 0.f);
     gv.clamped[idx] = clamped;
     gv.tiles_touched[idx] = w * h;
     radii[idx] = pr.radius;
@@ -149,12 +150,14 @@ sgr_duplicate_kernel(int P, SgrGeomView gv, const int* __restrict__ radii, uint6
     if (!(radii[idx] > 0)) return;
     uint32_t off = (idx == 0) ? 0u : gv.point_offsets[idx - 1];
     const uint32_t n = gv.tiles_touched[idx];
-    uint2 d = gv.recD[idx];
-    d.x = off;
-    gv.recD[idx] = d;
-    const uint32_t x0 = d.y & 1023u, y0 = (d.y >> 10) & 1023u, w = d.y >> 20;
+    float4* rec = gv.rec + 4 * (size_t)idx;
+    float4 d4 = rec[3];
+    d4.x = __uint_as_float(off);
+    rec[3] = d4;
+    const uint32_t dy = __float_as_uint(d4.y);
+    const uint32_t x0 = dy & 1023u, y0 = (dy >> 10) & 1023u, w = dy >> 20;
     const uint32_t h = n / w;
-    const uint64_t depth_bits = (uint64_t)__float_as_uint(gv.recC[idx].w);
+    const uint64_t depth_bits = (uint64_t)__float_as_uint(rec[2].w);
     for (uint32_t y = y0; y < y0 + h; y++) {
         for (uint32_t x = x0; x < x0 + w; x++) {
             uint64_t key = (uint64_t)(y * (uint32_t)gx + x);
