@@ -35,7 +35,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         if not force and os.path.exists(o) and os.path.getmtime(o) > max(os.path.getmtime(s), hdr_time):
             return o, False
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        cmd = [hipcc] + FLAGS + os.environ.get("SGR_EXTRA_FLAGS", "").split() + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd))
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -63,6 +63,70 @@ __device__ __forceinline__ void sgr_wave_sum4(float& a, float& b, float& c, floa
 }
 #undef SGR_DPP4
 
+// ---- wave64 REDUCE-SCATTER of NVAL values (NVAL % 4 == 0) -----------------------------------------------------
+// Summing NVAL values over 64 lanes one by one costs 6 DPP adds each.  Instead halve the number of live registers
+// at every cross-half step: v_permlane32_swap (gfx950) exchanges the upper half of A with the lower half of B, so
+// A+B leaves value A's pair sums in lanes 0-31 and value B's in lanes 32-63 -- two values, one register.
+// v_permlane16_swap does the same across 16-lane rows.  After the two stages register t holds, in row k, partial
+// sums of value 4t + {0,2,1,3}[k]; a 4-step DPP row reduction (on NVAL/4 registers only) finishes the job:
+//   NVAL = 12:  6+3 swaps, 9 adds, 12 DPP adds = 30 instructions instead of 72.
+__device__ __forceinline__ void sgr_swap32(float& a, float& b) {
+    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    a = __builtin_bit_cast(float, (unsigned)r[0]);
+    b = __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ void sgr_swap16(float& a, float& b) {
+    auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    a = __builtin_bit_cast(float, (unsigned)r[0]);
+    b = __builtin_bit_cast(float, (unsigned)r[1]);
+}
+// row (16-lane) sums, every lane of the row ends up with the row total; chains interleaved as in sgr_wave_sum4
+#define SGR_ROW4(ctrl)                                                                              \
+    "v_add_f32_dpp %0, %0, %0 " ctrl "\n\tv_add_f32_dpp %1, %1, %1 " ctrl "\n\tv_add_f32_dpp %2, %2, %2 " ctrl \
+    "\n\tv_add_f32_dpp %3, %3, %3 " ctrl "\n\t"
+#define SGR_ROW3(ctrl)                                                                              \
+    "v_add_f32_dpp %0, %0, %0 " ctrl "\n\tv_add_f32_dpp %1, %1, %1 " ctrl "\n\tv_add_f32_dpp %2, %2, %2 " ctrl "\n\t"
+#define SGR_ROW2(ctrl) "v_add_f32_dpp %0, %0, %0 " ctrl "\n\tv_add_f32_dpp %1, %1, %1 " ctrl "\n\ts_nop 0\n\t"
+#define SGR_ROWSTEPS(M)                                                                                        \
+    "s_nop 1\n\t" M("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") M("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf") \
+        M("row_half_mirror row_mask:0xf bank_mask:0xf") M("row_mirror row_mask:0xf bank_mask:0xf") "s_nop 0"
+__device__ __forceinline__ void sgr_row_sum4(float& a, float& b, float& c, float& d) {
+    asm volatile(SGR_ROWSTEPS(SGR_ROW4) : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+__device__ __forceinline__ void sgr_row_sum3(float& a, float& b, float& c) {
+    asm volatile(SGR_ROWSTEPS(SGR_ROW3) : "+v"(a), "+v"(b), "+v"(c));
+}
+__device__ __forceinline__ void sgr_row_sum2(float& a, float& b) { asm volatile(SGR_ROWSTEPS(SGR_ROW2) : "+v"(a), "+v"(b)); }
+#undef SGR_ROW4
+#undef SGR_ROW3
+#undef SGR_ROW2
+#undef SGR_ROWSTEPS
+
+// in: v[NVAL] per lane.  out: r[NVAL/4]; in row k (= lane >> 4) r[t] is the wave total of value 4t + {0,2,1,3}[k].
+template <int NVAL>
+__device__ __forceinline__ void sgr_wave_reduce_scatter(float (&v)[NVAL], float (&r)[NVAL / 4]) {
+    static_assert(NVAL % 4 == 0, "pad the value count to a multiple of 4");
+    float h[NVAL / 2];
+#pragma unroll
+    for (int p = 0; p < NVAL / 2; p++) {
+        sgr_swap32(v[2 * p], v[2 * p + 1]);
+        h[p] = v[2 * p] + v[2 * p + 1];
+    }
+#pragma unroll
+    for (int t = 0; t < NVAL / 4; t++) {
+        sgr_swap16(h[2 * t], h[2 * t + 1]);
+        r[t] = h[2 * t] + h[2 * t + 1];
+    }
+    constexpr int N = NVAL / 4;
+    int t = 0;
+#pragma unroll
+    for (; t + 4 <= N && (N - t) != 5; t += 4) sgr_row_sum4(r[t], r[t + 1], r[t + 2], r[t + 3]);
+#pragma unroll
+    for (; t + 3 <= N; t += 3) sgr_row_sum3(r[t], r[t + 1], r[t + 2]);
+    if (t + 2 == N) sgr_row_sum2(r[t], r[t + 1]);
+    static_assert(N != 1, "unsupported value count");
+}
+
 // self-test of the DPP reduction (sgr_selftest in sgr_api.hip)
 __global__ void sgr_wave_sum_test_kernel(const float* in, float* out_dpp, float* out_shfl) {
     const float v = in[blockIdx.x * 64 + threadIdx.x];
@@ -70,9 +134,20 @@ __global__ void sgr_wave_sum_test_kernel(const float* in, float* out_dpp, float*
     sgr_wave_sum4(a, a1, a2, a3);
     const float b = sgr_wave_sum_shfl(v);
     const float c = sgr_wave_sum_dpp(v);
+    // reduce-scatter of 12 values x_i = (i+1)*v: row k of r[t] must hold (4t + {0,2,1,3}[k] + 1) * sum(v)
+    float x[12], r[3];
+#pragma unroll
+    for (int i = 0; i < 12; i++) x[i] = (float)(i + 1) * v;
+    sgr_wave_reduce_scatter<12>(x, r);
+    const int k = threadIdx.x >> 4;
+    const int perm = (k == 1) ? 2 : ((k == 2) ? 1 : k);
+    bool rs_ok = true;
+#pragma unroll
+    for (int t = 0; t < 3; t++) rs_ok = rs_ok && (r[t] == (float)(4 * t + perm + 1) * b);
+    rs_ok = __all(rs_ok);
     if (threadIdx.x == 63) {
-        // all four asm chains and the builtin version must agree with the shuffle tree
-        const bool ok = (a1 == 2.f * a) && (a2 == -a) && (a3 == a + 64.f) && (c == a);
+        // all four asm chains, the builtin version and the reduce-scatter must agree with the shuffle tree
+        const bool ok = (a1 == 2.f * a) && (a2 == -a) && (a3 == a + 64.f) && (c == a) && rs_ok;
         out_dpp[blockIdx.x] = ok ? a : __builtin_nanf("");
         out_shfl[blockIdx.x] = b;
     }
@@ -180,17 +255,7 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
             if (SMAX > 0) {
                 for (int ch = 0; ch < S; ch++) sSem[tid * SMAX + ch] = semantics[(size_t)g * S + ch];
             }
-            if (CULL) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const float qx0 = tx0 + (float)((q & 1) * 8), qy0 = ty0 + (float)((q >> 1) * 8);
-                    const bool miss = (a.x + a.z < qx0) || (a.x - a.z > qx0 + 7.0f) || (a.y + a.w < qy0) ||
-                                      (a.y - a.w > qy0 + 7.0f);
-                    mask4 |= miss ? 0u : (1u << q);
-                }
-            } else {
-                mask4 = 0xFu;
-            }
+            mask4 = CULL ? sgr_quadrant_mask(a, b, tx0, ty0) : 0xFu;
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -199,22 +264,12 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
         }
         __syncthreads();
 
-        for (int chunk = 0; chunk < 4; chunk++) {
-            uint64_t m = sBits[wave][chunk];
-            m = sgr_uniform_u64(m);
-            while (m) {
-                const int j = chunk * 64 + (__ffsll((unsigned long long)m) - 1);
-                m &= m - 1;
+        auto process = [&](const int j, const float4 q, const float dx, const float dy, const float power2, const float G,
+                           const float alpha, const bool valid) __attribute__((always_inline)) {
                 const int posj = hi - j;  // 0-based list position == `contributor` after its decrement
-                const float4 a = sA[j];
-                const float4 q = sB[j];
-                const float dx = a.x - pxf, dy = a.y - pyf;
-                const float power2 = sgr_power2(q.x, q.y, q.z, dx, dy);
-                const float G = __builtin_amdgcn_exp2f(power2);
-                const float alpha = fminf(0.99f, q.w * G);
                 // backward.cu:527-545
-                const bool hit = inside && (posj < lastc) && !(power2 > 0.0f) && !(alpha < SGR_ALPHA_MIN);
-                if (!__any(hit)) continue;
+                const bool hit = valid && inside && (posj < lastc) && !(power2 > 0.0f) && !(alpha < SGR_ALPHA_MIN);
+                if (!__any(hit)) return;
 
                 const float4 c = sC[j];
                 const float oma = 1.0f - alpha;
@@ -279,26 +334,54 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                 v[8] = wm * dLdC1;
                 v[9] = wm * dLdC2;
                 v[10] = wm * dLdD;
+                // LDS row layout: float4 t = values (4t, 4t+2, 4t+1, 4t+3) -- the order the reduce-scatter leaves
+                // them in rows 0..3 of register t; the flush below swaps the middle pair back.
+                float r[NVAL / 4];
                 if (DPP) {
-#pragma unroll
-                    for (int k = 0; k < NVAL; k += 4) sgr_wave_sum4(v[k], v[k + 1], v[k + 2], v[k + 3]);
+                    sgr_wave_reduce_scatter<NVAL>(v, r);
                 } else {
 #pragma unroll
-                    for (int k = 0; k < NVAL; k++) v[k] = sgr_wave_sum_shfl(v[k]);
-                }
-                if (lane == 63) {
-                    if (DET) {
-                        float4* dst = reinterpret_cast<float4*>(&sAcc[(wave * SGR_TILE_THREADS + j) * ACCW]);
-#pragma unroll
-                        for (int k4 = 0; k4 < NVAL / 4; k4++)
-                            dst[k4] = make_float4(v[4 * k4], v[4 * k4 + 1], v[4 * k4 + 2], v[4 * k4 + 3]);
-                        reinterpret_cast<uint8_t*>(sFlag)[4 * j + wave] = 1;
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < SGR_ROW_BASE + SMAX; k++) atomicAdd(&sAcc[j * ACCW + k], v[k]);
-                        sFlag[j] = 1u;
+                    for (int t = 0; t < NVAL / 4; t++) {
+                        const float s0 = sgr_wave_sum_shfl(v[4 * t]), s1 = sgr_wave_sum_shfl(v[4 * t + 1]);
+                        const float s2 = sgr_wave_sum_shfl(v[4 * t + 2]), s3 = sgr_wave_sum_shfl(v[4 * t + 3]);
+                        const int k = lane >> 4;
+                        r[t] = k == 0 ? s0 : (k == 1 ? s2 : (k == 2 ? s1 : s3));
                     }
                 }
+                if ((lane & 15) == 0) {  // one lane per 16-lane row stores that row's values
+                    const int k = lane >> 4;
+                    if (DET) {
+                        float* dst = &sAcc[(wave * SGR_TILE_THREADS + j) * ACCW + k];
+#pragma unroll
+                        for (int t = 0; t < NVAL / 4; t++) dst[4 * t] = r[t];
+                        if (k == 0) reinterpret_cast<uint8_t*>(sFlag)[4 * j + wave] = 1;
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < NVAL / 4; t++) atomicAdd(&sAcc[j * ACCW + 4 * t + k], r[t]);
+                        if (k == 0) sFlag[j] = 1u;
+                    }
+                }
+        };
+        for (int chunk = 0; chunk < 4; chunk++) {
+            uint64_t m = sBits[wave][chunk];
+            m = sgr_uniform_u64(m);
+            while (m) {
+                // two survivors per trip: LDS reads and exp() of both are independent of each other; only the
+                // per-pixel recurrences (process) are ordered
+                const int j0 = chunk * 64 + (__ffsll((unsigned long long)m) - 1);
+                m &= m - 1;
+                const bool two = m != 0;
+                const int j1 = two ? chunk * 64 + (__ffsll((unsigned long long)m) - 1) : j0;
+                m &= m - 1;
+                const float4 a0 = sA[j0], q0 = sB[j0];
+                const float4 a1 = sA[j1], q1 = sB[j1];
+                const float dx0 = a0.x - pxf, dy0 = a0.y - pyf, dx1 = a1.x - pxf, dy1 = a1.y - pyf;
+                const float pw0 = sgr_power2(q0.x, q0.y, q0.z, dx0, dy0);
+                const float pw1 = sgr_power2(q1.x, q1.y, q1.z, dx1, dy1);
+                const float G0 = __builtin_amdgcn_exp2f(pw0), G1 = __builtin_amdgcn_exp2f(pw1);
+                const float al0 = fminf(0.99f, q0.w * G0), al1 = fminf(0.99f, q1.w * G1);
+                process(j0, q0, dx0, dy0, pw0, G0, al0, true);
+                process(j1, q1, dx1, dy1, pw1, G1, al1, two);
             }
         }
         __syncthreads();
@@ -329,7 +412,7 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                 for (int k4 = 0; k4 < NVAL / 4; k4++) r[k4] = src[k4];
             }
 #pragma unroll
-            for (int k4 = 0; k4 < NVAL / 4; k4++) row[k4] = r[k4];
+            for (int k4 = 0; k4 < NVAL / 4; k4++) row[k4] = make_float4(r[k4].x, r[k4].z, r[k4].y, r[k4].w);
         }
     }
 }

@@ -63,18 +63,7 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
             if (SMAX > 0) {
                 for (int ch = 0; ch < S; ch++) sSem[tid * SMAX + ch] = semantics[(size_t)g * S + ch];
             }
-            if (CULL) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const float qx0 = tx0 + (float)((q & 1) * 8), qy0 = ty0 + (float)((q >> 1) * 8);
-                    // written so that NaN extents never cull
-                    const bool miss = (a.x + a.z < qx0) || (a.x - a.z > qx0 + 7.0f) || (a.y + a.w < qy0) ||
-                                      (a.y - a.w > qy0 + 7.0f);
-                    mask4 |= miss ? 0u : (1u << q);
-                }
-            } else {
-                mask4 = 0xFu;
-            }
+            mask4 = CULL ? sgr_quadrant_mask(a, b, tx0, ty0) : 0xFu;
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -89,36 +78,47 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                 uint64_t m = sBits[wave][chunk];
                 m = sgr_uniform_u64(m);
                 while (m) {
-                    const int j = chunk * 64 + (__ffsll((unsigned long long)m) - 1);
+                    // two survivors per trip: their LDS reads and exp() are independent, only the blend is ordered
+                    const int j0 = chunk * 64 + (__ffsll((unsigned long long)m) - 1);
                     m &= m - 1;
-                    const float4 a = sA[j];
-                    const float4 q = sB[j];
-                    const float dx = a.x - pxf, dy = a.y - pyf;
-                    const float power2 = sgr_power2(q.x, q.y, q.z, dx, dy);
-                    const float alpha = fminf(0.99f, q.w * __builtin_amdgcn_exp2f(power2));
-                    // forward.cu:425-430: skip if power > 0 or alpha < 1/255
-                    const bool hit = !done && !(power2 > 0.0f) && !(alpha < SGR_ALPHA_MIN);
-                    if (__any(hit)) {
-                        const float test_T = T * (1.0f - alpha);
-                        const bool stop = hit && (test_T < 0.0001f);  // forward.cu:431-436
-                        const bool blend = hit && !stop;
-                        const float4 c = sC[j];
-                        const float w = blend ? alpha * T : 0.0f;
-                        C0 = fmaf(c.x, w, C0);
-                        C1 = fmaf(c.y, w, C1);
-                        C2 = fmaf(c.z, w, C2);
-                        Dp = fmaf(c.w, w, Dp);
-                        Wt += w;
-                        if (SMAX > 0) {
+                    const bool two = m != 0;
+                    const int j1 = two ? chunk * 64 + (__ffsll((unsigned long long)m) - 1) : j0;
+                    m &= m - 1;  // no-op when m == 0
+                    const float4 a0 = sA[j0], q0 = sB[j0];
+                    const float4 a1 = sA[j1], q1 = sB[j1];
+                    const float pw0 = sgr_power2(q0.x, q0.y, q0.z, a0.x - pxf, a0.y - pyf);
+                    const float pw1 = sgr_power2(q1.x, q1.y, q1.z, a1.x - pxf, a1.y - pyf);
+                    const float al0 = fminf(0.99f, q0.w * __builtin_amdgcn_exp2f(pw0));
+                    const float al1 = fminf(0.99f, q1.w * __builtin_amdgcn_exp2f(pw1));
 #pragma unroll
-                            for (int ch = 0; ch < SMAX; ch++)
-                                if (ch < S) sem[ch] = fmaf(sSem[j * SMAX + ch], w, sem[ch]);
-                        }
-                        T = blend ? test_T : T;
-                        last = blend ? (pos0 + (uint32_t)j + 1u) : last;
-                        if (__any(stop)) {
-                            done = done || stop;
-                            if (__all(done)) { m = 0; chunk = 4; }
+                    for (int u = 0; u < 2; u++) {
+                        const int j = u ? j1 : j0;
+                        const float power2 = u ? pw1 : pw0;
+                        const float alpha = u ? al1 : al0;
+                        // forward.cu:425-430: skip if power > 0 or alpha < 1/255
+                        const bool hit = (u == 0 || two) && !done && !(power2 > 0.0f) && !(alpha < SGR_ALPHA_MIN);
+                        if (__any(hit)) {
+                            const float test_T = T * (1.0f - alpha);
+                            const bool stop = hit && (test_T < 0.0001f);  // forward.cu:431-436
+                            const bool blend = hit && !stop;
+                            const float4 c = sC[j];
+                            const float w = blend ? alpha * T : 0.0f;
+                            C0 = fmaf(c.x, w, C0);
+                            C1 = fmaf(c.y, w, C1);
+                            C2 = fmaf(c.z, w, C2);
+                            Dp = fmaf(c.w, w, Dp);
+                            Wt += w;
+                            if (SMAX > 0) {
+#pragma unroll
+                                for (int ch = 0; ch < SMAX; ch++)
+                                    if (ch < S) sem[ch] = fmaf(sSem[j * SMAX + ch], w, sem[ch]);
+                            }
+                            T = blend ? test_T : T;
+                            last = blend ? (pos0 + (uint32_t)j + 1u) : last;
+                            if (__any(stop)) {
+                                done = done || stop;
+                                if (__all(done)) { m = 0; chunk = 4; }
+                            }
                         }
                     }
                 }

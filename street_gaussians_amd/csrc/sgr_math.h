@@ -188,6 +188,55 @@ SGR_HD void sgr_extent(float opacity, float cov_a, float cov_c, float& hx, float
     hy = sqrtf(2.0f * tau * cov_c) * 1.01f + 0.25f;
 }
 
+// Exact part of the quadrant cull.  tau2 = 2*tau' (same inflation as sgr_extent; negative = never visible).
+SGR_HD float sgr_tau2(float opacity) {
+    if (opacity < 0.0039f) return -1.0f;
+    const float tau = fmaxf(logf(255.0f * opacity), 0.0f) * 1.02f + 0.05f;
+    return 2.0f * tau;
+}
+// Minimum of Q(d) = A*dx^2 + 2*B*dx*dy + C*dy^2 over the rectangle dx in [dx0,dx1], dy in [dy0,dy1]
+// (offsets of a pixel block from the splat centre).  Q is convex: 0 if the centre is inside, else the minimum
+// lies on one of the four edges, where Q is a 1-D parabola whose vertex is clamped to the edge.
+SGR_HD float sgr_min_quadform_rect(float A, float B, float C, float dx0, float dx1, float dy0, float dy1) {
+    if (dx0 <= 0.0f && dx1 >= 0.0f && dy0 <= 0.0f && dy1 >= 0.0f) return 0.0f;
+    float m;
+    {
+        const float dy = fminf(fmaxf(-B * dx0 / C, dy0), dy1);
+        m = A * dx0 * dx0 + 2.0f * B * dx0 * dy + C * dy * dy;
+    }
+    {
+        const float dy = fminf(fmaxf(-B * dx1 / C, dy0), dy1);
+        m = fminf(m, A * dx1 * dx1 + 2.0f * B * dx1 * dy + C * dy * dy);
+    }
+    {
+        const float dx = fminf(fmaxf(-B * dy0 / A, dx0), dx1);
+        m = fminf(m, A * dx * dx + 2.0f * B * dx * dy0 + C * dy0 * dy0);
+    }
+    {
+        const float dx = fminf(fmaxf(-B * dy1 / A, dx0), dx1);
+        m = fminf(m, A * dx * dx + 2.0f * B * dx * dy1 + C * dy1 * dy1);
+    }
+    return m;
+}
+// 4-bit mask of the 8x8 quadrants of tile (tx0,ty0) a splat can touch: conservative box first (rec[0].zw), then
+// the exact ellipse-vs-rectangle test with a 0.25 px margin.  Comparisons are written so NaN never culls.
+SGR_HD uint32_t sgr_quadrant_mask(const float4& a, const float4& b, float tx0, float ty0) {
+    uint32_t mask4 = 0;
+    const float tau2 = sgr_tau2(b.w);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float qx0 = tx0 + (float)((q & 1) * 8), qy0 = ty0 + (float)((q >> 1) * 8);
+        bool miss = (a.x + a.z < qx0) || (a.x - a.z > qx0 + 7.0f) || (a.y + a.w < qy0) || (a.y - a.w > qy0 + 7.0f);
+        if (!miss) {
+            const float mq = sgr_min_quadform_rect(b.x, b.y, b.z, qx0 - 0.25f - a.x, qx0 + 7.25f - a.x,
+                                                   qy0 - 0.25f - a.y, qy0 + 7.25f - a.y);
+            miss = mq > tau2;
+        }
+        mask4 |= miss ? 0u : (1u << q);
+    }
+    return mask4;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Per-(pixel, Gaussian) evaluation shared by the forward and backward blend kernels.  The conic is
 // pre-scaled when a tile list is staged into LDS:  qa = -0.5*log2e*conic.x, qb = -log2e*conic.y,

@@ -86,5 +86,15 @@ void hm_backward(int P, int D, int M, const float* means, const float* scales, c
     }
 }
 
+// quadrant masks of n splats for the tile whose first pixel is (tx0, ty0)
+void hm_quadrant_masks(int n, const float* means2D, const float* conic_opacity, const float* extents, float tx0, float ty0,
+                       unsigned* masks) {
+    for (int i = 0; i < n; i++) {
+        const float4 a = make_float4(means2D[2 * i], means2D[2 * i + 1], extents[2 * i], extents[2 * i + 1]);
+        const float4 b = make_float4(conic_opacity[4 * i], conic_opacity[4 * i + 1], conic_opacity[4 * i + 2], conic_opacity[4 * i + 3]);
+        masks[i] = sgr_quadrant_mask(a, b, tx0, ty0);
+    }
+}
+
 float hm_power2(float qa, float qb, float qc, float dx, float dy) { return sgr_power2(qa, qb, qc, dx, dy); }
 }

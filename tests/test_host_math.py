@@ -89,6 +89,31 @@ def test_forward_geometry_bit_exact_and_backward_close(hm, deg, margin, scale_px
             worst = max(worst, (np.abs(dx)[acc] / ext[ids, 0][:, None, None].repeat(dx.shape[1], 1).repeat(dx.shape[2], 2)[acc]).max())
     assert 0.5 < worst <= 1.0  # the box is conservative but not vacuous
 
+    # quadrant cull (box + exact ellipse-vs-rectangle): never drops a quadrant that holds an accepted pair, and is
+    # tight enough to be worth running (most set bits correspond to a quadrant with an accepted pair)
+    set_bits = needed_bits = 0
+    for t in range(rg.shape[0]):
+        ids = pl[rg[t, 0]:rg[t, 1]]
+        if len(ids) == 0:
+            continue
+        ty, tx = divmod(t, gx)
+        masks = np.zeros(len(ids), np.uint32)
+        m2 = np.ascontiguousarray(fw.means2D[ids]); co = np.ascontiguousarray(fw.conic_opacity[ids])
+        ex = np.ascontiguousarray(ext[ids])
+        hm.hm_quadrant_masks(len(ids), _p(m2), _p(co), _p(ex), C.c_float(tx * 16.0), C.c_float(ty * 16.0), _p(masks))
+        ys, xs = np.meshgrid(np.arange(ty * 16, ty * 16 + 16), np.arange(tx * 16, tx * 16 + 16), indexing="ij")
+        dx = m2[:, 0][:, None, None] - xs[None].astype(np.float32)
+        dy = m2[:, 1][:, None, None] - ys[None].astype(np.float32)
+        power = -0.5 * (co[:, 0, None, None] * dx * dx + co[:, 2, None, None] * dy * dy) - co[:, 1, None, None] * dx * dy
+        alpha = np.minimum(0.99, co[:, 3, None, None] * np.exp(power))
+        acc = (power <= 0) & (alpha >= 1.0 / 255.0)
+        for q in range(4):
+            qa = acc[:, (q >> 1) * 8:(q >> 1) * 8 + 8, (q & 1) * 8:(q & 1) * 8 + 8].any(axis=(1, 2))
+            bit = (masks >> q) & 1
+            assert not (qa & (bit == 0)).any(), "cull dropped a quadrant with an accepted pair"
+            set_bits += int(bit.sum()); needed_bits += int(qa.sum())
+    assert needed_bits / max(set_bits, 1) > 0.6
+
     wts = syn.loss_weights(cam)
     g = oracle.backward(fw, wts["color"], wts["depth"], wts["alpha"], None)
     dmean3D = np.zeros((P, 3), np.float32); dcov = np.zeros((P, 6), np.float32); dscale = np.zeros((P, 3), np.float32)
