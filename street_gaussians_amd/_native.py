@@ -20,7 +20,7 @@ _lib = None
 SYMBOLS = [
     "sgr_last_error", "sgr_version", "sgr_forward", "sgr_backward", "sgr_mark_visible", "sgr_visible_filter",
     "sgr_knn", "sgr_geometry_bytes", "sgr_binning_bytes", "sgr_image_bytes", "sgr_partial_row_floats",
-    "sgr_export_internal", "sgr_test_scan", "sgr_test_sort", "sgr_test_sort_hist_words", "sgr_test_scan_tmp_words",
+    "sgr_export_internal", "sgr_test_scan", "sgr_test_sort", "sgr_test_sort32", "sgr_test_sort_hist_words", "sgr_test_scan_tmp_words",
     "sgr_test_wave_sum", "sgr_profile_enable", "sgr_profile_read",
 ]
 
@@ -65,6 +65,8 @@ def lib():
         L.sgr_test_scan.argtypes = [vp, vp, C.c_size_t, i, vp, vp]
         L.sgr_test_sort.restype = i
         L.sgr_test_sort.argtypes = [vp, vp, vp, vp, C.c_uint32, i, vp, vp, vp]
+        L.sgr_test_sort32.restype = i
+        L.sgr_test_sort32.argtypes = [vp, vp, vp, vp, C.c_uint32, i, vp, vp, vp]
         L.sgr_test_wave_sum.restype = i
         L.sgr_test_wave_sum.argtypes = [vp, vp, vp, i, vp]
         L.sgr_profile_enable.restype = i

@@ -19,9 +19,14 @@ void sgr_launch_preprocess(int P, int D, int M, const float* means3D, const floa
 void sgr_launch_filter(int P, const float* means3D, const float* scales, const float* rotations,
                        const float* cov3D_precomp, const SgrCam* cam, const SgrGeomView& gv, int* radii,
                        float* means2D, int prefiltered, hipStream_t s);
-void sgr_launch_duplicate(int P, const SgrGeomView& gv, const int* radii, uint64_t* keys, uint32_t* vals, int gx,
-                          hipStream_t s);
-void sgr_launch_tile_ranges(int L, const uint64_t* keys, uint2* ranges, hipStream_t s);
+void sgr_launch_gather_tiles(int P, const uint32_t* order, const uint32_t* tiles_touched, uint32_t* tt_sorted, hipStream_t s);
+void sgr_launch_duplicate(int P, const SgrGeomView& gv, const uint32_t* order, const uint32_t* offs_incl, uint32_t* keys,
+                          uint32_t* vals, int gx, hipStream_t s);
+void sgr_launch_tile_ranges(int L, const uint32_t* keys, uint2* ranges, hipStream_t s);
+void sgr_launch_compose_keys(int L, const uint32_t* tile_keys, const uint32_t* point_list, const float4* rec, uint64_t* out,
+                             hipStream_t s);
+int sgr_launch_sort_pairs32(uint32_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
+                            uint32_t* scan_tmp, hipStream_t s);
 void sgr_launch_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, bool inclusive, hipStream_t s);
 int sgr_launch_sort_pairs(uint64_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
                           uint32_t* scan_tmp, hipStream_t s);
@@ -51,7 +56,7 @@ static bool env_flag(const char* name) {
 }
 
 // ---- optional per-stage timing with HIP events on the caller's stream (sgr_profile_*) -------------------
-// stages: 0 preprocess(+camera pack, memsets) 1 scan 2 duplicate 3 sort 4 tile_ranges 5 blend_fwd
+// stages: 0 preprocess(+camera pack, memsets) 1 depth sort + scan 2 duplicate 3 tile sort 4 tile_ranges 5 blend_fwd
 //         6 partials memset 7 blend_bwd 8 gauss_bwd
 #define SGR_PROF_STAGES 9
 #define SGR_PROF_SLOTS 512
@@ -209,10 +214,14 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     SGR_STAGE("preprocess");
     prof_end(stream);
 
-    // K4 + K5: inclusive scan, then read back num_rendered (+ the prefilter flag) -- the one host sync
+    // Depth pre-sort of the P Gaussians (32-bit keys, 4 passes over P elements), then K4: scan of tiles_touched in
+    // that order.  K5: read back num_rendered (+ the prefilter flag) -- the one host sync of the forward.
     prof_begin(1, stream);
-    sgr_launch_scan(gv.tiles_touched, gv.point_offsets, (size_t)P, gv.scan_tmp, true, stream);
-    SGR_STAGE("scan");
+    const int dcur = sgr_launch_sort_pairs32(gv.dkeys, gv.dvals, (uint32_t)P, 32, gv.dhist, gv.scan_tmp, stream);
+    const uint32_t* order = gv.dvals[dcur];
+    sgr_launch_gather_tiles(P, order, gv.tiles_touched, gv.tt_sorted, stream);
+    sgr_launch_scan(gv.tt_sorted, gv.tt_sorted, (size_t)P, gv.scan_tmp, true, stream);
+    SGR_STAGE("depth_sort+scan");
     prof_end(stream);
     const size_t nb = ((size_t)P + SGR_SCAN_ITEMS - 1) / SGR_SCAN_ITEMS;
     uint32_t host_vals[2] = {0, 0};
@@ -231,12 +240,12 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     int cur = 0;
     if (R > 0) {
         prof_begin(2, stream);
-        sgr_launch_duplicate(P, gv, radii_ptr, bv.keys[0], bv.vals[0], gx, stream);
+        sgr_launch_duplicate(P, gv, order, gv.tt_sorted, bv.keys[0], bv.vals[0], gx, stream);
         SGR_STAGE("duplicate");
         prof_end(stream);
         prof_begin(3, stream);
         const int bit = (int)getHigherMsb((uint32_t)T);  // rasterizer_impl.cu:303
-        cur = sgr_launch_sort_pairs(bv.keys, bv.vals, (uint32_t)R, 32 + bit, bv.hist, bv.scan_tmp, stream);
+        cur = sgr_launch_sort_pairs32(bv.keys, bv.vals, (uint32_t)R, bit, bv.hist, bv.scan_tmp, stream);
         SGR_STAGE("sort");
         prof_end(stream);
         prof_begin(4, stream);
@@ -256,7 +265,7 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
 // which of the two ping-pong pairs holds the sorted list: one flip per 8-bit pass
 static int sorted_index(int width, int height) {
     const int gx = (width + SGR_BLOCK_X - 1) / SGR_BLOCK_X, gy = (height + SGR_BLOCK_Y - 1) / SGR_BLOCK_Y;
-    const int end_bit = 32 + (int)getHigherMsb((uint32_t)(gx * gy));
+    const int end_bit = (int)getHigherMsb((uint32_t)(gx * gy));  // the tile sort only; depth order comes from the emission order
     return ((end_bit + 7) / 8) & 1;
 }
 
@@ -429,6 +438,8 @@ int sgr_export_internal(int which, int P, int R, int width, int height, char* ge
     if (which <= 7 || which == 14) {
         if (P <= 0) return 0;
         const SgrGeomView gv = sgr_geom_carve(geom_buffer, (size_t)P);
+        if (which == 7)  // the reference's index-order inclusive scan is not needed by the pipeline: made on demand
+            sgr_launch_scan(gv.tiles_touched, gv.point_offsets, (size_t)P, gv.scan_tmp, true, stream);
         sgr_export_kernel<<<(P + 255) / 256, 256, 0, stream>>>(which, P, gv, dst);
         SGR_STAGE("export");
         return 0;
@@ -437,8 +448,13 @@ int sgr_export_internal(int which, int P, int R, int width, int height, char* ge
         if (R <= 0) return 0;
         const SgrBinView bv = sgr_bin_carve(binning_buffer, (size_t)R);
         const int cur = sorted_index(width, height);
-        if (which == 8) SGR_HIP(hipMemcpyAsync(dst, bv.vals[cur], (size_t)R * 4, hipMemcpyDeviceToDevice, stream));
-        else SGR_HIP(hipMemcpyAsync(dst, bv.keys[cur], (size_t)R * 8, hipMemcpyDeviceToDevice, stream));
+        if (which == 8) {
+            SGR_HIP(hipMemcpyAsync(dst, bv.vals[cur], (size_t)R * 4, hipMemcpyDeviceToDevice, stream));
+        } else {
+            const SgrGeomView gv = sgr_geom_carve(geom_buffer, (size_t)P);
+            sgr_launch_compose_keys(R, bv.keys[cur], bv.vals[cur], gv.rec, (uint64_t*)dst, stream);
+            SGR_STAGE("export keys");
+        }
         return 0;
     }
     const SgrImgView iv = sgr_img_carve(image_buffer, N, T);
@@ -464,6 +480,16 @@ int sgr_test_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_t* v
     uint32_t* vals[2] = {vals0, vals1};
     const int cur = sgr_launch_sort_pairs(keys, vals, n, end_bit, hist, scan_tmp, stream);
     SGR_STAGE("sort");
+    return cur;
+}
+int sgr_test_sort32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, uint32_t n, int end_bit,
+                    uint32_t* hist, uint32_t* scan_tmp, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int debug = 1;
+    uint32_t* keys[2] = {keys0, keys1};
+    uint32_t* vals[2] = {vals0, vals1};
+    const int cur = sgr_launch_sort_pairs32(keys, vals, n, end_bit, hist, scan_tmp, stream);
+    SGR_STAGE("sort32");
     return cur;
 }
 size_t sgr_test_sort_hist_words(uint32_t n) { return (size_t)256 * sgr_sort_blocks(n ? n : 1); }

@@ -12,8 +12,9 @@
 //     -> ONE 64-byte, 64-byte-aligned record per Gaussian: a tile kernel's gather of an instance touches
 //        a single cache line (three separate arrays cost three lines per instance: measured 2-4x over-fetch)
 //     cov3D[6g..], tiles_touched[g], point_offsets[g] (inclusive), clamped[g] (3-bit mask), radii (if not given)
-//   binning buffer: 64-bit keys (tile<<32 | depth bits) and 32-bit Gaussian ids, ping-pong for the
-//     LSD radix sort, plus the per-block digit histograms.
+//   binning buffer: 32-bit tile keys and 32-bit Gaussian ids, ping-pong for the stable LSD radix sort by
+//     tile (the instances are emitted in (depth, id) order, so the reference's 64-bit (tile|depth) key
+//     order falls out of a stable sort on the tile bits alone), plus the per-block digit histograms.
 //   image buffer: n_contrib[H*W], ranges[tiles].
 #pragma once
 #include <hip/hip_runtime.h>
@@ -33,7 +34,11 @@ struct SgrGeomView {
     float4* rec;  // [4P]
     float* cov3D;
     uint32_t* tiles_touched;
-    uint32_t* point_offsets;
+    uint32_t* point_offsets;  // inclusive scan in index order: only materialised by sgr_export_internal (parity)
+    uint32_t* dkeys[2];       // depth bits per Gaussian (0xffffffff = culled), ping-pong for the depth sort
+    uint32_t* dvals[2];       // Gaussian ids; after the sort dvals[cur] = ids in (depth, id) order
+    uint32_t* tt_sorted;      // tiles_touched in depth order, inclusive-scanned in place
+    uint32_t* dhist;          // digit histogram of the depth sort
     uint32_t* clamped;  // 3-bit mask per Gaussian, one u32 each (keeps stores simple and aligned)
     int* internal_radii;
     uint32_t* scan_tmp;   // block sums of the device-wide scan
@@ -41,7 +46,7 @@ struct SgrGeomView {
 };
 
 struct SgrBinView {
-    uint64_t* keys[2];
+    uint32_t* keys[2];   // tile id per instance (the depth order is already in the emission order)
     uint32_t* vals[2];
     uint32_t* hist;      // [256][nblocks] per-pass digit histogram, exclusive-scanned in place
     uint32_t* scan_tmp;
@@ -80,7 +85,16 @@ static inline SgrGeomView sgr_geom_carve(char* base, size_t P, char** end = null
     sgr_carve(p, v.point_offsets, Pn);
     sgr_carve(p, v.clamped, Pn);
     sgr_carve(p, v.internal_radii, Pn);
-    sgr_carve(p, v.scan_tmp, sgr_scan_tmp_count(Pn));
+    sgr_carve(p, v.dkeys[0], Pn);
+    sgr_carve(p, v.dkeys[1], Pn);
+    sgr_carve(p, v.dvals[0], Pn);
+    sgr_carve(p, v.dvals[1], Pn);
+    sgr_carve(p, v.tt_sorted, Pn);
+    {
+        const size_t nh = (size_t)256 * ((Pn + SGR_SORT_ITEMS - 1) / SGR_SORT_ITEMS);
+        sgr_carve(p, v.dhist, nh);
+        sgr_carve(p, v.scan_tmp, sgr_scan_tmp_count(nh > Pn ? nh : Pn));
+    }
     if (end) *end = p;
     return v;
 }

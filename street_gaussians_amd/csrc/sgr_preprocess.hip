@@ -1,6 +1,6 @@
 // sgr_preprocess.hip -- per-Gaussian forward stage for gfx950:
 //   K1 mark_visible, K2 preprocess (cull + EWA projection + SH->RGB), K3 visible_filter,
-//   K6 duplicate-with-keys.
+//   K6 duplicate-with-keys (in depth order), K9 tile ranges.
 // Replaces checkFrustum / preprocessCUDA / filter_preprocessCUDA / duplicateWithKeys of the reference
 // (rasterizer_impl.cu:54-111, forward.cu:155-334).  One Gaussian per lane, 256-lane workgroups; the
 // outputs are packed into three float4 records per Gaussian so that the tile kernels gather each
@@ -67,9 +67,13 @@ sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         if (gv.header) atomicOr(&gv.header[0], 1u);  // reference: printf + __trap() (auxiliary.h:156-161); we raise on the host
     }
 
+    if (!FILTER) gv.dvals[0][idx] = (uint32_t)idx;
     if (!pr.ok) {
         radii[idx] = 0;
-        if (!FILTER) gv.tiles_touched[idx] = 0;
+        if (!FILTER) {
+            gv.tiles_touched[idx] = 0;
+            gv.dkeys[0][idx] = 0xffffffffu;  // sorts behind every real depth (> 0.2 => sign bit clear)
+        }
         return;
     }
     if (FILTER) {
@@ -138,18 +142,32 @@ sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     rec[3] = make_float4(0.f, __uint_as_float(sgr_pack_rect(pr.rx0, pr.ry0, w)), 0.f, 0.f);
     gv.clamped[idx] = clamped;
     gv.tiles_touched[idx] = w * h;
+    gv.dkeys[0][idx] = __float_as_uint(pr.depth);
     radii[idx] = pr.radius;
 }
 
-// ---- K6: one (key, value) per overlapped tile, row-major tile order (rasterizer_impl.cu:70-111) ----
+// ---- tiles_touched gathered in (depth, id) order, ready for the scan that gives every Gaussian its slot ----
 __global__ void __launch_bounds__(SGR_PRE_THREADS)
-sgr_duplicate_kernel(int P, SgrGeomView gv, const int* __restrict__ radii, uint64_t* __restrict__ keys,
-                     uint32_t* __restrict__ vals, int gx) {
-    const int idx = blockIdx.x * SGR_PRE_THREADS + threadIdx.x;
-    if (idx >= P) return;
-    if (!(radii[idx] > 0)) return;
-    uint32_t off = (idx == 0) ? 0u : gv.point_offsets[idx - 1];
+sgr_gather_tiles_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles_touched,
+                        uint32_t* __restrict__ tt_sorted) {
+    const int i = blockIdx.x * SGR_PRE_THREADS + threadIdx.x;
+    if (i >= P) return;
+    tt_sorted[i] = tiles_touched[order[i]];
+}
+
+// ---- K6: one (tile key, Gaussian id) per overlapped tile (rasterizer_impl.cu:70-111).  Lane i handles the i-th
+// Gaussian in (depth, id) order, so the instance array is already ordered by the low 32 bits of the reference's
+// 64-bit key and a STABLE sort on the tile id alone reproduces the reference's order, ties included.  The
+// Gaussian's first slot is also its first partial-gradient row in the backward (rec[3].x).
+__global__ void __launch_bounds__(SGR_PRE_THREADS)
+sgr_duplicate_kernel(int P, SgrGeomView gv, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offs_incl,
+                     uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int gx) {
+    const int i = blockIdx.x * SGR_PRE_THREADS + threadIdx.x;
+    if (i >= P) return;
+    const uint32_t idx = order[i];
     const uint32_t n = gv.tiles_touched[idx];
+    if (n == 0) return;
+    uint32_t off = (i == 0) ? 0u : offs_incl[i - 1];
     float4* rec = gv.rec + 4 * (size_t)idx;
     float4 d4 = rec[3];
     d4.x = __uint_as_float(off);
@@ -157,35 +175,40 @@ sgr_duplicate_kernel(int P, SgrGeomView gv, const int* __restrict__ radii, uint6
     const uint32_t dy = __float_as_uint(d4.y);
     const uint32_t x0 = dy & 1023u, y0 = (dy >> 10) & 1023u, w = dy >> 20;
     const uint32_t h = n / w;
-    const uint64_t depth_bits = (uint64_t)__float_as_uint(rec[2].w);
     for (uint32_t y = y0; y < y0 + h; y++) {
         for (uint32_t x = x0; x < x0 + w; x++) {
-            uint64_t key = (uint64_t)(y * (uint32_t)gx + x);
-            key <<= 32;
-            key |= depth_bits;
-            keys[off] = key;
-            vals[off] = (uint32_t)idx;
+            keys[off] = y * (uint32_t)gx + x;
+            vals[off] = idx;
             off++;
         }
     }
 }
 
-// ---- K9: tile ranges from the sorted keys (rasterizer_impl.cu:116-138) ------------------------
+// ---- K9: tile ranges from the sorted tile keys (rasterizer_impl.cu:116-138) -------------------
 __global__ void __launch_bounds__(256)
-sgr_tile_ranges_kernel(int L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges) {
+sgr_tile_ranges_kernel(int L, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= L) return;
-    const uint32_t currtile = (uint32_t)(keys[idx] >> 32);
+    const uint32_t currtile = keys[idx];
     if (idx == 0) {
         ranges[currtile].x = 0;
     } else {
-        const uint32_t prevtile = (uint32_t)(keys[idx - 1] >> 32);
+        const uint32_t prevtile = keys[idx - 1];
         if (currtile != prevtile) {
             ranges[prevtile].y = idx;
             ranges[currtile].x = idx;
         }
     }
     if (idx == L - 1) ranges[currtile].y = L;
+}
+
+// parity introspection: the reference's 64-bit sorted keys, recomposed from tile id and depth bits
+__global__ void __launch_bounds__(256)
+sgr_compose_keys_kernel(int L, const uint32_t* __restrict__ tile_keys, const uint32_t* __restrict__ point_list,
+                        const float4* __restrict__ rec, uint64_t* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= L) return;
+    out[i] = ((uint64_t)tile_keys[i] << 32) | (uint64_t)__float_as_uint(rec[4 * (size_t)point_list[i] + 2].w);
 }
 
 // ---- host launchers ---------------------------------------------------------------------------
@@ -213,13 +236,27 @@ void sgr_launch_filter(int P, const float* means3D, const float* scales, const f
         prefiltered);
 }
 
-void sgr_launch_duplicate(int P, const SgrGeomView& gv, const int* radii, uint64_t* keys, uint32_t* vals, int gx,
-                          hipStream_t s) {
+void sgr_launch_gather_tiles(int P, const uint32_t* order, const uint32_t* tiles_touched, uint32_t* tt_sorted,
+                             hipStream_t s) {
     if (P <= 0) return;
-    sgr_duplicate_kernel<<<(P + SGR_PRE_THREADS - 1) / SGR_PRE_THREADS, SGR_PRE_THREADS, 0, s>>>(P, gv, radii, keys, vals, gx);
+    sgr_gather_tiles_kernel<<<(P + SGR_PRE_THREADS - 1) / SGR_PRE_THREADS, SGR_PRE_THREADS, 0, s>>>(P, order, tiles_touched,
+                                                                                                tt_sorted);
 }
 
-void sgr_launch_tile_ranges(int L, const uint64_t* keys, uint2* ranges, hipStream_t s) {
+void sgr_launch_duplicate(int P, const SgrGeomView& gv, const uint32_t* order, const uint32_t* offs_incl, uint32_t* keys,
+                          uint32_t* vals, int gx, hipStream_t s) {
+    if (P <= 0) return;
+    sgr_duplicate_kernel<<<(P + SGR_PRE_THREADS - 1) / SGR_PRE_THREADS, SGR_PRE_THREADS, 0, s>>>(P, gv, order, offs_incl, keys,
+                                                                                             vals, gx);
+}
+
+void sgr_launch_tile_ranges(int L, const uint32_t* keys, uint2* ranges, hipStream_t s) {
     if (L <= 0) return;
     sgr_tile_ranges_kernel<<<(L + 255) / 256, 256, 0, s>>>(L, keys, ranges);
+}
+
+void sgr_launch_compose_keys(int L, const uint32_t* tile_keys, const uint32_t* point_list, const float4* rec, uint64_t* out,
+                             hipStream_t s) {
+    if (L <= 0) return;
+    sgr_compose_keys_kernel<<<(L + 255) / 256, 256, 0, s>>>(L, tile_keys, point_list, rec, out);
 }

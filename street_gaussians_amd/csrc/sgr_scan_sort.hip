@@ -100,8 +100,9 @@ void sgr_launch_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp,
 // radix sort
 // block b owns keys [b*2048, (b+1)*2048); wave w of the block owns 512 consecutive keys, read in 8
 // steps of 64 (lane l <-> key base + w*512 + step*64 + l), so memory order == (wave, step, lane).
+template <typename K>
 __global__ void __launch_bounds__(256)
-sgr_sort_hist_kernel(const uint64_t* __restrict__ keys, uint32_t n, int shift, uint32_t nblocks,
+sgr_sort_hist_kernel(const K* __restrict__ keys, uint32_t n, int shift, uint32_t nblocks,
                      uint32_t* __restrict__ hist) {
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
@@ -116,8 +117,9 @@ sgr_sort_hist_kernel(const uint64_t* __restrict__ keys, uint32_t n, int shift, u
     hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];  // [digit][block]
 }
 
+template <typename K>
 __global__ void __launch_bounds__(256)
-sgr_sort_scatter_kernel(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin, uint64_t* __restrict__ kout,
+sgr_sort_scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* __restrict__ kout,
                         uint32_t* __restrict__ vout, uint32_t n, int shift, uint32_t nblocks,
                         const uint32_t* __restrict__ hist_scanned) {
     __shared__ uint32_t cnt[4][256];
@@ -128,13 +130,13 @@ sgr_sort_scatter_kernel(const uint64_t* __restrict__ kin, const uint32_t* __rest
 
     const uint32_t base = blockIdx.x * SGR_SORT_ITEMS + wave * 512;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    uint64_t key[8];
+    K key[8];
     uint32_t val[8], rnk[8];
 #pragma unroll
     for (int s = 0; s < 8; s++) {
         const uint32_t i = base + s * 64 + lane;
         const bool valid = i < n;
-        key[s] = valid ? kin[i] : 0ull;
+        key[s] = valid ? kin[i] : (K)0;
         val[s] = valid ? vin[i] : 0u;
         const uint32_t d = (uint32_t)(key[s] >> shift) & 255u;
         uint64_t m = __ballot(valid);
@@ -183,18 +185,27 @@ sgr_sort_scatter_kernel(const uint64_t* __restrict__ kin, const uint32_t* __rest
 // of the pair of buffers that holds the sorted output.  hist: 256*nblocks words (+ scan_tmp).
 // The per-block digit histogram depends on where the previous pass left the keys, so it is
 // recomputed before every scatter pass.
-int sgr_launch_sort_pairs(uint64_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
-                          uint32_t* scan_tmp, hipStream_t s) {
+template <typename K>
+static int sort_pairs_impl(K* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
+                           uint32_t* scan_tmp, hipStream_t s) {
     if (n == 0) return 0;
     const int npass = (end_bit + 7) / 8;
     const uint32_t nblocks = (n + SGR_SORT_ITEMS - 1) / SGR_SORT_ITEMS;
     int cur = 0;
     for (int p = 0; p < npass; p++) {
-        sgr_sort_hist_kernel<<<nblocks, 256, 0, s>>>(keys[cur], n, 8 * p, nblocks, hist);
+        sgr_sort_hist_kernel<K><<<nblocks, 256, 0, s>>>(keys[cur], n, 8 * p, nblocks, hist);
         sgr_launch_scan(hist, hist, (size_t)256 * nblocks, scan_tmp, false, s);
-        sgr_sort_scatter_kernel<<<nblocks, 256, 0, s>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, 8 * p,
-                                                        nblocks, hist);
+        sgr_sort_scatter_kernel<K><<<nblocks, 256, 0, s>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, 8 * p,
+                                                           nblocks, hist);
         cur ^= 1;
     }
     return cur;
+}
+int sgr_launch_sort_pairs(uint64_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
+                          uint32_t* scan_tmp, hipStream_t s) {
+    return sort_pairs_impl<uint64_t>(keys, vals, n, end_bit, hist, scan_tmp, s);
+}
+int sgr_launch_sort_pairs32(uint32_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
+                            uint32_t* scan_tmp, hipStream_t s) {
+    return sort_pairs_impl<uint32_t>(keys, vals, n, end_bit, hist, scan_tmp, s);
 }

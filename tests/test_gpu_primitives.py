@@ -65,6 +65,27 @@ def test_sort_pairs_stable(n, end_bit, dup):
     assert (vs == vals[order]).all()
 
 
+@pytest.mark.parametrize("n,end_bit,dup", [(1, 14, False), (4097, 14, True), (2_500_000, 14, True), (1_000_000, 32, False)])
+def test_sort_pairs32_stable(n, end_bit, dup):
+    L, check = _lib()
+    rng = np.random.default_rng(n + 1)
+    hi = 1 << end_bit
+    keys = (rng.integers(0, 61, n, dtype=np.uint64) * (hi // 64) if dup else rng.integers(0, hi, n, dtype=np.uint64)).astype(np.uint32)
+    vals = np.arange(n, dtype=np.uint32)
+    k0 = torch.from_numpy(keys.view(np.int32)).cuda()
+    v0 = torch.from_numpy(vals.view(np.int32)).cuda()
+    k1, v1 = torch.zeros_like(k0), torch.zeros_like(v0)
+    hist = torch.zeros(L.sgr_test_sort_hist_words(n), dtype=torch.int32, device="cuda")
+    tmp = torch.zeros(L.sgr_test_scan_tmp_words(hist.numel()), dtype=torch.int32, device="cuda")
+    cur = check(L.sgr_test_sort32(_vp(k0), _vp(k1), _vp(v0), _vp(v1), n, end_bit, _vp(hist), _vp(tmp), None))
+    torch.cuda.synchronize()
+    ks = (k1 if cur else k0).cpu().numpy().view(np.uint32)
+    vs = (v1 if cur else v0).cpu().numpy().view(np.uint32)
+    order = np.argsort(keys, kind="stable")
+    assert (ks == keys[order]).all()
+    assert (vs == vals[order]).all()
+
+
 def test_wave_sum_dpp_equals_shuffle():
     L, check = _lib()
     nw = 257
