@@ -172,12 +172,17 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
     __shared__ float4 sB[SGR_TILE_THREADS];  // {qa, qb, qc, opacity}
     __shared__ float4 sC[SGR_TILE_THREADS];  // {r, g, b, depth}
     __shared__ uint32_t sU[SGR_TILE_THREADS];
-    __shared__ uint32_t sFlag[SGR_TILE_THREADS];  // DET: one byte per wave (bit set = that wave stored a partial)
+    __shared__ uint32_t sFlag[SGR_TILE_THREADS];
     __shared__ uint64_t sBits[4][4];
     __shared__ int sMax[4];
-    // DET: one accumulator row per (wave, slot), written with plain stores and summed in wave order when the
-    // row is flushed -> bit-reproducible.  !DET: one row per slot, the four waves combine with ds_add_f32.
-    __shared__ __attribute__((aligned(16))) float sAcc[(DET ? 4 : 1) * SGR_TILE_THREADS * ACCW];
+    // The (up to four) wave partials of an instance meet in LDS with ds_add_f32.  DET: two zero-initialised
+    // rows per slot, waves {0,1} add into row 0 and waves {2,3} into row 1, the flush adds row 0 + row 1.  Every
+    // float add then has exactly two operands (x + 0 is exact), and two-operand addition commutes, so the result
+    // does not depend on the order in which the waves arrive: bit-reproducible at half the LDS of per-wave rows.
+    // !DET: a single row shared by all four waves (arrival order can change the last bit, like the reference's
+    // atomicAdd).
+    constexpr int NROW = DET ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) float sAcc[NROW * SGR_TILE_THREADS * ACCW];
     __shared__ float sSem[SMAX > 0 ? SGR_TILE_THREADS * SMAX : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -236,9 +241,11 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
         const int pos = hi - tid;
         uint32_t mask4 = 0;
         sFlag[tid] = 0;
-        if (!DET) {
 #pragma unroll
-            for (int k = 0; k < ACCW; k++) sAcc[tid * ACCW + k] = 0.f;
+        for (int rr = 0; rr < NROW; rr++) {
+            float4* z = reinterpret_cast<float4*>(&sAcc[(rr * SGR_TILE_THREADS + tid) * ACCW]);
+#pragma unroll
+            for (int k4 = 0; k4 < ACCW / 4; k4++) z[k4] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (pos >= 0) {
             const uint32_t g = point_list[range.x + (uint32_t)pos];
@@ -350,16 +357,10 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                 }
                 if ((lane & 15) == 0) {  // one lane per 16-lane row stores that row's values
                     const int k = lane >> 4;
-                    if (DET) {
-                        float* dst = &sAcc[(wave * SGR_TILE_THREADS + j) * ACCW + k];
+                    float* dst = &sAcc[((DET ? (wave >> 1) : 0) * SGR_TILE_THREADS + j) * ACCW + k];
 #pragma unroll
-                        for (int t = 0; t < NVAL / 4; t++) dst[4 * t] = r[t];
-                        if (k == 0) reinterpret_cast<uint8_t*>(sFlag)[4 * j + wave] = 1;
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < NVAL / 4; t++) atomicAdd(&sAcc[j * ACCW + 4 * t + k], r[t]);
-                        if (k == 0) sFlag[j] = 1u;
-                    }
+                    for (int t = 0; t < NVAL / 4; t++) atomicAdd(&dst[4 * t], r[t]);
+                    if (k == 0) sFlag[j] = 1u;
                 }
         };
         for (int chunk = 0; chunk < 4; chunk++) {
@@ -394,22 +395,18 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
             float4 r[NVAL / 4];
 #pragma unroll
             for (int k4 = 0; k4 < NVAL / 4; k4++) r[k4] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (DET) {
-#pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    if ((flags >> (8 * w)) & 0xffu) {
-                        const float4* src = reinterpret_cast<const float4*>(&sAcc[(w * SGR_TILE_THREADS + tid) * ACCW]);
-#pragma unroll
-                        for (int k4 = 0; k4 < NVAL / 4; k4++) {
-                            const float4 t = src[k4];
-                            r[k4].x += t.x; r[k4].y += t.y; r[k4].z += t.z; r[k4].w += t.w;
-                        }
-                    }
-                }
-            } else {
+            {
                 const float4* src = reinterpret_cast<const float4*>(&sAcc[tid * ACCW]);
 #pragma unroll
                 for (int k4 = 0; k4 < NVAL / 4; k4++) r[k4] = src[k4];
+                if (DET) {
+                    const float4* src1 = reinterpret_cast<const float4*>(&sAcc[(SGR_TILE_THREADS + tid) * ACCW]);
+#pragma unroll
+                    for (int k4 = 0; k4 < NVAL / 4; k4++) {
+                        const float4 t = src1[k4];
+                        r[k4].x += t.x; r[k4].y += t.y; r[k4].z += t.z; r[k4].w += t.w;
+                    }
+                }
             }
 #pragma unroll
             for (int k4 = 0; k4 < NVAL / 4; k4++) row[k4] = make_float4(r[k4].x, r[k4].z, r[k4].y, r[k4].w);
@@ -423,7 +420,7 @@ static void launch_bwd(bool cull, bool dpp, bool det, unsigned tiles, hipStream_
                        const float* alphas,
                        const uint32_t* n_contrib, const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha,
                        const float* dL_dsem, float* partials, int row_stride, uint8_t* touched) {
-    // per-wave accumulators (deterministic) need 4*256*ACCW floats of LDS: used up to 16 semantic channels
+    // the deterministic combine needs 2*256*ACCW floats of LDS: used up to 16 semantic channels
     constexpr bool kDet = SMAX <= 16;
 #define SGR_GO(C, D)                                                                                                 \
     do {                                                                                                             \
