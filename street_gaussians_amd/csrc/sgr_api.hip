@@ -27,7 +27,8 @@ void sgr_launch_compose_keys(int L, const uint32_t* tile_keys, const uint32_t* p
                              hipStream_t s);
 int sgr_launch_sort_pairs32(uint32_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
                             uint32_t* scan_tmp, hipStream_t s);
-void sgr_launch_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, bool inclusive, hipStream_t s);
+void sgr_launch_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, bool inclusive, hipStream_t s,
+                     uint32_t* total_out = nullptr);
 int sgr_launch_sort_pairs(uint64_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
                           uint32_t* scan_tmp, hipStream_t s);
 void sgr_launch_blend_fwd(bool cull, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W, int H,
@@ -99,6 +100,13 @@ static int fail(int code, const std::string& msg) {
         if (e__ == hipSuccess && debug) e__ = hipStreamSynchronize(stream);                               \
         if (e__ != hipSuccess) return fail(SGR_E_HIP, std::string("stage ") + name + ": " + hipGetErrorString(e__)); \
     } while (0)
+
+// per-thread pinned landing zone for the forward's one device->host readback
+static uint32_t* pinned_pair() {
+    static thread_local uint32_t* p = nullptr;
+    if (!p && hipHostMalloc((void**)&p, 64, hipHostMallocDefault) != hipSuccess) p = nullptr;
+    return p;
+}
 
 // rasterizer_impl.cu:35-50
 static uint32_t getHigherMsb(uint32_t n) {
@@ -220,18 +228,18 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     const int dcur = sgr_launch_sort_pairs32(gv.dkeys, gv.dvals, (uint32_t)P, 32, gv.dhist, gv.scan_tmp, stream);
     const uint32_t* order = gv.dvals[dcur];
     sgr_launch_gather_tiles(P, order, gv.tiles_touched, gv.tt_sorted, stream);
-    sgr_launch_scan(gv.tt_sorted, gv.tt_sorted, (size_t)P, gv.scan_tmp, true, stream);
+    sgr_launch_scan(gv.tt_sorted, gv.tt_sorted, (size_t)P, gv.scan_tmp, true, stream, gv.header + 1);
     SGR_STAGE("depth_sort+scan");
     prof_end(stream);
-    const size_t nb = ((size_t)P + SGR_SCAN_ITEMS - 1) / SGR_SCAN_ITEMS;
-    uint32_t host_vals[2] = {0, 0};
-    SGR_HIP(hipMemcpyAsync(&host_vals[0], gv.scan_tmp + nb, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    SGR_HIP(hipMemcpyAsync(&host_vals[1], gv.header, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    // header[0] = prefilter flag, header[1] = num_rendered: ONE 8-byte copy into pinned host memory
+    uint32_t* host_vals = pinned_pair();
+    if (!host_vals) return fail(SGR_E_HIP, "hipHostMalloc failed");
+    SGR_HIP(hipMemcpyAsync(host_vals, gv.header, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     SGR_HIP(hipStreamSynchronize(stream));
-    if (host_vals[1] & 1u)
+    if (host_vals[0] & 1u)
         return fail(SGR_E_PREFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
-    if (host_vals[0] > 0x7fffffffu) return fail(SGR_E_INVALID, "more than 2^31 tile instances");
-    const int R = (int)host_vals[0];
+    if (host_vals[1] > 0x7fffffffu) return fail(SGR_E_INVALID, "more than 2^31 tile instances");
+    const int R = (int)host_vals[1];
 
     char* bbase = binning_buffer(sgr_binning_bytes(R), binning_user);
     if (!bbase) return fail(SGR_E_ALLOC, "binning buffer allocation failed");

@@ -104,27 +104,58 @@ sgr_gauss_bwd_kernel(int P, int D, int M, int S, const float* __restrict__ means
         // view-direction path adds dnormvdv(dir_orig, dL/ddir) to dL/dmean (backward.cu:131-138).
         float* dsh = dL_dsh + (size_t)idx * M * 3;
         const int ncoef = (D + 1) * (D + 1);
+        const bool vec = ((M * 3) & 3) == 0 && M <= 16;  // 16-byte aligned rows: stream them as float4
+        float shl[48];
+        float dshv[48];
+#pragma unroll
+        for (int k = 0; k < 48; k++) { shl[k] = 0.f; dshv[k] = 0.f; }
         if (visible) {
             float Y[16];
             sgr_sh_basis(D, dir[0], dir[1], dir[2], Y);
             const float* sh = shs + (size_t)idx * M * 3;
-            float shl[48];
+            if (vec) {
+                const float4* sh4 = reinterpret_cast<const float4*>(sh);
+                const int n4 = (ncoef * 3 + 3) >> 2;
+#pragma unroll
+                for (int i = 0; i < 12; i++) {
+                    if (i < n4) {
+                        const float4 t = sh4[i];
+                        shl[4 * i] = t.x; shl[4 * i + 1] = t.y; shl[4 * i + 2] = t.z; shl[4 * i + 3] = t.w;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 16; k++) {  // entries past the active degree were loaded as padding: clear them
+                    if (k >= ncoef) { shl[3 * k] = 0.f; shl[3 * k + 1] = 0.f; shl[3 * k + 2] = 0.f; }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    if (k < ncoef) { shl[3 * k] = sh[3 * k]; shl[3 * k + 1] = sh[3 * k + 1]; shl[3 * k + 2] = sh[3 * k + 2]; }
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 if (k < ncoef) {
-                    shl[3 * k] = sh[3 * k]; shl[3 * k + 1] = sh[3 * k + 1]; shl[3 * k + 2] = sh[3 * k + 2];
-                    dsh[3 * k] = Y[k] * dRGB[0]; dsh[3 * k + 1] = Y[k] * dRGB[1]; dsh[3 * k + 2] = Y[k] * dRGB[2];
-                } else {
-                    shl[3 * k] = 0.f; shl[3 * k + 1] = 0.f; shl[3 * k + 2] = 0.f;
+                    dshv[3 * k] = Y[k] * dRGB[0]; dshv[3 * k + 1] = Y[k] * dRGB[1]; dshv[3 * k + 2] = Y[k] * dRGB[2];
                 }
             }
-            for (int k = ncoef; k < M; k++) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
             float ddir[3], dm[3];
             sgr_sh_dir_backward(D, dir[0], dir[1], dir[2], shl, dRGB, ddir);
             sgr_dnormvdv(dir_orig, ddir, dm);
             dmean[0] += dm[0]; dmean[1] += dm[1]; dmean[2] += dm[2];
+        }
+        // dL/dSH row: Y_k * dL/dRGB below the active degree, zeros above and for culled Gaussians
+        if (vec) {
+            float4* dsh4 = reinterpret_cast<float4*>(dsh);
+            const int n4 = (M * 3) >> 2;
+#pragma unroll
+            for (int i = 0; i < 12; i++)
+                if (i < n4) dsh4[i] = make_float4(dshv[4 * i], dshv[4 * i + 1], dshv[4 * i + 2], dshv[4 * i + 3]);
         } else {
-            for (int k = 0; k < M * 3; k++) dsh[k] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 48; k++)
+                if (k < M * 3) dsh[k] = dshv[k];
+            for (int k = 48; k < M * 3; k++) dsh[k] = 0.f;
         }
     }
 

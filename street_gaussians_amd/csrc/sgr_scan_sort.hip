@@ -10,6 +10,9 @@
 // lanes is the stable rank) and per-wave LDS digit counters -- no atomics, fully deterministic.
 #include "sgr_common.h"
 
+void sgr_launch_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, bool inclusive, hipStream_t s,
+                     uint32_t* total_out = nullptr);
+
 // ------------------------------------------------------------------------------------------------
 // wave / block primitives
 __device__ __forceinline__ uint32_t sgr_wave_incl_scan(uint32_t v, int lane) {
@@ -50,7 +53,8 @@ __global__ void __launch_bounds__(256) sgr_scan_reduce_kernel(const uint32_t* __
 }
 
 // single block: exclusive scan of block_sums[0..nb) in place; block_sums[nb] = grand total
-__global__ void __launch_bounds__(256) sgr_scan_spine_kernel(uint32_t* __restrict__ block_sums, size_t nb) {
+__global__ void __launch_bounds__(256) sgr_scan_spine_kernel(uint32_t* __restrict__ block_sums, size_t nb,
+                                                             uint32_t* __restrict__ total_out) {
     __shared__ uint32_t lds4[4];
     uint32_t carry = 0;
     for (size_t start = 0; start < nb; start += 256) {
@@ -61,7 +65,10 @@ __global__ void __launch_bounds__(256) sgr_scan_spine_kernel(uint32_t* __restric
         if (i < nb) block_sums[i] = carry + ex;
         carry += total;
     }
-    if (threadIdx.x == 0) block_sums[nb] = carry;
+    if (threadIdx.x == 0) {
+        block_sums[nb] = carry;
+        if (total_out) *total_out = carry;
+    }
 }
 
 template <bool INCLUSIVE>
@@ -86,12 +93,15 @@ __global__ void __launch_bounds__(256) sgr_scan_final_kernel(const uint32_t* __r
     }
 }
 
-// out may alias in.  tmp needs sgr_scan_tmp_count(n) words; tmp[nblocks] receives the grand total.
-void sgr_launch_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, bool inclusive, hipStream_t s) {
+// out may alias in.  tmp needs sgr_scan_tmp_count(n) words; tmp[nblocks] receives the grand total, and so does
+// *total_out when given.
+void sgr_launch_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, bool inclusive, hipStream_t s,
+                     uint32_t* total_out) {
     if (n == 0) return;
     const size_t nb = (n + SGR_SCAN_ITEMS - 1) / SGR_SCAN_ITEMS;
+
     sgr_scan_reduce_kernel<<<(unsigned)nb, 256, 0, s>>>(in, n, tmp);
-    sgr_scan_spine_kernel<<<1, 256, 0, s>>>(tmp, nb);
+    sgr_scan_spine_kernel<<<1, 256, 0, s>>>(tmp, nb, total_out);
     if (inclusive) sgr_scan_final_kernel<true><<<(unsigned)nb, 256, 0, s>>>(in, out, n, tmp);
     else sgr_scan_final_kernel<false><<<(unsigned)nb, 256, 0, s>>>(in, out, n, tmp);
 }
