@@ -94,8 +94,12 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    force_dist = bool(os.environ.get("SGR_BENCH_FORCE_DIST"))  # exercise the RCCL path on a single GPU (testing)
+    if world > 1 or force_dist:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29511"
+            os.environ.setdefault("RANK", "0"), os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
@@ -117,7 +121,7 @@ def main():
         bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=cam.viewmatrix.to(dev),
         projmatrix=cam.projmatrix.to(dev), sh_degree=3, campos=cam.campos.to(dev), prefiltered=False, debug=False)
     rast = GaussianRasterizer(st)
-    reducer = multiview.GradReducer(list(params.values()) + [means2D]) if world > 1 else None
+    reducer = multiview.GradReducer(list(params.values()) + [means2D], force=force_dist) if dist is not None else None
     stats = {}
 
     def step():
@@ -227,7 +231,11 @@ def main():
             except Exception as ex:  # the baseline is a reported extra; never lose the GPU number over it
                 line["cpu_baseline"] = {"value": None, "unit": "iters/s", "cores": os.cpu_count(), "kind": "port",
                                         "sample": f"failed: {ex}"}
-        print(json.dumps(line))
+        try:  # RCCL prints a version banner through C stdio; flush it so the JSON line stays the last line
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

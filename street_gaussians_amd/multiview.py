@@ -24,11 +24,12 @@ class GradReducer:
     """All-reduce (sum) of the ``.grad`` of a fixed list of parameters through one flat bucket."""
 
     def __init__(self, params: Iterable[torch.Tensor], group: Optional[dist.ProcessGroup] = None, mode: str = "all_reduce",
-                 average: bool = False):
+                 average: bool = False, force: bool = False):
         self.params: List[torch.Tensor] = list(params)
         self.group = group
         self.mode = mode
         self.average = average
+        self.force = force  # run the collective even with one rank (testing)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._numel = [p.numel() for p in self.params]
         total = sum(self._numel)
@@ -47,7 +48,7 @@ class GradReducer:
 
     def all_reduce(self) -> None:
         """Sum gradients over all ranks; ``p.grad`` is replaced by a view of the reduced bucket."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         grads = [p.grad if p.grad is not None else torch.zeros_like(v) for p, v in zip(self.params, self._views)]
         torch._foreach_copy_(self._views, grads)
