@@ -159,7 +159,7 @@ void sgr_launch_wave_sum_test(const float* in, float* out_dpp, float* out_shfl, 
 template <int SMAX, bool CULL, bool DPP, bool DET>
 __global__ void __launch_bounds__(SGR_TILE_THREADS)
 sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int S,
-                     int gx, const float* __restrict__ bg_color, const float4* __restrict__ rec,
+                     int gx, int gy, const float* __restrict__ bg_color, const float4* __restrict__ rec,
                      const float* __restrict__ semantics, const float* __restrict__ alphas,
                      const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
                      const float* __restrict__ dL_dpixel_depths, const float* __restrict__ dL_dalphas,
@@ -186,8 +186,9 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
     __shared__ float sSem[SMAX > 0 ? SGR_TILE_THREADS * SMAX : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t tile = blockIdx.x;
-    const uint32_t tx = tile % (uint32_t)gx, ty = tile / (uint32_t)gx;
+    uint32_t tx, ty;
+    if (!sgr_xcd_tile(blockIdx.x, (uint32_t)gx, (uint32_t)gy, tx, ty)) return;  // whole workgroup: padding block
+    const uint32_t tile = ty * (uint32_t)gx + tx;
     const uint32_t px = tx * SGR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
     const uint32_t py = ty * SGR_BLOCK_Y + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < (uint32_t)W && py < (uint32_t)H;
@@ -416,7 +417,7 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
 
 template <int SMAX>
 static void launch_bwd(bool cull, bool dpp, bool det, unsigned tiles, hipStream_t s, const uint2* ranges, const uint32_t* point_list,
-                       int W, int H, int S, int gx, const float* bg, const float4* rec, const float* semantics,
+                       int W, int H, int S, int gx, int gy, const float* bg, const float4* rec, const float* semantics,
                        const float* alphas,
                        const uint32_t* n_contrib, const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha,
                        const float* dL_dsem, float* partials, int row_stride, uint8_t* touched) {
@@ -426,11 +427,11 @@ static void launch_bwd(bool cull, bool dpp, bool det, unsigned tiles, hipStream_
     do {                                                                                                             \
         if (kDet && det)                                                                                             \
             sgr_blend_bwd_kernel<SMAX, C, D, kDet><<<tiles, SGR_TILE_THREADS, 0, s>>>(                                \
-                ranges, point_list, W, H, S, gx, bg, rec, semantics, alphas, n_contrib, dL_dpix, dL_ddepth,            \
+                ranges, point_list, W, H, S, gx, gy, bg, rec, semantics, alphas, n_contrib, dL_dpix, dL_ddepth,        \
                 dL_dalpha, dL_dsem, partials, row_stride, touched);                                                   \
         else                                                                                                         \
             sgr_blend_bwd_kernel<SMAX, C, D, false><<<tiles, SGR_TILE_THREADS, 0, s>>>(                               \
-                ranges, point_list, W, H, S, gx, bg, rec, semantics, alphas, n_contrib, dL_dpix, dL_ddepth,            \
+                ranges, point_list, W, H, S, gx, gy, bg, rec, semantics, alphas, n_contrib, dL_dpix, dL_ddepth,        \
                 dL_dalpha, dL_dsem, partials, row_stride, touched);                                                   \
     } while (0)
     if (cull && dpp) SGR_GO(true, true);
@@ -447,10 +448,10 @@ void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, int gx, int gy, const u
                           int H, int S, const float* bg, const float4* rec, const float* semantics, const float* alphas, const uint32_t* n_contrib,
                           const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha, const float* dL_dsem,
                           float* partials, uint8_t* touched, hipStream_t s) {
-    const unsigned tiles = (unsigned)gx * (unsigned)gy;
-    if (tiles == 0) return;
+    if (gx <= 0 || gy <= 0) return;
+    const unsigned tiles = sgr_xcd_grid_blocks(gx, gy);  // supertile-ordered grid incl. padding blocks
     const int stride = sgr_partial_row_stride(S);
-#define SGR_BWD(N) launch_bwd<N>(cull, dpp, det, tiles, s, ranges, point_list, W, H, S, gx, bg, rec, semantics, alphas, \
+#define SGR_BWD(N) launch_bwd<N>(cull, dpp, det, tiles, s, ranges, point_list, W, H, S, gx, gy, bg, rec, semantics, alphas, \
                                  n_contrib, dL_dpix, dL_ddepth, dL_dalpha, dL_dsem, partials, stride, touched)
     if (S == 0) SGR_BWD(0);
     else if (S <= 4) SGR_BWD(4);

@@ -18,7 +18,7 @@
 template <int SMAX, bool CULL>
 __global__ void __launch_bounds__(SGR_TILE_THREADS)
 sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int S,
-                     int gx, const float4* __restrict__ rec, const float* __restrict__ semantics,
+                     int gx, int gy, const float4* __restrict__ rec, const float* __restrict__ semantics,
                      const float* __restrict__ bg_color, float* __restrict__ out_color, float* __restrict__ out_depth,
                      float* __restrict__ out_alpha, float* __restrict__ out_semantic, uint32_t* __restrict__ n_contrib) {
     __shared__ float4 sA[SGR_TILE_THREADS];  // {x, y, -, -}
@@ -28,8 +28,9 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
     __shared__ float sSem[SMAX > 0 ? SGR_TILE_THREADS * SMAX : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t tile = blockIdx.x;
-    const uint32_t tx = tile % (uint32_t)gx, ty = tile / (uint32_t)gx;
+    uint32_t tx, ty;
+    if (!sgr_xcd_tile(blockIdx.x, (uint32_t)gx, (uint32_t)gy, tx, ty)) return;  // whole workgroup: padding block
+    const uint32_t tile = ty * (uint32_t)gx + tx;
     const uint32_t px = tx * SGR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
     const uint32_t py = ty * SGR_BLOCK_Y + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < (uint32_t)W && py < (uint32_t)H;
@@ -145,14 +146,14 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
 
 template <int SMAX>
 static void launch_fwd(bool cull, unsigned tiles, hipStream_t s, const uint2* ranges, const uint32_t* point_list, int W,
-                       int H, int S, int gx, const float4* rec, const float* semantics, const float* bg, float* out_color, float* out_depth, float* out_alpha,
+                       int H, int S, int gx, int gy, const float4* rec, const float* semantics, const float* bg, float* out_color, float* out_depth, float* out_alpha,
                        float* out_semantic, uint32_t* n_contrib) {
     if (cull)
-        sgr_blend_fwd_kernel<SMAX, true><<<tiles, SGR_TILE_THREADS, 0, s>>>(ranges, point_list, W, H, S, gx, rec, semantics,
+        sgr_blend_fwd_kernel<SMAX, true><<<tiles, SGR_TILE_THREADS, 0, s>>>(ranges, point_list, W, H, S, gx, gy, rec, semantics,
                                                                            bg, out_color, out_depth, out_alpha,
                                                                            out_semantic, n_contrib);
     else
-        sgr_blend_fwd_kernel<SMAX, false><<<tiles, SGR_TILE_THREADS, 0, s>>>(ranges, point_list, W, H, S, gx, rec, semantics,
+        sgr_blend_fwd_kernel<SMAX, false><<<tiles, SGR_TILE_THREADS, 0, s>>>(ranges, point_list, W, H, S, gx, gy, rec, semantics,
                                                                             bg, out_color, out_depth, out_alpha,
                                                                             out_semantic, n_contrib);
 }
@@ -162,9 +163,9 @@ void sgr_launch_blend_fwd(bool cull, int gx, int gy, const uint2* ranges, const 
                           int S, const float4* rec, const float* semantics,
                           const float* bg, float* out_color, float* out_depth, float* out_alpha, float* out_semantic,
                           uint32_t* n_contrib, hipStream_t s) {
-    const unsigned tiles = (unsigned)gx * (unsigned)gy;
-    if (tiles == 0) return;
-#define SGR_FWD(N) launch_fwd<N>(cull, tiles, s, ranges, point_list, W, H, S, gx, rec, semantics, bg, \
+    if (gx <= 0 || gy <= 0) return;
+    const unsigned tiles = sgr_xcd_grid_blocks(gx, gy);  // supertile-ordered grid incl. padding blocks
+#define SGR_FWD(N) launch_fwd<N>(cull, tiles, s, ranges, point_list, W, H, S, gx, gy, rec, semantics, bg, \
                                  out_color, out_depth, out_alpha, out_semantic, n_contrib)
     if (S == 0) SGR_FWD(0);
     else if (S <= 4) SGR_FWD(4);

@@ -136,6 +136,24 @@ static inline size_t sgr_required(F carve) {
 }
 
 #ifdef __HIPCC__
+// XCD-aware workgroup -> tile map.  The dispatcher places workgroup b on XCD b % 8 (observed, used for speed only),
+// and each XCD has a private 4 MiB L2.  A splat's instances live in neighbouring tiles, so neighbouring tiles
+// should share an L2: workgroups are handed out in 8x8-tile supertiles (128x128 px), supertile k going to XCD
+// k % 8.  Returns false for the padding workgroups past the last supertile / outside the grid.
+#define SGR_ST 8
+static inline unsigned sgr_xcd_grid_blocks(int gx, int gy) {
+    const unsigned nst = (unsigned)((gx + SGR_ST - 1) / SGR_ST) * (unsigned)((gy + SGR_ST - 1) / SGR_ST);
+    return ((nst + 7u) / 8u) * 8u * (SGR_ST * SGR_ST);
+}
+__device__ __forceinline__ bool sgr_xcd_tile(uint32_t b, uint32_t gx, uint32_t gy, uint32_t& tx, uint32_t& ty) {
+    const uint32_t x = b & 7u, q = b >> 3;
+    const uint32_t st = (q / (SGR_ST * SGR_ST)) * 8u + x, within = q % (SGR_ST * SGR_ST);
+    const uint32_t sgx = (gx + SGR_ST - 1) / SGR_ST;
+    tx = (st % sgx) * SGR_ST + (within % SGR_ST);
+    ty = (st / sgx) * SGR_ST + (within / SGR_ST);
+    return tx < gx && ty < gy;
+}
+
 // Move a wave-uniform 64-bit value into SGPRs.  __builtin_amdgcn_readfirstlane returns a SIGNED int:
 // each half must go through uint32_t, otherwise bit 31 of the low word sign-extends over the high word.
 __device__ __forceinline__ uint64_t sgr_uniform_u64(uint64_t v) {
