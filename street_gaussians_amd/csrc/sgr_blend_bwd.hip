@@ -183,7 +183,7 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
     // atomicAdd).
     constexpr int NROW = DET ? 2 : 1;
     __shared__ __attribute__((aligned(16))) float sAcc[NROW * SGR_TILE_THREADS * ACCW];
-    __shared__ float sSem[SMAX > 0 ? SGR_TILE_THREADS * SMAX : 1];
+    __shared__ __attribute__((aligned(16))) float sSem[SMAX > 0 ? SGR_TILE_THREADS * SMAX : 4];  // zero-padded to SMAX
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t tx, ty;
@@ -261,7 +261,8 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
             const uint32_t rx0 = dy_ & 1023u, ry0 = (dy_ >> 10) & 1023u, rw = dy_ >> 20;
             sU[tid] = __float_as_uint(d4.x) + (ty - ry0) * rw + (tx - rx0);
             if (SMAX > 0) {
-                for (int ch = 0; ch < S; ch++) sSem[tid * SMAX + ch] = semantics[(size_t)g * S + ch];
+#pragma unroll
+                for (int ch = 0; ch < SMAX; ch++) sSem[tid * SMAX + ch] = ch < S ? semantics[(size_t)g * S + ch] : 0.0f;
             }
             mask4 = CULL ? sgr_quadrant_mask(a, b, tx0, ty0) : 0xFu;
         }
@@ -300,16 +301,20 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                     dopa = fmaf(c.w - ad, dLdD, dopa);
                     const float aa = fmaf(one_m_la, accA, last_alpha);
                     dopa = fmaf(1.0f - aa, dLdA, dopa);
-                    if (SMAX > 0) {
+                    if (SMAX > 0) {  // padded channels carry zeros end to end (sSem, dLdS), so no per-channel test
+                        const float4* sj = reinterpret_cast<const float4*>(&sSem[j * SMAX]);
 #pragma unroll
-                        for (int ch = 0; ch < SMAX; ch++) {
-                            if (ch < S) {
-                                const float sv = sSem[j * SMAX + ch];
+                        for (int c4 = 0; c4 < SMAX / 4; c4++) {
+                            const float4 s4 = sj[c4];
+                            const float svv[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const int ch = 4 * c4 + e;
                                 const float as = fmaf(last_alpha, lastS[ch], one_m_la * accS[ch]);
-                                dopa = fmaf(sv - as, dLdS[ch], dopa);
+                                dopa = fmaf(svv[e] - as, dLdS[ch], dopa);
                                 v[SGR_ROW_BASE + ch] = wm * dLdS[ch];
                                 accS[ch] = hit ? as : accS[ch];
-                                lastS[ch] = hit ? sv : lastS[ch];
+                                lastS[ch] = hit ? svv[e] : lastS[ch];
                             }
                         }
                     }
@@ -421,8 +426,9 @@ static void launch_bwd(bool cull, bool dpp, bool det, unsigned tiles, hipStream_
                        const float* alphas,
                        const uint32_t* n_contrib, const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha,
                        const float* dL_dsem, float* partials, int row_stride, uint8_t* touched) {
-    // the deterministic combine needs 2*256*ACCW floats of LDS: used up to 16 semantic channels
-    constexpr bool kDet = SMAX <= 16;
+    // the deterministic combine needs 2*256*ACCW floats of LDS: used up to 8 semantic channels (60 KB total)
+    constexpr bool kDet = SMAX <= 8;
+    if (SMAX > 4) { cull = true; dpp = true; }  // the A/B switches (tests) exist for the small instantiations only
 #define SGR_GO(C, D)                                                                                                 \
     do {                                                                                                             \
         if (kDet && det)                                                                                             \
@@ -435,14 +441,16 @@ static void launch_bwd(bool cull, bool dpp, bool det, unsigned tiles, hipStream_
                 dL_dalpha, dL_dsem, partials, row_stride, touched);                                                   \
     } while (0)
     if (cull && dpp) SGR_GO(true, true);
-    else if (cull) SGR_GO(true, false);
-    else if (dpp) SGR_GO(false, true);
-    else SGR_GO(false, false);
+    else if constexpr (SMAX <= 4) {
+        if (cull) SGR_GO(true, false);
+        else if (dpp) SGR_GO(false, true);
+        else SGR_GO(false, false);
+    }
 #undef SGR_GO
 }
 
 // floats per partial row for S semantic channels: the kernel's SMAX bucket writes ceil((11+SMAX)/4) float4
-int sgr_partial_row_stride(int S) { return S <= 4 ? 16 : (S <= 16 ? 32 : 48); }
+int sgr_partial_row_stride(int S) { return S <= 4 ? 16 : (S <= 20 ? 32 : 48); }
 
 void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
                           int H, int S, const float* bg, const float4* rec, const float* semantics, const float* alphas, const uint32_t* n_contrib,
@@ -456,7 +464,10 @@ void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, int gx, int gy, const u
     if (S == 0) SGR_BWD(0);
     else if (S <= 4) SGR_BWD(4);
     else if (S <= 8) SGR_BWD(8);
+    else if (S <= 12) SGR_BWD(12);
     else if (S <= 16) SGR_BWD(16);
+    else if (S <= 20) SGR_BWD(20);
+    else if (S <= 24) SGR_BWD(24);
     else SGR_BWD(32);
 #undef SGR_BWD
 }

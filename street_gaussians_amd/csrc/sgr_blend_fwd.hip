@@ -25,7 +25,7 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
     __shared__ float4 sB[SGR_TILE_THREADS];  // {qa, qb, qc, opacity}
     __shared__ float4 sC[SGR_TILE_THREADS];  // {r, g, b, depth}
     __shared__ uint64_t sBits[4][4];         // [quadrant][chunk of 64 instances]
-    __shared__ float sSem[SMAX > 0 ? SGR_TILE_THREADS * SMAX : 1];
+    __shared__ __attribute__((aligned(16))) float sSem[SMAX > 0 ? SGR_TILE_THREADS * SMAX : 4];  // zero-padded to SMAX
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t tx, ty;
@@ -61,8 +61,9 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
             sA[tid] = a;
             sB[tid] = make_float4(-0.5f * SGR_LOG2E * b.x, -SGR_LOG2E * b.y, -0.5f * SGR_LOG2E * b.z, b.w);
             sC[tid] = r[2];
-            if (SMAX > 0) {
-                for (int ch = 0; ch < S; ch++) sSem[tid * SMAX + ch] = semantics[(size_t)g * S + ch];
+            if (SMAX > 0) {  // channels S..SMAX-1 are staged as zeros so the walk needs no per-channel test
+#pragma unroll
+                for (int ch = 0; ch < SMAX; ch++) sSem[tid * SMAX + ch] = ch < S ? semantics[(size_t)g * S + ch] : 0.0f;
             }
             mask4 = CULL ? sgr_quadrant_mask(a, b, tx0, ty0) : 0xFu;
         }
@@ -110,9 +111,15 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                             Dp = fmaf(c.w, w, Dp);
                             Wt += w;
                             if (SMAX > 0) {
+                                const float4* sj = reinterpret_cast<const float4*>(&sSem[j * SMAX]);
 #pragma unroll
-                                for (int ch = 0; ch < SMAX; ch++)
-                                    if (ch < S) sem[ch] = fmaf(sSem[j * SMAX + ch], w, sem[ch]);
+                                for (int c4 = 0; c4 < SMAX / 4; c4++) {
+                                    const float4 sv = sj[c4];
+                                    sem[4 * c4] = fmaf(sv.x, w, sem[4 * c4]);
+                                    sem[4 * c4 + 1] = fmaf(sv.y, w, sem[4 * c4 + 1]);
+                                    sem[4 * c4 + 2] = fmaf(sv.z, w, sem[4 * c4 + 2]);
+                                    sem[4 * c4 + 3] = fmaf(sv.w, w, sem[4 * c4 + 3]);
+                                }
                             }
                             T = blend ? test_T : T;
                             last = blend ? (pos0 + (uint32_t)j + 1u) : last;
@@ -170,7 +177,10 @@ void sgr_launch_blend_fwd(bool cull, int gx, int gy, const uint2* ranges, const 
     if (S == 0) SGR_FWD(0);
     else if (S <= 4) SGR_FWD(4);
     else if (S <= 8) SGR_FWD(8);
+    else if (S <= 12) SGR_FWD(12);
     else if (S <= 16) SGR_FWD(16);
+    else if (S <= 20) SGR_FWD(20);
+    else if (S <= 24) SGR_FWD(24);
     else SGR_FWD(32);
 #undef SGR_FWD
 }

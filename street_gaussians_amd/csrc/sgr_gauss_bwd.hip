@@ -187,7 +187,10 @@ void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, cons
     if (S == 0) SGR_GB(0);
     else if (S <= 4) SGR_GB(4);
     else if (S <= 8) SGR_GB(8);
+    else if (S <= 12) SGR_GB(12);
     else if (S <= 16) SGR_GB(16);
+    else if (S <= 20) SGR_GB(20);
+    else if (S <= 24) SGR_GB(24);
     else SGR_GB(32);
 #undef SGR_GB
 }
