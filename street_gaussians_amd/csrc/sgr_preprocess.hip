@@ -27,16 +27,14 @@ sgr_mark_visible_kernel(int P, const float* __restrict__ means3D, const SgrCam* 
 }
 
 // ---- K2 / K3 ----------------------------------------------------------------------------------
+// One Gaussian; returns its tiles_touched (0 when culled).
 template <bool FILTER>
-__global__ void __launch_bounds__(SGR_PRE_THREADS)
-sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
-                      const float* __restrict__ rotations, const float* __restrict__ opacities,
-                      const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
-                      const float* __restrict__ colors_precomp, const SgrCam* __restrict__ camp, SgrGeomView gv,
-                      int* __restrict__ radii, float* __restrict__ filter_means2D, int prefiltered) {
-    const SgrCam& cam = *camp;
-    const int idx = blockIdx.x * SGR_PRE_THREADS + threadIdx.x;
-    if (idx >= P) return;
+__device__ __forceinline__ uint32_t
+sgr_preprocess_one(const int idx, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
+                   const float* __restrict__ rotations, const float* __restrict__ opacities,
+                   const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
+                   const float* __restrict__ colors_precomp, const SgrCam& cam, const SgrGeomView& gv,
+                   int* __restrict__ radii, float* __restrict__ filter_means2D, int prefiltered) {
 
     const float p[3] = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
     float tz;
@@ -74,13 +72,13 @@ sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             gv.tiles_touched[idx] = 0;
             gv.dkeys[0][idx] = 0xffffffffu;  // sorts behind every real depth (> 0.2 => sign bit clear)
         }
-        return;
+        return 0;
     }
     if (FILTER) {
         radii[idx] = pr.radius;
         filter_means2D[2 * idx] = pr.px;
         filter_means2D[2 * idx + 1] = pr.py;
-        return;
+        return 0;
     }
 
     // colour: precomputed, or SH -> RGB (forward.cu:20-71)
@@ -144,6 +142,37 @@ sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     gv.tiles_touched[idx] = w * h;
     gv.dkeys[0][idx] = __float_as_uint(pr.depth);
     radii[idx] = pr.radius;
+    return w * h;
+}
+
+// num_rendered = sum of tiles_touched does not depend on the depth order, so it is accumulated here (one atomic per
+// workgroup into header[1]) and the host can read it back while the depth sort and the offset scan are still running.
+template <bool FILTER>
+__global__ void __launch_bounds__(SGR_PRE_THREADS)
+sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
+                      const float* __restrict__ rotations, const float* __restrict__ opacities,
+                      const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
+                      const float* __restrict__ colors_precomp, const SgrCam* __restrict__ camp, SgrGeomView gv,
+                      int* __restrict__ radii, float* __restrict__ filter_means2D, int prefiltered) {
+    const int idx = blockIdx.x * SGR_PRE_THREADS + threadIdx.x;
+    uint32_t n = 0;
+    if (idx < P)
+        n = sgr_preprocess_one<FILTER>(idx, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
+                                       *camp, gv, radii, filter_means2D, prefiltered);
+    if (FILTER) return;
+    // device-scope atomics on one address are resolved beyond the per-XCD L2s (~6 ns each, serialised): one per
+    // workgroup, not one per wave (16k of them cost 0.1 ms at P = 1M)
+    __shared__ uint32_t wave_sum[SGR_PRE_THREADS / 64];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) n += __shfl_xor(n, m, 64);
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int i = 0; i < SGR_PRE_THREADS / 64; i++) t += wave_sum[i];
+        if (t) atomicAdd(&gv.header[1], t);
+    }
 }
 
 // ---- tiles_touched gathered in (depth, id) order, ready for the scan that gives every Gaussian its slot ----
