@@ -235,6 +235,8 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
     __syncthreads();
     const int maxc = max(max(sMax[0], sMax[1]), max(sMax[2], sMax[3]));
     const float tx0 = (float)(tx * SGR_BLOCK_X), ty0 = (float)(ty * SGR_BLOCK_Y);
+    // LDS row of this lane's 16-lane group inside a slot (see the reduce-scatter layout below)
+    const int acc_lane_off = (DET ? (wave >> 1) : 0) * SGR_TILE_THREADS * ACCW + (lane >> 4);
 
     for (int hi = maxc - 1; hi >= 0; hi -= SGR_TILE_THREADS) {
         // slot t of this batch holds list position hi - t (descending: back to front)
@@ -277,30 +279,36 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                            const float alpha, const bool valid) __attribute__((always_inline)) {
                 const int posj = hi - j;  // 0-based list position == `contributor` after its decrement
                 // backward.cu:527-545
-                const bool hit = valid && inside && (posj < lastc) && !(power2 > 0.0f) && !(alpha < SGR_ALPHA_MIN);
-                if (!__any(hit)) return;
+                // (pixels outside the image have lastc = 0).  The wave-wide "any hit" is taken from the three compare
+                // masks with scalar ANDs: ballot(compound bool) costs hipcc a v_cndmask + v_cmp per survivor.
+                const bool k0 = posj < lastc, k1 = !(power2 > 0.0f), k2 = !(alpha < SGR_ALPHA_MIN);
+                const uint64_t hm = __builtin_amdgcn_ballot_w64(k0) & __builtin_amdgcn_ballot_w64(k1) &
+                                    __builtin_amdgcn_ballot_w64(k2);
+                if (!valid || hm == 0) return;
+                const bool hit = k0 && k1 && k2;
 
                 const float4 c = sC[j];
-                const float oma = 1.0f - alpha;
-                float inv1ma = __builtin_amdgcn_rcpf(oma);
-                inv1ma = fmaf(fmaf(-oma, inv1ma, 1.0f), inv1ma, inv1ma);  // Newton step: T recovery compounds per layer
-                const float Tn = T * inv1ma;  // T = T / (1 - alpha)
-                const float w = alpha * Tn;
-                float dopa;
                 float v[NVAL];
 #pragma unroll
                 for (int k = 0; k < NVAL; k++) v[k] = 0.0f;
-                const float wm = hit ? w : 0.0f;  // every output below is a product with wm or dopa: mask those two
-                {
+                // Everything per-pixel runs under the hit mask and updates the recurrences in place; the other lanes
+                // keep dopa = wm = 0, and every output below is a product with one of those two.
+                float dopa = 0.0f, wm = 0.0f;
+                if (hit) {
+                    const float oma = 1.0f - alpha;
+                    float inv1ma = __builtin_amdgcn_rcpf(oma);
+                    inv1ma = fmaf(fmaf(-oma, inv1ma, 1.0f), inv1ma, inv1ma);  // Newton step: T recovery compounds per layer
+                    T = T * inv1ma;  // T = T / (1 - alpha)
+                    wm = alpha * T;
                     const float one_m_la = 1.0f - last_alpha;
-                    const float a0 = fmaf(last_alpha, lastC0, one_m_la * accC0);
-                    const float a1 = fmaf(last_alpha, lastC1, one_m_la * accC1);
-                    const float a2 = fmaf(last_alpha, lastC2, one_m_la * accC2);
-                    dopa = (c.x - a0) * dLdC0 + (c.y - a1) * dLdC1 + (c.z - a2) * dLdC2;
-                    const float ad = fmaf(last_alpha, lastD, one_m_la * accD);
-                    dopa = fmaf(c.w - ad, dLdD, dopa);
-                    const float aa = fmaf(one_m_la, accA, last_alpha);
-                    dopa = fmaf(1.0f - aa, dLdA, dopa);
+                    accC0 = fmaf(last_alpha, lastC0, one_m_la * accC0);
+                    accC1 = fmaf(last_alpha, lastC1, one_m_la * accC1);
+                    accC2 = fmaf(last_alpha, lastC2, one_m_la * accC2);
+                    float d = (c.x - accC0) * dLdC0 + (c.y - accC1) * dLdC1 + (c.z - accC2) * dLdC2;
+                    accD = fmaf(last_alpha, lastD, one_m_la * accD);
+                    d = fmaf(c.w - accD, dLdD, d);
+                    accA = fmaf(one_m_la, accA, last_alpha);
+                    d = fmaf(1.0f - accA, dLdA, d);
                     if (SMAX > 0) {  // padded channels carry zeros end to end (sSem, dLdS), so no per-channel test
                         const float4* sj = reinterpret_cast<const float4*>(&sSem[j * SMAX]);
 #pragma unroll
@@ -310,26 +318,22 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
 #pragma unroll
                             for (int e = 0; e < 4; e++) {
                                 const int ch = 4 * c4 + e;
-                                const float as = fmaf(last_alpha, lastS[ch], one_m_la * accS[ch]);
-                                dopa = fmaf(svv[e] - as, dLdS[ch], dopa);
-                                v[SGR_ROW_BASE + ch] = wm * dLdS[ch];
-                                accS[ch] = hit ? as : accS[ch];
-                                lastS[ch] = hit ? svv[e] : lastS[ch];
+                                accS[ch] = fmaf(last_alpha, lastS[ch], one_m_la * accS[ch]);
+                                d = fmaf(svv[e] - accS[ch], dLdS[ch], d);
+                                lastS[ch] = svv[e];
                             }
                         }
                     }
-                    if (hit) {
-                        accC0 = a0; accC1 = a1; accC2 = a2;
-                        lastC0 = c.x; lastC1 = c.y; lastC2 = c.z;
-                        accD = ad; lastD = c.w;
-                        accA = aa;
-                        last_alpha = alpha;
-                        T = Tn;
-                    }
+                    lastC0 = c.x; lastC1 = c.y; lastC2 = c.z;
+                    lastD = c.w;
+                    last_alpha = alpha;
+                    d *= T;
+                    dopa = fmaf(-T_final * inv1ma, bgdot, d);  // backward.cu:611-614
                 }
-                dopa *= Tn;
-                dopa = fmaf(-T_final * inv1ma, bgdot, dopa);  // backward.cu:611-614
-                dopa = hit ? dopa : 0.0f;
+                if (SMAX > 0) {
+#pragma unroll
+                    for (int ch = 0; ch < SMAX; ch++) v[SGR_ROW_BASE + ch] = wm * dLdS[ch];
+                }
                 const float dL_dG = q.w * dopa;
                 const float gdx = G * dx, gdy = G * dy;
                 // dG/ddelx = -gdx*A - gdy*B = (2*qa*gdx + qb*gdy)/log2e  (qa = -0.5*log2e*A, qb = -log2e*B)
@@ -363,7 +367,8 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                 }
                 if ((lane & 15) == 0) {  // one lane per 16-lane row stores that row's values
                     const int k = lane >> 4;
-                    float* dst = &sAcc[((DET ? (wave >> 1) : 0) * SGR_TILE_THREADS + j) * ACCW + k];
+                    float* dst = sAcc + (acc_lane_off + j * ACCW);  // j is wave-uniform: scalar multiply
+                    (void)k;
 #pragma unroll
                     for (int t = 0; t < NVAL / 4; t++) atomicAdd(&dst[4 * t], r[t]);
                     if (k == 0) sFlag[j] = 1u;
