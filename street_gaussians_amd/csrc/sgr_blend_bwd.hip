@@ -17,6 +17,11 @@
 #include "sgr_math.h"
 
 #define SGR_TILE_THREADS 256
+// list entries staged in LDS per round.  128 (not 256) keeps the workgroup at 20 KB of LDS so that occupancy is set by
+// registers (5 waves / SIMD) instead of LDS (4): measured +11 % time at 3 workgroups / CU vs 4.
+#ifndef SGR_BWD_BATCH
+#define SGR_BWD_BATCH 128
+#endif
 #define SGR_ROW_BASE 11
 
 // Sum over the 64 lanes of a wave; the result is valid in lanes 48..63 (read it from lane 63).
@@ -168,11 +173,11 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
     constexpr int NS = SMAX > 0 ? SMAX : 1;
     constexpr int NVAL = (SGR_ROW_BASE + SMAX + 3) / 4 * 4;  // values per row, padded to float4s
     constexpr int ACCW = NVAL;                                 // LDS row stride (16-B aligned rows)
-    __shared__ float4 sA[SGR_TILE_THREADS];  // {x, y, -, -}
-    __shared__ float4 sB[SGR_TILE_THREADS];  // {qa, qb, qc, opacity}
-    __shared__ float4 sC[SGR_TILE_THREADS];  // {r, g, b, depth}
-    __shared__ uint32_t sU[SGR_TILE_THREADS];
-    __shared__ uint32_t sFlag[SGR_TILE_THREADS];
+    __shared__ float4 sA[SGR_BWD_BATCH];  // {x, y, -, -}
+    __shared__ float4 sB[SGR_BWD_BATCH];  // {qa, qb, qc, opacity}
+    __shared__ float4 sC[SGR_BWD_BATCH];  // {r, g, b, depth}
+    __shared__ uint32_t sU[SGR_BWD_BATCH];
+    __shared__ uint32_t sFlag[SGR_BWD_BATCH];
     __shared__ uint64_t sBits[4][4];
     __shared__ int sMax[4];
     // The (up to four) wave partials of an instance meet in LDS with ds_add_f32.  DET: two zero-initialised
@@ -182,8 +187,8 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
     // !DET: a single row shared by all four waves (arrival order can change the last bit, like the reference's
     // atomicAdd).
     constexpr int NROW = DET ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) float sAcc[NROW * SGR_TILE_THREADS * ACCW];
-    __shared__ __attribute__((aligned(16))) float sSem[SMAX > 0 ? SGR_TILE_THREADS * SMAX : 4];  // zero-padded to SMAX
+    __shared__ __attribute__((aligned(16))) float sAcc[NROW * SGR_BWD_BATCH * ACCW];
+    __shared__ __attribute__((aligned(16))) float sSem[SMAX > 0 ? SGR_BWD_BATCH * SMAX : 4];  // zero-padded to SMAX
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t tx, ty;
@@ -236,17 +241,18 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
     const int maxc = max(max(sMax[0], sMax[1]), max(sMax[2], sMax[3]));
     const float tx0 = (float)(tx * SGR_BLOCK_X), ty0 = (float)(ty * SGR_BLOCK_Y);
     // LDS row of this lane's 16-lane group inside a slot (see the reduce-scatter layout below)
-    const int acc_lane_off = (DET ? (wave >> 1) : 0) * SGR_TILE_THREADS * ACCW + (lane >> 4);
+    const int acc_lane_off = (DET ? (wave >> 1) : 0) * SGR_BWD_BATCH * ACCW + (lane >> 4);
 
-    for (int hi = maxc - 1; hi >= 0; hi -= SGR_TILE_THREADS) {
+    for (int hi = maxc - 1; hi >= 0; hi -= SGR_BWD_BATCH) {
         // slot t of this batch holds list position hi - t (descending: back to front)
         __syncthreads();  // previous batch fully consumed (rows written) before LDS is overwritten
-        const int pos = hi - tid;
+        const bool stager = tid < SGR_BWD_BATCH;  // whole waves: the batch is a multiple of 64
+        const int pos = stager ? hi - tid : -1;
         uint32_t mask4 = 0;
-        sFlag[tid] = 0;
+        if (stager) sFlag[tid] = 0;
 #pragma unroll
-        for (int rr = 0; rr < NROW; rr++) {
-            float4* z = reinterpret_cast<float4*>(&sAcc[(rr * SGR_TILE_THREADS + tid) * ACCW]);
+        for (int row = tid; row < NROW * SGR_BWD_BATCH; row += SGR_TILE_THREADS) {
+            float4* z = reinterpret_cast<float4*>(&sAcc[row * ACCW]);
 #pragma unroll
             for (int k4 = 0; k4 < ACCW / 4; k4++) z[k4] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -268,10 +274,12 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
             }
             mask4 = CULL ? sgr_quadrant_mask(a, b, tx0, ty0) : 0xFu;
         }
+        if (stager) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint64_t m = __ballot((mask4 >> q) & 1u);
-            if (lane == 0) sBits[q][wave] = m;
+            for (int q = 0; q < 4; q++) {
+                const uint64_t m = __ballot((mask4 >> q) & 1u);
+                if (lane == 0) sBits[q][wave] = m;
+            }
         }
         __syncthreads();
 
@@ -374,7 +382,7 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                     if (k == 0) sFlag[j] = 1u;
                 }
         };
-        for (int chunk = 0; chunk < 4; chunk++) {
+        for (int chunk = 0; chunk < SGR_BWD_BATCH / 64; chunk++) {
             uint64_t m = sBits[wave][chunk];
             m = sgr_uniform_u64(m);
             while (m) {
@@ -398,7 +406,7 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
         }
         __syncthreads();
         // one row per touched (tile, instance): plain stores, written exactly once
-        const uint32_t flags = sFlag[tid];
+        const uint32_t flags = stager ? sFlag[tid] : 0u;
         if (flags) {
             const uint32_t u = sU[tid];
             touched[u] = 1;  // the per-Gaussian reduction only reads rows that were written (no 64 B/instance memset)
@@ -411,7 +419,7 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
 #pragma unroll
                 for (int k4 = 0; k4 < NVAL / 4; k4++) r[k4] = src[k4];
                 if (DET) {
-                    const float4* src1 = reinterpret_cast<const float4*>(&sAcc[(SGR_TILE_THREADS + tid) * ACCW]);
+                    const float4* src1 = reinterpret_cast<const float4*>(&sAcc[(SGR_BWD_BATCH + tid) * ACCW]);
 #pragma unroll
                     for (int k4 = 0; k4 < NVAL / 4; k4++) {
                         const float4 t = src1[k4];
