@@ -25,6 +25,7 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
     __shared__ float4 sB[SGR_TILE_THREADS];  // {qa, qb, qc, opacity}
     __shared__ float4 sC[SGR_TILE_THREADS];  // {r, g, b, depth}
     __shared__ uint64_t sBits[4][4];         // [quadrant][chunk of 64 instances]
+    __shared__ uint32_t sDone[4];
     __shared__ __attribute__((aligned(16))) float sSem[SMAX > 0 ? SGR_TILE_THREADS * SMAX : 4];  // zero-padded to SMAX
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -42,14 +43,22 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
 #pragma unroll
     for (int i = 0; i < (SMAX > 0 ? SMAX : 1); i++) sem[i] = 0.f;
     uint32_t last = 0;
-    bool done = !inside;
+    // Finished pixels (outside the image, or T exhausted) are tracked twice: `done_mask` is the wave's scalar lane mask
+    // (tile-/wave-wide exits are scalar compares), and `thr`, the per-lane alpha threshold, becomes +inf so that a
+    // finished lane fails the alpha test without a separate predicate (hipcc turns ballot(compound bool) and
+    // __any/__all into v_cndmask + v_cmp pairs; direct compares combined with scalar ANDs cost no VALU).
+    uint64_t done_mask = sgr_uniform_u64(__builtin_amdgcn_ballot_w64(!inside));
+    float thr = inside ? SGR_ALPHA_MIN : __builtin_inff();
 
     // quadrant bounds (pixel centres) used by the staging lanes for the cull test
     const float tx0 = (float)(tx * SGR_BLOCK_X), ty0 = (float)(ty * SGR_BLOCK_Y);
 
     for (uint32_t base = range.x; base < range.y; base += SGR_TILE_THREADS) {
         // tile-wide early exit (forward.cu:394-396); also the barrier that protects LDS reuse
-        if (__syncthreads_and(done)) break;
+        // (each wave posts "all my pixels are finished"; hipcc's __syncthreads_and is a 20-instruction DPP reduction)
+        if (lane == 0) sDone[wave] = (done_mask == ~0ull) ? 1u : 0u;
+        __syncthreads();
+        if (sDone[0] & sDone[1] & sDone[2] & sDone[3]) break;
 
         const uint32_t idx = base + tid;
         uint32_t mask4 = 0;
@@ -74,7 +83,7 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
         }
         __syncthreads();
 
-        if (!__all(done)) {
+        if (done_mask != ~0ull) {
             const uint32_t pos0 = base - range.x;  // list position of slot 0 of this batch
             for (int chunk = 0; chunk < 4; chunk++) {
                 uint64_t m = sBits[wave][chunk];
@@ -97,12 +106,13 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                         const int j = u ? j1 : j0;
                         const float power2 = u ? pw1 : pw0;
                         const float alpha = u ? al1 : al0;
-                        // forward.cu:425-430: skip if power > 0 or alpha < 1/255
-                        const bool hit = (u == 0 || two) && !done && !(power2 > 0.0f) && !(alpha < SGR_ALPHA_MIN);
-                        if (__any(hit)) {
+                        // forward.cu:425-430: skip if power > 0 or alpha < 1/255 (or the pixel is finished: thr = inf)
+                        const bool k1 = !(power2 > 0.0f), k2 = !(alpha < thr);
+                        const uint64_t hm = __builtin_amdgcn_ballot_w64(k1) & __builtin_amdgcn_ballot_w64(k2);
+                        if ((u == 0 || two) && hm != 0) {
                             const float test_T = T * (1.0f - alpha);
-                            const bool stop = hit && (test_T < 0.0001f);  // forward.cu:431-436
-                            const bool blend = hit && !stop;
+                            const bool k3 = test_T < 0.0001f;  // forward.cu:431-436
+                            const bool blend = k1 && k2 && !k3;
                             const float4 c = sC[j];
                             const float w = blend ? alpha * T : 0.0f;
                             C0 = fmaf(c.x, w, C0);
@@ -123,9 +133,11 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                             }
                             T = blend ? test_T : T;
                             last = blend ? (pos0 + (uint32_t)j + 1u) : last;
-                            if (__any(stop)) {
-                                done = done || stop;
-                                if (__all(done)) { m = 0; chunk = 4; }
+                            const uint64_t sm = hm & __builtin_amdgcn_ballot_w64(k3);
+                            if (sm != 0) {
+                                thr = (k1 && k2 && k3) ? __builtin_inff() : thr;
+                                done_mask |= sm;
+                                if (done_mask == ~0ull) { m = 0; chunk = 4; }
                             }
                         }
                     }
