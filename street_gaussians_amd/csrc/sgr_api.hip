@@ -42,9 +42,9 @@ void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, int gx, int gy, const u
 void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const int* radii, const float* shs,
                           const float* scales, const float* rotations, const float* cov3D_precomp, const SgrCam* cam,
                           const SgrGeomView& gv, const float* partials, int row_stride, const uint8_t* touched,
-                          float* dL_dmean2D,
-                          float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
-                          float* dL_dscale, float* dL_drot, float* dL_dsemantic, hipStream_t s);
+                          float4* cd, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+                          float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dsemantic,
+                          hipStream_t s);
 void sgr_launch_wave_sum_test(const float* in, float* out_dpp, float* out_shfl, int nwaves, hipStream_t s);
 int sgr_knn_impl(int P, const float* points, float* meanDists, sgr_alloc_fn scratch, void* scratch_user, hipStream_t s,
                  std::string& err);
@@ -313,15 +313,17 @@ int sgr_backward(int P, int D, int M, int R, int S, const float* background, int
     const SgrImgView iv = sgr_img_carve(image_buffer, N, T);
     const int* radii_ptr = radii ? radii : gv.internal_radii;
     const int stride = sgr_partial_row_stride(S);
-    float* partials = nullptr;
-    uint8_t* touched = nullptr;
+    // scratch = [P float4: conic + depth terms between the two per-Gaussian stages][R partial rows][R flag bytes]
+    const size_t cd_bytes = sgr_align_up((size_t)P * sizeof(float4), 256);
+    const size_t bytes = sgr_align_up((size_t)R * stride * sizeof(float), 256);
+    char* sbase = scratch(cd_bytes + bytes + (size_t)R, scratch_user);
+    if (!sbase) return fail(SGR_E_ALLOC, "backward scratch allocation failed");
+    float4* cd = reinterpret_cast<float4*>(sbase);
+    float* partials = reinterpret_cast<float*>(sbase + cd_bytes);
+    uint8_t* touched = reinterpret_cast<uint8_t*>(sbase + cd_bytes + bytes);  // one byte per (tile, instance) row
     if (R > 0) {
         const SgrBinView bv = sgr_bin_carve(binning_buffer, (size_t)R);
         const int cur = sorted_index(W, H);
-        const size_t bytes = sgr_align_up((size_t)R * stride * sizeof(float), 256);
-        partials = (float*)scratch(bytes + (size_t)R, scratch_user);
-        if (!partials) return fail(SGR_E_ALLOC, "backward scratch allocation failed");
-        touched = reinterpret_cast<uint8_t*>(partials) + bytes;  // one byte per (tile, instance) row
         prof_begin(6, stream);
         SGR_HIP(hipMemsetAsync(touched, 0, (size_t)R, stream));  // rows themselves are never cleared
         prof_end(stream);
@@ -335,8 +337,8 @@ int sgr_backward(int P, int D, int M, int R, int S, const float* background, int
     }
     prof_begin(8, stream);
     sgr_launch_gauss_bwd(P, D, M, S, means3D, radii_ptr, shs, scales, rotations, cov3D_precomp, cam_slot(gv), gv, partials,
-                         stride, touched, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
-                         dL_dsemantic, stream);
+                         stride, touched, cd, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
+                         dL_drot, dL_dsemantic, stream);
     SGR_STAGE("gauss_bwd");
     prof_end(stream);
     return 0;

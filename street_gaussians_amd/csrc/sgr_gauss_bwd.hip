@@ -11,43 +11,73 @@
 
 #define SGR_GB_THREADS 256
 
+// ---- stage 1: sum the partial rows ---------------------------------------------------------------------------
+// A latency-bound gather (flag byte -> 48..176-byte row, n rows per Gaussian, n differs per lane), so it lives in its
+// own kernel: ~24 VGPRs -> 8 waves / SIMD in flight, where the fused kernel (114 VGPRs for the SH arrays) had 4.
+// Four rows are in flight per lane; they are ADDED in ascending row order, so the result does not depend on it.
+// Writes the outputs that come straight from the blend backward (backward.cu:568-638) and hands the conic / depth
+// terms to stage 2 through `cd`.
 template <int SMAX>
 __global__ void __launch_bounds__(SGR_GB_THREADS)
-sgr_gauss_bwd_kernel(int P, int D, int M, int S, const float* __restrict__ means3D, const int* __restrict__ radii,
-                     const float* __restrict__ shs, const float* __restrict__ scales,
-                     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
-                     const SgrCam* __restrict__ camp, SgrGeomView gv, const float* __restrict__ partials, int row_stride,
-                     const uint8_t* __restrict__ touched, float* __restrict__ dL_dmean2D,
-                     float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
-                     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
-                     float* __restrict__ dL_drot, float* __restrict__ dL_dsemantic) {
+sgr_row_sum_kernel(int P, int S, const int* __restrict__ radii, SgrGeomView gv, const float* __restrict__ partials,
+                   int row_stride, const uint8_t* __restrict__ touched, float* __restrict__ dL_dmean2D,
+                   float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dsemantic,
+                   float4* __restrict__ cd) {
     constexpr int NS = SMAX > 0 ? SMAX : 1;
-    const SgrCam& cam = *camp;
+    constexpr int NV = (SGR_ROW_BASE_N + SMAX + 3) / 4;
     const int idx = blockIdx.x * SGR_GB_THREADS + threadIdx.x;
     if (idx >= P) return;
-    const bool visible = radii[idx] > 0;
-
-    float acc[SGR_ROW_BASE_N + NS];
+    float acc[4 * NV];
 #pragma unroll
-    for (int k = 0; k < SGR_ROW_BASE_N + NS; k++) acc[k] = 0.f;
-    if (visible) {
+    for (int k = 0; k < 4 * NV; k++) acc[k] = 0.f;
+    (void)NS;
+    if (radii[idx] > 0) {
         const uint32_t u0 = __float_as_uint(gv.rec[4 * (size_t)idx + 3].x);
         const uint32_t n = gv.tiles_touched[idx];
-        constexpr int NV = (SGR_ROW_BASE_N + SMAX + 3) / 4;
-        for (uint32_t i = 0; i < n; i++) {
-            if (!touched[u0 + i]) continue;  // row never written by the blend backward
-            const float4* row = reinterpret_cast<const float4*>(partials + (size_t)(u0 + i) * row_stride);
+        const uint8_t* flag = touched + u0;
+        const float* rows = partials + (size_t)u0 * row_stride;
+        auto add_row = [&](const float4 (&t)[NV]) __attribute__((always_inline)) {
 #pragma unroll
             for (int k4 = 0; k4 < NV; k4++) {
-                const float4 t = row[k4];
-                acc[4 * k4] += t.x;
-                if (4 * k4 + 1 < SGR_ROW_BASE_N + SMAX) acc[4 * k4 + 1] += t.y;
-                if (4 * k4 + 2 < SGR_ROW_BASE_N + SMAX) acc[4 * k4 + 2] += t.z;
-                if (4 * k4 + 3 < SGR_ROW_BASE_N + SMAX) acc[4 * k4 + 3] += t.w;
+                acc[4 * k4] += t[k4].x; acc[4 * k4 + 1] += t[k4].y; acc[4 * k4 + 2] += t[k4].z; acc[4 * k4 + 3] += t[k4].w;
             }
+        };
+        uint32_t i = 0;
+        for (; i + 4 <= n; i += 4) {
+            const uint8_t f0 = flag[i], f1 = flag[i + 1], f2 = flag[i + 2], f3 = flag[i + 3];
+            float4 t0[NV], t1[NV], t2[NV], t3[NV];
+#pragma unroll
+            for (int k4 = 0; k4 < NV; k4++) {
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                t0[k4] = z; t1[k4] = z; t2[k4] = z; t3[k4] = z;
+            }
+            // rows never written by the blend backward hold garbage: load under the flag (x + 0 is exact)
+            if (f0) { const float4* r = reinterpret_cast<const float4*>(rows + (size_t)i * row_stride);
+#pragma unroll
+                for (int k4 = 0; k4 < NV; k4++) t0[k4] = r[k4]; }
+            if (f1) { const float4* r = reinterpret_cast<const float4*>(rows + (size_t)(i + 1) * row_stride);
+#pragma unroll
+                for (int k4 = 0; k4 < NV; k4++) t1[k4] = r[k4]; }
+            if (f2) { const float4* r = reinterpret_cast<const float4*>(rows + (size_t)(i + 2) * row_stride);
+#pragma unroll
+                for (int k4 = 0; k4 < NV; k4++) t2[k4] = r[k4]; }
+            if (f3) { const float4* r = reinterpret_cast<const float4*>(rows + (size_t)(i + 3) * row_stride);
+#pragma unroll
+                for (int k4 = 0; k4 < NV; k4++) t3[k4] = r[k4]; }
+            if (f0) add_row(t0);
+            if (f1) add_row(t1);
+            if (f2) add_row(t2);
+            if (f3) add_row(t3);
+        }
+        for (; i < n; i++) {
+            if (!flag[i]) continue;
+            const float4* r = reinterpret_cast<const float4*>(rows + (size_t)i * row_stride);
+            float4 t[NV];
+#pragma unroll
+            for (int k4 = 0; k4 < NV; k4++) t[k4] = r[k4];
+            add_row(t);
         }
     }
-    // outputs that come straight from the blend backward (backward.cu:568-638)
     dL_dmean2D[3 * idx + 0] = acc[0];
     dL_dmean2D[3 * idx + 1] = acc[1];
     dL_dmean2D[3 * idx + 2] = acc[2];
@@ -55,10 +85,38 @@ sgr_gauss_bwd_kernel(int P, int D, int M, int S, const float* __restrict__ means
     dL_dcolor[3 * idx + 0] = acc[7];
     dL_dcolor[3 * idx + 1] = acc[8];
     dL_dcolor[3 * idx + 2] = acc[9];
+    cd[idx] = make_float4(acc[3], acc[4], acc[5], acc[10]);
     if (SMAX > 0) {
 #pragma unroll
         for (int ch = 0; ch < SMAX; ch++)
             if (ch < S) dL_dsemantic[(size_t)idx * S + ch] = acc[SGR_ROW_BASE_N + ch];
+    }
+}
+
+// ---- stage 2: K12 + K13 ----------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(SGR_GB_THREADS)
+sgr_gauss_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const int* __restrict__ radii,
+                     const float* __restrict__ shs, const float* __restrict__ scales,
+                     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
+                     const SgrCam* __restrict__ camp, SgrGeomView gv, const float4* __restrict__ cd,
+                     const float* __restrict__ dL_dmean2D, const float* __restrict__ dL_dcolor,
+                     float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
+                     float* __restrict__ dL_dscale, float* __restrict__ dL_drot) {
+    const SgrCam& cam = *camp;
+    const int idx = blockIdx.x * SGR_GB_THREADS + threadIdx.x;
+    if (idx >= P) return;
+    const bool visible = radii[idx] > 0;
+    float acc[SGR_ROW_BASE_N];
+#pragma unroll
+    for (int k = 0; k < SGR_ROW_BASE_N; k++) acc[k] = 0.f;
+    if (visible) {
+        const float4 c = cd[idx];
+        acc[0] = dL_dmean2D[3 * idx];
+        acc[1] = dL_dmean2D[3 * idx + 1];
+        acc[3] = c.x; acc[4] = c.y; acc[5] = c.z; acc[10] = c.w;
+        acc[7] = dL_dcolor[3 * idx];
+        acc[8] = dL_dcolor[3 * idx + 1];
+        acc[9] = dL_dcolor[3 * idx + 2];
     }
 
     float dmean[3] = {0.f, 0.f, 0.f};
@@ -173,24 +231,24 @@ sgr_gauss_bwd_kernel(int P, int D, int M, int S, const float* __restrict__ means
 void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const int* radii, const float* shs,
                           const float* scales, const float* rotations, const float* cov3D_precomp, const SgrCam* cam,
                           const SgrGeomView& gv, const float* partials, int row_stride, const uint8_t* touched,
-                          float* dL_dmean2D,
-                          float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
-                          float* dL_dscale, float* dL_drot, float* dL_dsemantic, hipStream_t s) {
+                          float4* cd, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+                          float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dsemantic,
+                          hipStream_t s) {
     if (P <= 0) return;
     const unsigned nb = (P + SGR_GB_THREADS - 1) / SGR_GB_THREADS;
-#define SGR_GB(N)                                                                                                     \
-    sgr_gauss_bwd_kernel<N><<<nb, SGR_GB_THREADS, 0, s>>>(P, D, M, S, means3D, radii, shs, scales, rotations,           \
-                                                          cov3D_precomp, cam, gv, partials, row_stride, touched,      \
-                                                          dL_dmean2D,                                              \
-                                                          dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,       \
-                                                          dL_dscale, dL_drot, dL_dsemantic)
-    if (S == 0) SGR_GB(0);
-    else if (S <= 4) SGR_GB(4);
-    else if (S <= 8) SGR_GB(8);
-    else if (S <= 12) SGR_GB(12);
-    else if (S <= 16) SGR_GB(16);
-    else if (S <= 20) SGR_GB(20);
-    else if (S <= 24) SGR_GB(24);
-    else SGR_GB(32);
-#undef SGR_GB
+#define SGR_RS(N)                                                                                                    \
+    sgr_row_sum_kernel<N><<<nb, SGR_GB_THREADS, 0, s>>>(P, S, radii, gv, partials, row_stride, touched, dL_dmean2D,   \
+                                                        dL_dopacity, dL_dcolor, dL_dsemantic, cd)
+    if (S == 0) SGR_RS(0);
+    else if (S <= 4) SGR_RS(4);
+    else if (S <= 8) SGR_RS(8);
+    else if (S <= 12) SGR_RS(12);
+    else if (S <= 16) SGR_RS(16);
+    else if (S <= 20) SGR_RS(20);
+    else if (S <= 24) SGR_RS(24);
+    else SGR_RS(32);
+#undef SGR_RS
+    sgr_gauss_bwd_kernel<<<nb, SGR_GB_THREADS, 0, s>>>(P, D, M, means3D, radii, shs, scales, rotations, cov3D_precomp, cam,
+                                                       gv, cd, dL_dmean2D, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
+                                                       dL_dscale, dL_drot);
 }
