@@ -12,9 +12,10 @@
 #define SGR_GB_THREADS 256
 
 // ---- stage 1: sum the partial rows ---------------------------------------------------------------------------
-// A latency-bound gather (flag byte -> 48..176-byte row, n rows per Gaussian, n differs per lane), so it lives in its
-// own kernel: ~24 VGPRs -> 8 waves / SIMD in flight, where the fused kernel (114 VGPRs for the SH arrays) had 4.
-// Four rows are in flight per lane; they are ADDED in ascending row order, so the result does not depend on it.
+// A latency-bound gather (flag byte -> 48..176-byte row; n rows per Gaussian, n between 1 and hundreds), so it lives
+// in its own kernel with few registers (8 waves / SIMD; the fused kernel had 4 because of the SH arrays) and FOUR
+// LANES PER GAUSSIAN: lane q of a quad sums rows q, q+4, q+8, ... (two in flight), then the quad's four partial sums
+// are combined with two quad_perm DPP steps.  The order of the additions is fixed -> deterministic.
 // Writes the outputs that come straight from the blend backward (backward.cu:568-638) and hands the conic / depth
 // terms to stage 2 through `cd`.
 template <int SMAX>
@@ -23,15 +24,14 @@ sgr_row_sum_kernel(int P, int S, const int* __restrict__ radii, SgrGeomView gv, 
                    int row_stride, const uint8_t* __restrict__ touched, float* __restrict__ dL_dmean2D,
                    float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dsemantic,
                    float4* __restrict__ cd) {
-    constexpr int NS = SMAX > 0 ? SMAX : 1;
     constexpr int NV = (SGR_ROW_BASE_N + SMAX + 3) / 4;
-    const int idx = blockIdx.x * SGR_GB_THREADS + threadIdx.x;
-    if (idx >= P) return;
+    const int gtid = blockIdx.x * SGR_GB_THREADS + threadIdx.x;
+    const int idx = gtid >> 2, q = gtid & 3;
     float acc[4 * NV];
 #pragma unroll
     for (int k = 0; k < 4 * NV; k++) acc[k] = 0.f;
-    (void)NS;
-    if (radii[idx] > 0) {
+    const bool live = idx < P;  // P need not be a multiple of 16: keep whole quads alive for the DPP steps
+    if (live && radii[idx] > 0) {
         const uint32_t u0 = __float_as_uint(gv.rec[4 * (size_t)idx + 3].x);
         const uint32_t n = gv.tiles_touched[idx];
         const uint8_t* flag = touched + u0;
@@ -42,35 +42,21 @@ sgr_row_sum_kernel(int P, int S, const int* __restrict__ radii, SgrGeomView gv, 
                 acc[4 * k4] += t[k4].x; acc[4 * k4 + 1] += t[k4].y; acc[4 * k4 + 2] += t[k4].z; acc[4 * k4 + 3] += t[k4].w;
             }
         };
-        uint32_t i = 0;
-        for (; i + 4 <= n; i += 4) {
-            const uint8_t f0 = flag[i], f1 = flag[i + 1], f2 = flag[i + 2], f3 = flag[i + 3];
-            float4 t0[NV], t1[NV], t2[NV], t3[NV];
-#pragma unroll
-            for (int k4 = 0; k4 < NV; k4++) {
-                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                t0[k4] = z; t1[k4] = z; t2[k4] = z; t3[k4] = z;
-            }
-            // rows never written by the blend backward hold garbage: load under the flag (x + 0 is exact)
+        uint32_t i = (uint32_t)q;
+        for (; i + 4 < n; i += 8) {
+            const uint8_t f0 = flag[i], f1 = flag[i + 4];
+            float4 t0[NV], t1[NV];
+            // rows never written by the blend backward hold garbage: load under the flag
             if (f0) { const float4* r = reinterpret_cast<const float4*>(rows + (size_t)i * row_stride);
 #pragma unroll
                 for (int k4 = 0; k4 < NV; k4++) t0[k4] = r[k4]; }
-            if (f1) { const float4* r = reinterpret_cast<const float4*>(rows + (size_t)(i + 1) * row_stride);
+            if (f1) { const float4* r = reinterpret_cast<const float4*>(rows + (size_t)(i + 4) * row_stride);
 #pragma unroll
                 for (int k4 = 0; k4 < NV; k4++) t1[k4] = r[k4]; }
-            if (f2) { const float4* r = reinterpret_cast<const float4*>(rows + (size_t)(i + 2) * row_stride);
-#pragma unroll
-                for (int k4 = 0; k4 < NV; k4++) t2[k4] = r[k4]; }
-            if (f3) { const float4* r = reinterpret_cast<const float4*>(rows + (size_t)(i + 3) * row_stride);
-#pragma unroll
-                for (int k4 = 0; k4 < NV; k4++) t3[k4] = r[k4]; }
             if (f0) add_row(t0);
             if (f1) add_row(t1);
-            if (f2) add_row(t2);
-            if (f3) add_row(t3);
         }
-        for (; i < n; i++) {
-            if (!flag[i]) continue;
+        if (i < n && flag[i]) {
             const float4* r = reinterpret_cast<const float4*>(rows + (size_t)i * row_stride);
             float4 t[NV];
 #pragma unroll
@@ -78,18 +64,30 @@ sgr_row_sum_kernel(int P, int S, const int* __restrict__ radii, SgrGeomView gv, 
             add_row(t);
         }
     }
-    dL_dmean2D[3 * idx + 0] = acc[0];
-    dL_dmean2D[3 * idx + 1] = acc[1];
-    dL_dmean2D[3 * idx + 2] = acc[2];
-    dL_dopacity[idx] = acc[6];
-    dL_dcolor[3 * idx + 0] = acc[7];
-    dL_dcolor[3 * idx + 1] = acc[8];
-    dL_dcolor[3 * idx + 2] = acc[9];
-    cd[idx] = make_float4(acc[3], acc[4], acc[5], acc[10]);
+    // (q0 + q1) + (q2 + q3) in every lane of the quad
+#pragma unroll
+    for (int k = 0; k < 4 * NV; k++) {
+        acc[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc[k]), 0xB1, 0xF, 0xF, false));
+        acc[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc[k]), 0x4E, 0xF, 0xF, false));
+    }
+    if (!live) return;
+    // the quad shares the stores
+    if (q == 0) {
+        dL_dmean2D[3 * idx + 0] = acc[0];
+        dL_dmean2D[3 * idx + 1] = acc[1];
+        dL_dmean2D[3 * idx + 2] = acc[2];
+    } else if (q == 1) {
+        dL_dopacity[idx] = acc[6];
+        dL_dcolor[3 * idx + 0] = acc[7];
+        dL_dcolor[3 * idx + 1] = acc[8];
+        dL_dcolor[3 * idx + 2] = acc[9];
+    } else if (q == 2) {
+        cd[idx] = make_float4(acc[3], acc[4], acc[5], acc[10]);
+    }
     if (SMAX > 0) {
 #pragma unroll
         for (int ch = 0; ch < SMAX; ch++)
-            if (ch < S) dL_dsemantic[(size_t)idx * S + ch] = acc[SGR_ROW_BASE_N + ch];
+            if (ch < S && (ch & 3) == q) dL_dsemantic[(size_t)idx * S + ch] = acc[SGR_ROW_BASE_N + ch];
     }
 }
 
@@ -236,8 +234,9 @@ void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, cons
                           hipStream_t s) {
     if (P <= 0) return;
     const unsigned nb = (P + SGR_GB_THREADS - 1) / SGR_GB_THREADS;
+    const unsigned nb4 = (unsigned)(((size_t)P * 4 + SGR_GB_THREADS - 1) / SGR_GB_THREADS);  // four lanes per Gaussian
 #define SGR_RS(N)                                                                                                    \
-    sgr_row_sum_kernel<N><<<nb, SGR_GB_THREADS, 0, s>>>(P, S, radii, gv, partials, row_stride, touched, dL_dmean2D,   \
+    sgr_row_sum_kernel<N><<<nb4, SGR_GB_THREADS, 0, s>>>(P, S, radii, gv, partials, row_stride, touched, dL_dmean2D,   \
                                                         dL_dopacity, dL_dcolor, dL_dsemantic, cd)
     if (S == 0) SGR_RS(0);
     else if (S <= 4) SGR_RS(4);
