@@ -10,6 +10,9 @@
 #include "sgr_math.h"
 
 #define SGR_GB_THREADS 256
+#ifndef SGR_RS_LANES
+#define SGR_RS_LANES 4  // lanes that share one Gaussian's partial rows in the row-sum stage (4 or 8)
+#endif
 
 // ---- stage 1: sum the partial rows ---------------------------------------------------------------------------
 // A latency-bound gather (flag byte -> 48..176-byte row; n rows per Gaussian, n between 1 and hundreds), so it lives
@@ -26,7 +29,7 @@ sgr_row_sum_kernel(int P, int S, const int* __restrict__ radii, SgrGeomView gv, 
                    float4* __restrict__ cd) {
     constexpr int NV = (SGR_ROW_BASE_N + SMAX + 3) / 4;
     const int gtid = blockIdx.x * SGR_GB_THREADS + threadIdx.x;
-    const int idx = gtid >> 2, q = gtid & 3;
+    const int idx = gtid / SGR_RS_LANES, q = gtid % SGR_RS_LANES;
     float acc[4 * NV];
 #pragma unroll
     for (int k = 0; k < 4 * NV; k++) acc[k] = 0.f;
@@ -43,14 +46,14 @@ sgr_row_sum_kernel(int P, int S, const int* __restrict__ radii, SgrGeomView gv, 
             }
         };
         uint32_t i = (uint32_t)q;
-        for (; i + 4 < n; i += 8) {
-            const uint8_t f0 = flag[i], f1 = flag[i + 4];
+        for (; i + SGR_RS_LANES < n; i += 2 * SGR_RS_LANES) {
+            const uint8_t f0 = flag[i], f1 = flag[i + SGR_RS_LANES];
             float4 t0[NV], t1[NV];
             // rows never written by the blend backward hold garbage: load under the flag
             if (f0) { const float4* r = reinterpret_cast<const float4*>(rows + (size_t)i * row_stride);
 #pragma unroll
                 for (int k4 = 0; k4 < NV; k4++) t0[k4] = r[k4]; }
-            if (f1) { const float4* r = reinterpret_cast<const float4*>(rows + (size_t)(i + 4) * row_stride);
+            if (f1) { const float4* r = reinterpret_cast<const float4*>(rows + (size_t)(i + SGR_RS_LANES) * row_stride);
 #pragma unroll
                 for (int k4 = 0; k4 < NV; k4++) t1[k4] = r[k4]; }
             if (f0) add_row(t0);
@@ -69,6 +72,8 @@ sgr_row_sum_kernel(int P, int S, const int* __restrict__ radii, SgrGeomView gv, 
     for (int k = 0; k < 4 * NV; k++) {
         acc[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc[k]), 0xB1, 0xF, 0xF, false));
         acc[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc[k]), 0x4E, 0xF, 0xF, false));
+        if (SGR_RS_LANES == 8)  // row_half_mirror: lane i <-> 7 - i, i.e. the other quad of the 8-lane group
+            acc[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc[k]), 0x141, 0xF, 0xF, false));
     }
     if (!live) return;
     // the quad shares the stores
@@ -87,7 +92,7 @@ sgr_row_sum_kernel(int P, int S, const int* __restrict__ radii, SgrGeomView gv, 
     if (SMAX > 0) {
 #pragma unroll
         for (int ch = 0; ch < SMAX; ch++)
-            if (ch < S && (ch & 3) == q) dL_dsemantic[(size_t)idx * S + ch] = acc[SGR_ROW_BASE_N + ch];
+            if (ch < S && (ch & 3) == (q & 3) && q < 4) dL_dsemantic[(size_t)idx * S + ch] = acc[SGR_ROW_BASE_N + ch];
     }
 }
 
@@ -234,7 +239,7 @@ void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, cons
                           hipStream_t s) {
     if (P <= 0) return;
     const unsigned nb = (P + SGR_GB_THREADS - 1) / SGR_GB_THREADS;
-    const unsigned nb4 = (unsigned)(((size_t)P * 4 + SGR_GB_THREADS - 1) / SGR_GB_THREADS);  // four lanes per Gaussian
+    const unsigned nb4 = (unsigned)(((size_t)P * SGR_RS_LANES + SGR_GB_THREADS - 1) / SGR_GB_THREADS);
 #define SGR_RS(N)                                                                                                    \
     sgr_row_sum_kernel<N><<<nb4, SGR_GB_THREADS, 0, s>>>(P, S, radii, gv, partials, row_stride, touched, dL_dmean2D,   \
                                                         dL_dopacity, dL_dcolor, dL_dsemantic, cd)
