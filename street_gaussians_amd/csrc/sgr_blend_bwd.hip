@@ -17,6 +17,7 @@
 #include "sgr_math.h"
 
 #define SGR_TILE_THREADS 256
+typedef float sgr_f2 __attribute__((ext_vector_type(2)));
 // list entries staged in LDS per round.  128 (not 256) keeps the workgroup at 20 KB of LDS so that occupancy is set by
 // registers (5 waves / SIMD) instead of LDS (4): measured +11 % time at 3 workgroups / CU vs 4.
 #ifndef SGR_BWD_BATCH
@@ -226,8 +227,12 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
     // d(pixel)/d(ndc) (backward.cu:501-502) with the 1/log2(e) of the pre-scaled conic folded in
     const float kx = (0.5f * (float)W) / SGR_LOG2E, ky = (0.5f * (float)H) / SGR_LOG2E;
 
-    float accC0 = 0.f, accC1 = 0.f, accC2 = 0.f, lastC0 = 0.f, lastC1 = 0.f, lastC2 = 0.f;
-    float accD = 0.f, lastD = 0.f, accA = 0.f, last_alpha = 0.f;
+    // colour / depth recurrences as register pairs {C0, C1} and {C2, D}: the four channels follow the same recurrence,
+    // and the float4 {r, g, b, depth} read from LDS is already laid out that way, so they run on v_pk_mul / v_pk_fma
+    // (two values per instruction) without any shuffling
+    sgr_f2 acc01 = {0.f, 0.f}, acc2D = {0.f, 0.f}, last01 = {0.f, 0.f}, last2D = {0.f, 0.f};
+    const sgr_f2 dL01 = {dLdC0, dLdC1}, dL2D = {dLdC2, dLdD};
+    float accA = 0.f, last_alpha = 0.f;
     float accS[NS], lastS[NS];
 #pragma unroll
     for (int i = 0; i < NS; i++) { accS[i] = 0.f; lastS[i] = 0.f; }
@@ -309,12 +314,11 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                     T = T * inv1ma;  // T = T / (1 - alpha)
                     wm = alpha * T;
                     const float one_m_la = 1.0f - last_alpha;
-                    accC0 = fmaf(last_alpha, lastC0, one_m_la * accC0);
-                    accC1 = fmaf(last_alpha, lastC1, one_m_la * accC1);
-                    accC2 = fmaf(last_alpha, lastC2, one_m_la * accC2);
-                    float d = (c.x - accC0) * dLdC0 + (c.y - accC1) * dLdC1 + (c.z - accC2) * dLdC2;
-                    accD = fmaf(last_alpha, lastD, one_m_la * accD);
-                    d = fmaf(c.w - accD, dLdD, d);
+                    const sgr_f2 c01 = {c.x, c.y}, c2D = {c.z, c.w};
+                    acc01 = last_alpha * last01 + one_m_la * acc01;
+                    acc2D = last_alpha * last2D + one_m_la * acc2D;
+                    const sgr_f2 t = (c01 - acc01) * dL01 + (c2D - acc2D) * dL2D;
+                    float d = t.x + t.y;
                     accA = fmaf(one_m_la, accA, last_alpha);
                     d = fmaf(1.0f - accA, dLdA, d);
                     if (SMAX > 0) {  // padded channels carry zeros end to end (sSem, dLdS), so no per-channel test
@@ -332,8 +336,8 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                             }
                         }
                     }
-                    lastC0 = c.x; lastC1 = c.y; lastC2 = c.z;
-                    lastD = c.w;
+                    last01 = c01;
+                    last2D = c2D;
                     last_alpha = alpha;
                     d *= T;
                     dopa = fmaf(-T_final * inv1ma, bgdot, d);  // backward.cu:611-614
@@ -355,10 +359,11 @@ sgr_blend_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                 v[4] = h * gdx * dy;
                 v[5] = h * gdy * dy;
                 v[6] = G * dopa;
-                v[7] = wm * dLdC0;
-                v[8] = wm * dLdC1;
-                v[9] = wm * dLdC2;
-                v[10] = wm * dLdD;
+                const sgr_f2 o01 = wm * dL01, o2D = wm * dL2D;
+                v[7] = o01.x;
+                v[8] = o01.y;
+                v[9] = o2D.x;
+                v[10] = o2D.y;
                 // LDS row layout: float4 t = values (4t, 4t+2, 4t+1, 4t+3) -- the order the reduce-scatter leaves
                 // them in rows 0..3 of register t; the flush below swaps the middle pair back.
                 float r[NVAL / 4];
