@@ -1,6 +1,6 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
-TAG=${1:-v2}
+TAG=${1:-v3}
 mkdir -p $R/gpurun_out/ev_$TAG
 echo "== full gpu suite"; timeout 1500 python -m pytest tests -q --tb=short -m gpu 2>&1 | grep -v amdgpu.ids | tail -6 | tee $R/gpurun_out/ev_$TAG/pytest_gpu.log
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -2
