@@ -515,7 +515,7 @@ int sgr_test_sort32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t*
     SGR_STAGE("sort32");
     return cur;
 }
-size_t sgr_test_sort_hist_words(uint32_t n) { return (size_t)256 * sgr_sort_blocks(n ? n : 1); }
+size_t sgr_test_sort_hist_words(uint32_t n) { return sgr_sort_hist_words(n ? n : 1); }
 size_t sgr_test_scan_tmp_words(size_t n) { return sgr_scan_tmp_count(n ? n : 1); }
 int sgr_test_wave_sum(const float* in, float* out_dpp, float* out_shfl, int nwaves, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;

@@ -72,6 +72,10 @@ static inline void sgr_carve(char*& p, T*& out, size_t count) {
 #define SGR_SORT_MAX_PASS 8
 
 static inline size_t sgr_scan_tmp_count(size_t n) { return (n + SGR_SCAN_ITEMS - 1) / SGR_SCAN_ITEMS + 1; }
+// dwords of the radix sort's digit table: [256 digits][nblocks] + the 256 per-digit totals
+static inline size_t sgr_sort_hist_words(size_t n) {
+    return (size_t)256 * ((n + SGR_SORT_ITEMS - 1) / SGR_SORT_ITEMS) + 256;
+}
 
 // Carve the geometry buffer.  base may be (char*)256 to compute the required size: *end - base.
 static inline SgrGeomView sgr_geom_carve(char* base, size_t P, char** end = nullptr) {
@@ -91,7 +95,7 @@ static inline SgrGeomView sgr_geom_carve(char* base, size_t P, char** end = null
     sgr_carve(p, v.dvals[1], Pn);
     sgr_carve(p, v.tt_sorted, Pn);
     {
-        const size_t nh = (size_t)256 * ((Pn + SGR_SORT_ITEMS - 1) / SGR_SORT_ITEMS);
+        const size_t nh = sgr_sort_hist_words(Pn);
         sgr_carve(p, v.dhist, nh);
         sgr_carve(p, v.scan_tmp, sgr_scan_tmp_count(nh > Pn ? nh : Pn));
     }
@@ -106,7 +110,8 @@ static inline SgrBinView sgr_bin_carve(char* base, size_t R, char** end = nullpt
     char* p = base;
     size_t Rn = R ? R : 1;
     size_t nb = sgr_sort_blocks(Rn);
-    size_t nh = (size_t)256 * nb;
+    size_t nh = sgr_sort_hist_words(Rn);
+    (void)nb;
     sgr_carve(p, v.header, 64);
     sgr_carve(p, v.keys[0], Rn);
     sgr_carve(p, v.keys[1], Rn);

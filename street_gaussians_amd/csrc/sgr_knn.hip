@@ -196,7 +196,7 @@ int sgr_knn_impl(int P, const float* points, float* meanDists, sgr_alloc_fn scra
     const uint32_t n = (uint32_t)P;
     const uint32_t nb1 = (n + 4095u) / 4096u;
     const uint32_t nboxes = (n + SGR_KNN_BOX - 1) / SGR_KNN_BOX;
-    const size_t nh = (size_t)256 * sgr_sort_blocks(n);
+    const size_t nh = sgr_sort_hist_words(n);
     // carve the scratch
     char* p = (char*)256;
     uint64_t* keys[2]; uint32_t* vals[2]; uint32_t *hist, *scan_tmp; SgrBox *part, *bb, *boxes;

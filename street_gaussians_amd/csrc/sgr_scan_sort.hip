@@ -4,8 +4,10 @@
 // to 64, simple-knn's Morton sort (simple_knn.cu:210-213).
 //
 // Scan: reduce-then-scan over 2048-element blocks; wave64 shuffles inside a block.
-// Sort: 8-bit digits.  Per pass: an LDS-privatised per-block digit histogram, one exclusive scan of
-// the [digit][block] table, and a scatter that ranks its 2048-key block with a wave64
+// Sort: 8-bit digits.  Per pass, three launches: an LDS-privatised per-block digit histogram; a scan of
+// the [digit][block] table in which workgroup d scans row d and emits the row total (the scatter turns the
+// 256 totals into digit bases itself -- a generic device-wide scan would cost three launches here, and at
+// these sizes every launch is ~5 us of GPU time); and a scatter that ranks its 2048-key block with a wave64
 // ballot-match (8 ballots per key give the set of lanes sharing the digit; popcount of the lower
 // lanes is the stable rank) and per-wave LDS digit counters -- no atomics, fully deterministic.
 #include "sgr_common.h"
@@ -127,12 +129,39 @@ sgr_sort_hist_kernel(const K* __restrict__ keys, uint32_t n, int shift, uint32_t
     hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];  // [digit][block]
 }
 
+// workgroup d: exclusive scan of row d of the [digit][block] table in place; totals[d] = row sum
+__global__ void __launch_bounds__(256)
+sgr_sort_rowscan_kernel(uint32_t* __restrict__ hist, uint32_t nblocks, uint32_t* __restrict__ totals) {
+    __shared__ uint32_t lds4[4];
+    uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
+    uint32_t carry = 0;
+    for (uint32_t start = 0; start < nblocks; start += 256 * 8) {
+        const uint32_t base = start + threadIdx.x * 8;
+        uint32_t v[8], s = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            v[i] = (base + i < nblocks) ? row[base + i] : 0u;
+            s += v[i];
+        }
+        uint32_t total;
+        uint32_t run = carry + sgr_block_excl_scan256(s, lds4, total);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (base + i < nblocks) row[base + i] = run;
+            run += v[i];
+        }
+        carry += total;
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
 template <typename K>
 __global__ void __launch_bounds__(256)
 sgr_sort_scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* __restrict__ kout,
                         uint32_t* __restrict__ vout, uint32_t n, int shift, uint32_t nblocks,
-                        const uint32_t* __restrict__ hist_scanned) {
+                        const uint32_t* __restrict__ hist_scanned, const uint32_t* __restrict__ totals) {
     __shared__ uint32_t cnt[4][256];
+    __shared__ uint32_t lds4[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int w = 0; w < 4; w++) cnt[w][tid] = 0;
@@ -171,8 +200,9 @@ sgr_sort_scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ 
     __syncthreads();
     {
         const uint32_t c0 = cnt[0][tid], c1 = cnt[1][tid], c2 = cnt[2][tid];
-        const uint32_t g = hist_scanned[(size_t)tid * nblocks + blockIdx.x];
-        __syncthreads();
+        uint32_t all;
+        const uint32_t g = hist_scanned[(size_t)tid * nblocks + blockIdx.x] +
+                           sgr_block_excl_scan256(totals[tid], lds4, all);  // digit base; contains the barrier
         cnt[0][tid] = g;
         cnt[1][tid] = g + c0;
         cnt[2][tid] = g + c0 + c1;
@@ -192,7 +222,7 @@ sgr_sort_scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ 
 }
 
 // Sorts n pairs on key bits [0, end_bit).  keys[0]/vals[0] hold the input; returns the index (0/1)
-// of the pair of buffers that holds the sorted output.  hist: 256*nblocks words (+ scan_tmp).
+// of the pair of buffers that holds the sorted output.  hist: sgr_sort_hist_words(n) dwords (scan_tmp is unused).
 // The per-block digit histogram depends on where the previous pass left the keys, so it is
 // recomputed before every scatter pass.
 template <typename K>
@@ -204,9 +234,10 @@ static int sort_pairs_impl(K* const keys[2], uint32_t* const vals[2], uint32_t n
     int cur = 0;
     for (int p = 0; p < npass; p++) {
         sgr_sort_hist_kernel<K><<<nblocks, 256, 0, s>>>(keys[cur], n, 8 * p, nblocks, hist);
-        sgr_launch_scan(hist, hist, (size_t)256 * nblocks, scan_tmp, false, s);
+        uint32_t* totals = hist + (size_t)256 * nblocks;
+        sgr_sort_rowscan_kernel<<<256, 256, 0, s>>>(hist, nblocks, totals);
         sgr_sort_scatter_kernel<K><<<nblocks, 256, 0, s>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, 8 * p,
-                                                           nblocks, hist);
+                                                           nblocks, hist, totals);
         cur ^= 1;
     }
     return cur;
