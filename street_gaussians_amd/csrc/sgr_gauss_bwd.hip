@@ -106,9 +106,29 @@ sgr_gauss_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, con
                      float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
                      float* __restrict__ dL_dscale, float* __restrict__ dL_drot) {
     const SgrCam& cam = *camp;
-    const int idx = blockIdx.x * SGR_GB_THREADS + threadIdx.x;
-    if (idx >= P) return;
-    const bool visible = radii[idx] > 0;
+    // lanes past P stay alive (they help with the cooperative SH copies) on a clamped index; their stores are masked
+    const int gidx = blockIdx.x * SGR_GB_THREADS + threadIdx.x;
+    const bool live = gidx < P;
+    const int idx = live ? gidx : P - 1;
+    const bool visible = live && radii[idx] > 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // SH rows of 48 floats (M = 16): the 64 rows of a wave are one contiguous 12 KB block.  Per-lane float4 loads at
+    // a 192-byte stride touch 64 cache lines per instruction and were issue-bound (SQ_WAIT_INST_ANY 70 % of the
+    // wave-cycles); instead the wave copies the block with coalesced 1 KB transfers through LDS, both ways.
+    __shared__ float4 sSH[SGR_GB_THREADS / 64][64 * 12];
+    const bool stage = shs != nullptr && M == 16;
+    const int g0 = blockIdx.x * SGR_GB_THREADS + wave * 64;
+    const int nrow4 = max(0, min(64, P - g0)) * 12;  // float4s of this wave's rows
+    if (stage) {
+        const uint64_t vis = __ballot(visible);
+        const float4* src = reinterpret_cast<const float4*>(shs) + (size_t)g0 * 12;
+#pragma unroll
+        for (int it = 0; it < 12; it++) {
+            const int f = it * 64 + lane;
+            if (f < nrow4 && ((vis >> (f / 12)) & 1ull)) sSH[wave][f] = src[f];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
     float acc[SGR_ROW_BASE_N];
 #pragma unroll
     for (int k = 0; k < SGR_ROW_BASE_N; k++) acc[k] = 0.f;
@@ -175,7 +195,7 @@ sgr_gauss_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, con
             sgr_sh_basis(D, dir[0], dir[1], dir[2], Y);
             const float* sh = shs + (size_t)idx * M * 3;
             if (vec) {
-                const float4* sh4 = reinterpret_cast<const float4*>(sh);
+                const float4* sh4 = stage ? &sSH[wave][lane * 12] : reinterpret_cast<const float4*>(sh);
                 const int n4 = (ncoef * 3 + 3) >> 2;
 #pragma unroll
                 for (int i = 0; i < 12; i++) {
@@ -206,7 +226,20 @@ sgr_gauss_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, con
             dmean[0] += dm[0]; dmean[1] += dm[1]; dmean[2] += dm[2];
         }
         // dL/dSH row: Y_k * dL/dRGB below the active degree, zeros above and for culled Gaussians
-        if (vec) {
+        if (stage) {
+            __builtin_amdgcn_wave_barrier();  // every lane has read its row
+#pragma unroll
+            for (int i = 0; i < 12; i++)
+                sSH[wave][lane * 12 + i] = make_float4(dshv[4 * i], dshv[4 * i + 1], dshv[4 * i + 2], dshv[4 * i + 3]);
+            __builtin_amdgcn_wave_barrier();
+            float4* dst = reinterpret_cast<float4*>(dL_dsh) + (size_t)g0 * 12;
+#pragma unroll
+            for (int it = 0; it < 12; it++) {
+                const int f = it * 64 + lane;
+                if (f < nrow4) dst[f] = sSH[wave][f];
+            }
+        } else if (!live) {
+        } else if (vec) {
             float4* dsh4 = reinterpret_cast<float4*>(dsh);
             const int n4 = (M * 3) >> 2;
 #pragma unroll
@@ -220,6 +253,7 @@ sgr_gauss_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, con
         }
     }
 
+    if (!live) return;
     dL_dmean3D[3 * idx + 0] = dmean[0];
     dL_dmean3D[3 * idx + 1] = dmean[1];
     dL_dmean3D[3 * idx + 2] = dmean[2];
