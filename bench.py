@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--semantics", type=int, default=0)
     ap.add_argument("--loss", choices=["grads", "scalar"], default="grads",
                     help="grads: backward from fixed upstream gradients; scalar: torch-built loss sum(out*w)")
+    ap.add_argument("--step-times", action="store_true", help="debug: also print 10 individually synchronised steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-gaussians", type=int, default=0, help="override the CPU sample size")
     return ap.parse_args()
@@ -198,6 +199,16 @@ def main():
     counts = (C.c_int * 9)()
     L.sgr_profile_read(sums, counts)
     L.sgr_profile_enable(0)
+    if args.step_times:
+        for tag in ("profiled-off",):
+            ts = []
+            for _ in range(10):
+                fence()
+                t1 = time.perf_counter()
+                step()
+                fence()
+                ts.append(round(1e3 * (time.perf_counter() - t1), 3))
+            print(f"[step-times {tag}] {ts}", file=sys.stderr)
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
