@@ -12,7 +12,9 @@ sum(out * w); `--loss scalar` builds that loss with torch ops instead, which add
 that are not part of the rasterizer -- the CPU and reference-kernel baselines below are fed the same upstream
 gradients directly).  Inputs are resident in HBM.  With N > 1 every rank renders
 its own camera view of the replicated Gaussian set (weak scaling: per-GPU work fixed) and the per-Gaussian gradients
-are all-reduced over RCCL each step (street_gaussians_amd/multiview.py).  Rank 0 prints ONE JSON line.
+are summed over RCCL each step (street_gaussians_amd/multiview.py: by default the dense parameter gradients are
+all-reduced and the SH gradient, which is rank-1 per view, is rebuilt on every rank from an all-gather of the per-view
+dRGB; `--reduce bucket` all-reduces everything as one flat bucket).  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
   roofline     -- the dominant kernel (blend backward): algorithmic bytes per launch (SURVEY.md 8d B_blend_b)
@@ -53,6 +55,10 @@ def parse():
     ap.add_argument("--semantics", type=int, default=0)
     ap.add_argument("--loss", choices=["grads", "scalar"], default="grads",
                     help="grads: backward from fixed upstream gradients; scalar: torch-built loss sum(out*w)")
+    ap.add_argument("--reduce", choices=["factored", "bucket"], default="factored",
+                    help="N > 1 exchange: factored = all-reduce of the dense parameter gradients + all-gather of per-view "
+                         "dRGB with a local rebuild of dL/dSH (60 B/Gaussian on the wire); bucket = one flat all-reduce "
+                         "of everything (236 B/Gaussian)")
     ap.add_argument("--step-times", action="store_true", help="debug: also print 10 individually synchronised steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-gaussians", type=int, default=0, help="override the CPU sample size")
@@ -156,7 +162,16 @@ def main():
         bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=cam.viewmatrix.to(dev),
         projmatrix=cam.projmatrix.to(dev), sh_degree=3, campos=cam.campos.to(dev), prefiltered=False, debug=False)
     rast = GaussianRasterizer(st)
-    reducer = multiview.GradReducer(list(params.values()) + [means2D], force=force_dist) if dist is not None else None
+    # exchange step (N > 1): the optimiser's gradients.  dL/dmeans2D is not one of them -- it feeds per-view
+    # densification statistics (multiview.reduce_densification_stats) -- so it stays local.
+    reducer = None
+    if dist is not None:
+        if args.reduce == "factored":
+            dense = [v for k, v in params.items() if k != "shs"]
+            reducer = multiview.FactoredGradReducer(dense, params["shs"], params["means3D"], force=force_dist)
+        else:
+            reducer = multiview.GradReducer(list(params.values()), force=force_dist)
+        reducer.warm_up()  # RCCL's lazy communicator / channel set-up is not part of a training step
     stats = {}
 
     def step():
@@ -263,7 +278,10 @@ def main():
                        "gaussians": args.gaussians, "width": args.width, "height": args.height, "sh_degree": 3,
                        "semantic_channels": S, "loss": args.loss, "views_per_step": world, "num_rendered_R": R, "visible_V": V,
                        "R_over_P": round(R / args.gaussians, 3), "V_over_P": round(V / args.gaussians, 3),
-                       "parallelism": f"view-dp{world}" + (" + RCCL all-reduce of Gaussian grads" if world > 1 else "")},
+                       "parallelism": f"view-dp{world}" + ((" + RCCL all-reduce of Gaussian grads" + (
+                           " (dense 44 B/Gaussian; SH gradient rebuilt from an all-gather of per-view dRGB, 12 B/Gaussian/view)"
+                           if args.reduce == "factored" else " (one 236 B/Gaussian bucket)")) if world > 1 else ""),
+                       "exchange_bytes_per_rank": reducer.nbytes if reducer is not None else 0},
             "roofline": {"bound": "hbm", "kernel": "sgr_blend_bwd_kernel",
                          "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": traffic,

@@ -67,6 +67,18 @@ int sgr_backward(int P, int D, int M, int R, int S, const float* background, int
                  float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                  float* dL_dsemantic, sgr_alloc_fn scratch, void* scratch_user, int debug, void* stream);
 
+/* ---- view-sharded multi-GPU training (BASELINE.json north_star; no counterpart in the single-GPU reference) -------
+ * The SH gradient of one view is rank-1: dL/dSH[k][c] = Y_k(dir) * dRGB[c] (cuda_rasterizer/backward.cu:46-105), so
+ * ranks exchange the 3 floats of dRGB per Gaussian instead of the 3*M floats of dL/dSH and rebuild the sum locally.
+ *
+ * sgr_masked_color_grad: dL_drgb[P,3] = dL_dcolor[P,3] (as returned by sgr_backward) with the channels the forward
+ * clamped at zero (forward.cu:64-70) set to 0 (backward.cu:40-44).  geom_buffer = the one sgr_forward filled. */
+int sgr_masked_color_grad(int P, const char* geom_buffer, const float* dL_dcolor, float* dL_drgb, void* stream);
+/* sgr_sh_grad_from_views: dL_dsh[P,M,3] = sum over v < V of Y(normalize(means3D - campos[v])) (x) dL_drgb[v]
+ * (campos [V,3], dL_drgb [V,P,3]); coefficients k >= (D+1)^2 are written as zeros, like sgr_backward does. */
+int sgr_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* campos, const float* dL_drgb,
+                           float* dL_dsh, void* stream);
+
 /* CudaRasterizer::Rasterizer::markVisible  (cuda_rasterizer/rasterizer.h:24-29, rasterizer_impl.cu:141-153).
  * present[P] as bytes (0/1). */
 int sgr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,

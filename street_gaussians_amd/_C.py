@@ -203,6 +203,36 @@ _EXPORT = {"depths": (0, torch.float32, lambda P, R, N, T: (P,)), "clamped": (1,
            "extents": (14, torch.float32, lambda P, R, N, T: (P, 2))}
 
 
+def masked_color_grad(geomBuffer, grad_colors, P):
+    """sgr_masked_color_grad: dL/dcolour with the channels the forward clamped set to zero -> [P, 3]."""
+    _dev_check(grad_colors, "grad_colors")
+    dev = grad_colors.device
+    out = torch.empty((int(P), 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_native.lib().sgr_masked_color_grad(int(P), C.c_void_p(geomBuffer.data_ptr()),
+                                                  C.c_void_p(grad_colors.contiguous().data_ptr()),
+                                                  C.c_void_p(out.data_ptr()), _stream(dev)))
+    return out
+
+
+def sh_grad_from_views(means3D, campos, drgb, degree, M):
+    """sgr_sh_grad_from_views: sum_v Y(normalize(means3D - campos[v])) (x) drgb[v] -> dL/dSH [P, M, 3].
+    campos [V, 3], drgb [V, P, 3]."""
+    _dev_check(means3D, "means3D")
+    dev = means3D.device
+    P, V = means3D.size(0), campos.size(0)
+    if drgb.shape != (V, P, 3):
+        raise RuntimeError("drgb must have dimensions (num_views, num_points, 3)")
+    out = torch.empty((P, int(M), 3), dtype=torch.float32, device=dev)
+    f32 = lambda t: t.detach().to(torch.float32).contiguous()
+    means3D, campos, drgb = f32(means3D), f32(campos), f32(drgb)
+    with torch.cuda.device(dev):
+        check(_native.lib().sgr_sh_grad_from_views(P, int(degree), int(M), V, C.c_void_p(means3D.data_ptr()),
+                                                   C.c_void_p(campos.data_ptr()), C.c_void_p(drgb.data_ptr()),
+                                                   C.c_void_p(out.data_ptr()), _stream(dev)))
+    return out
+
+
 def export_internal(name, P, R, image_height, image_width, geomBuffer, binningBuffer, imageBuffer):
     """Parity-test introspection (sgr_export_internal): dense copy of one internal array."""
     which, dtype, shp = _EXPORT[name]

@@ -21,7 +21,8 @@ SYMBOLS = [
     "sgr_last_error", "sgr_version", "sgr_forward", "sgr_backward", "sgr_mark_visible", "sgr_visible_filter",
     "sgr_knn", "sgr_geometry_bytes", "sgr_binning_bytes", "sgr_image_bytes", "sgr_partial_row_floats",
     "sgr_export_internal", "sgr_test_scan", "sgr_test_sort", "sgr_test_sort32", "sgr_test_sort_hist_words", "sgr_test_scan_tmp_words",
-    "sgr_test_wave_sum", "sgr_profile_enable", "sgr_profile_read",
+    "sgr_test_wave_sum", "sgr_profile_enable", "sgr_profile_read", "sgr_masked_color_grad",
+    "sgr_sh_grad_from_views",
 ]
 
 
@@ -57,6 +58,10 @@ def lib():
         L.sgr_mark_visible.argtypes = [i, vp, vp, vp, vp, vp]
         L.sgr_visible_filter.restype = i
         L.sgr_visible_filter.argtypes = [i, i, i, vp, vp, f, vp, vp, vp, vp, f, f, i, vp, vp, i, vp]
+        L.sgr_masked_color_grad.restype = i
+        L.sgr_masked_color_grad.argtypes = [i, vp, vp, vp, vp]
+        L.sgr_sh_grad_from_views.restype = i
+        L.sgr_sh_grad_from_views.argtypes = [i, i, i, i, vp, vp, vp, vp, vp]
         L.sgr_knn.restype = i
         L.sgr_knn.argtypes = [i, vp, vp, ALLOC_FN, vp, vp]
         L.sgr_export_internal.restype = i

@@ -45,6 +45,9 @@ void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, cons
                           float4* cd, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dsemantic,
                           hipStream_t s);
+void sgr_launch_masked_color_grad(int P, const uint32_t* clamped, const float* dL_dcolor, float* out, hipStream_t s);
+void sgr_launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* campos,
+                                   const float* drgb, float* dL_dsh, hipStream_t s);
 void sgr_launch_wave_sum_test(const float* in, float* out_dpp, float* out_shfl, int nwaves, hipStream_t s);
 int sgr_knn_impl(int P, const float* points, float* meanDists, sgr_alloc_fn scratch, void* scratch_user, hipStream_t s,
                  std::string& err);
@@ -341,6 +344,30 @@ int sgr_backward(int P, int D, int M, int R, int S, const float* background, int
                          dL_drot, dL_dsemantic, stream);
     SGR_STAGE("gauss_bwd");
     prof_end(stream);
+    return 0;
+}
+
+// ---- view-sharded training: factored exchange of the SH gradient (sgr_multiview.hip) ----
+int sgr_masked_color_grad(int P, const char* geom_buffer, const float* dL_dcolor, float* dL_drgb, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int debug = 0;
+    if (P <= 0) return 0;
+    if (!geom_buffer || !dL_dcolor || !dL_drgb) return fail(SGR_E_INVALID, "geom_buffer, dL_dcolor and dL_drgb are required");
+    const SgrGeomView gv = sgr_geom_carve(const_cast<char*>(geom_buffer), (size_t)P);
+    sgr_launch_masked_color_grad(P, gv.clamped, dL_dcolor, dL_drgb, stream);
+    SGR_STAGE("masked_color_grad");
+    return 0;
+}
+
+int sgr_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* campos, const float* dL_drgb,
+                           float* dL_dsh, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int debug = 0;
+    if (P <= 0) return 0;
+    if (D < 0 || D > 3 || M < (D + 1) * (D + 1) || V < 0) return fail(SGR_E_INVALID, "need 0 <= D <= 3, M >= (D+1)^2, V >= 0");
+    if (!means3D || !campos || !dL_drgb || !dL_dsh) return fail(SGR_E_INVALID, "means3D, campos, dL_drgb and dL_dsh are required");
+    sgr_launch_sh_grad_from_views(P, D, M, V, means3D, campos, dL_drgb, dL_dsh, stream);
+    SGR_STAGE("sh_grad_from_views");
     return 0;
 }
 

@@ -8,6 +8,11 @@ bucket so a step issues one large collective (236 B per Gaussian at SH degree 3,
 one per tensor; on the 8-GPU xGMI mesh a reduce-scatter + all-gather pair keeps all seven links busy, so that
 is what ``mode="rs_ag"`` issues explicitly (the default lets RCCL choose).
 
+``FactoredGradReducer`` cuts the exchange to a quarter: 48 of those 59 floats are dL/dSH, and the SH gradient of one
+view is rank-1, ``dL/dSH[k][c] = Y_k(dir) * dRGB[c]`` (cuda_rasterizer/backward.cu:46-105).  Ranks all-gather the
+3 floats of dRGB per Gaussian (+ their camera centre) and rebuild ``sum_v Y(dir_v) (x) dRGB_v`` locally with one HIP
+kernel (csrc/sgr_multiview.hip): 44 B all-reduced + 12 B all-gathered per Gaussian instead of 236 B all-reduced.
+
 Also combines the densification statistics the training loop derives from the rasterizer outputs
 (/root/reference/lib/models/street_gaussian_model.py:551-571): sums for the view-space gradient accumulators,
 max for the screen radii.  Works with the gloo backend on CPU tensors (tests/test_multiview_gloo.py).
@@ -46,12 +51,18 @@ class GradReducer:
     def nbytes(self) -> int:
         return self.flat.numel() * 4
 
-    def all_reduce(self) -> None:
-        """Sum gradients over all ranks; ``p.grad`` is replaced by a view of the reduced bucket."""
+    def warm_up(self, rounds: int = 3) -> None:
+        """Run the collective on the (zeroed) bucket a few times: RCCL builds communicators, channels and its
+        algorithm tables lazily on first use -- seconds that belong to set-up, not to a training step."""
         if self.world == 1 and not self.force:
             return
-        grads = [p.grad if p.grad is not None else torch.zeros_like(v) for p, v in zip(self.params, self._views)]
-        torch._foreach_copy_(self._views, grads)
+        self.flat.zero_()
+        for _ in range(rounds):
+            self._collective()
+        if self.flat.is_cuda:
+            torch.cuda.synchronize(self.flat.device)
+
+    def _collective(self) -> None:
         if self.mode == "rs_ag":
             shard = self.flat.numel() // self.world
             rank = dist.get_rank(self.group)
@@ -60,10 +71,115 @@ class GradReducer:
             dist.all_gather_into_tensor(self.flat, mine.clone(), group=self.group)
         else:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    def all_reduce(self) -> None:
+        """Sum gradients over all ranks; ``p.grad`` is replaced by a view of the reduced bucket."""
+        if self.world == 1 and not self.force:
+            return
+        grads = [p.grad if p.grad is not None else torch.zeros_like(v) for p, v in zip(self.params, self._views)]
+        torch._foreach_copy_(self._views, grads)
+        self._collective()
         if self.average:
             self.flat.div_(self.world)
         for p, v in zip(self.params, self._views):
             p.grad = v
+
+
+class FactoredGradReducer:
+    """Exchange step for view-sharded training with SH colours: dense parameters through a flat all-reduce bucket, the
+    SH gradient through an all-gather of per-view dRGB + a local rebuild (module docstring).
+
+    dense_params  parameters whose ``.grad`` is all-reduced as is (means3D, scales, rotations, opacities, semantics ...)
+    shs           the SH coefficient parameter [P, M, 3]; its ``.grad`` is REPLACED by the rebuilt sum over all views
+    means3D       positions [P, 3] (view directions are recomputed from them on every rank)
+    views_per_rank  rasterizer backward calls every rank makes per step (equal on all ranks)
+
+    The per-view dL/dcolour, geometry buffer and camera centre are picked up from the rasterizer's backward through
+    ``rasterizer.BACKWARD_OBSERVERS``; call ``close()`` (or use it as a context manager) to detach.  ``mask_fn`` /
+    ``rebuild_fn`` default to the HIP kernels and exist so the collective logic can be tested on CPU tensors with the
+    gloo backend; there is no CPU implementation in the product.
+    """
+
+    def __init__(self, dense_params: Iterable[torch.Tensor], shs: torch.Tensor, means3D: torch.Tensor,
+                 group: Optional[dist.ProcessGroup] = None, views_per_rank: int = 1, mode: str = "all_reduce",
+                 force: bool = False, mask_fn=None, rebuild_fn=None):
+        from . import rasterizer as _rast
+        self.dense = GradReducer(dense_params, group=group, mode=mode, force=force)
+        self.shs, self.means3D, self.group, self.force = shs, means3D, group, force
+        self.k = int(views_per_rank)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._mask_fn, self._rebuild_fn = mask_fn, rebuild_fn
+        self._pending = []
+        P = means3D.shape[0]
+        dev = means3D.device
+        # payload of one view: [campos (3) | dRGB (3P)]
+        self._mine = torch.zeros(self.k, 3 + 3 * P, dtype=torch.float32, device=dev)
+        self._all = torch.zeros(self.world * self.k, 3 + 3 * P, dtype=torch.float32, device=dev)
+        self._rast = _rast
+        _rast.BACKWARD_OBSERVERS.append(self._observe)
+
+    # -- rasterizer backward hook --
+    def _observe(self, grad_colors, geomBuffer, campos, sh_degree, num_points):
+        if len(self._pending) >= self.k:
+            raise RuntimeError(f"more than views_per_rank={self.k} rasterizer backward passes since the last exchange")
+        if self._mask_fn is not None:
+            drgb = self._mask_fn(geomBuffer, grad_colors, num_points)
+        else:
+            from . import _C
+            drgb = _C.masked_color_grad(geomBuffer, grad_colors, num_points)
+        slot = self._mine[len(self._pending)]
+        slot[:3].copy_(campos.reshape(3))
+        slot[3:].copy_(drgb.reshape(-1))
+        self._pending.append(int(sh_degree))
+
+    @property
+    def nbytes(self) -> int:
+        """Bytes this rank contributes to the collectives per step."""
+        return self.dense.nbytes + self._mine.numel() * 4
+
+    def warm_up(self, rounds: int = 3) -> None:
+        """Set-up time collectives (see GradReducer.warm_up)."""
+        if self.world == 1 and not self.force:
+            return
+        self.dense.warm_up(rounds)
+        if dist.is_initialized():
+            for _ in range(rounds):
+                dist.all_gather_into_tensor(self._all, self._mine, group=self.group)
+        if self._all.is_cuda:
+            torch.cuda.synchronize(self._all.device)
+
+    def all_reduce(self) -> None:
+        if len(self._pending) != self.k:
+            raise RuntimeError(f"expected {self.k} rasterizer backward passes before the exchange, saw {len(self._pending)}")
+        degree = self._pending[0]
+        self._pending = []
+        if self.world == 1 and not self.force:
+            return  # shs.grad of the single view is already the sum
+        self.dense.all_reduce()
+        if self.world > 1 or dist.is_initialized():
+            dist.all_gather_into_tensor(self._all, self._mine, group=self.group)
+        else:
+            self._all.copy_(self._mine)
+        V = self._all.shape[0]
+        P, M = self.means3D.shape[0], self.shs.shape[1]
+        campos = self._all[:, :3].contiguous()
+        drgb = self._all[:, 3:].reshape(V, P, 3)
+        if self._rebuild_fn is not None:
+            grad = self._rebuild_fn(self.means3D.detach(), campos, drgb, degree, M)
+        else:
+            from . import _C
+            grad = _C.sh_grad_from_views(self.means3D.detach(), campos, drgb, degree, M)
+        self.shs.grad = grad.view_as(self.shs)
+
+    def close(self) -> None:
+        if self._observe in self._rast.BACKWARD_OBSERVERS:
+            self._rast.BACKWARD_OBSERVERS.remove(self._observe)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 def reduce_densification_stats(xyz_gradient_accum: torch.Tensor, denom: torch.Tensor, max_radii2D: torch.Tensor,

@@ -25,6 +25,11 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, semantics, opaciti
                                      cov3Ds_precomp, raster_settings)
 
 
+# callables invoked at the end of every rasterizer backward with that view's dL/dcolour, geometry buffer and camera
+# centre; empty unless a multiview.FactoredGradReducer is alive (extension, not part of the reference API)
+BACKWARD_OBSERVERS = []
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, semantics, opacities, scales, rotations, cov3Ds_precomp,
@@ -78,6 +83,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         else:
             (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
              grad_scales, grad_rotations, grad_semantics) = _C.rasterize_gaussians_backward(*args)
+
+        for observer in list(BACKWARD_OBSERVERS):  # view-sharded training (multiview.FactoredGradReducer)
+            observer(grad_colors=grad_colors_precomp, geomBuffer=geomBuffer, campos=raster_settings.campos,
+                     sh_degree=raster_settings.sh_degree, num_points=means3D.shape[0])
 
         # same order as the reference (__init__.py:152-163); gradients of inputs that do not take part in
         # autograd (None / empty placeholders) are dropped instead of returned and ignored

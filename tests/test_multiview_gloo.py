@@ -58,3 +58,72 @@ def test_grad_reducer_world2(mode):
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok in res), res
+
+
+def _rebuild_ref(means3D, campos, drgb, degree, M):
+    """float64 autograd reference of sgr_sh_grad_from_views: d/dSH of sum_v <SH->RGB(dir_v), dRGB_v>."""
+    import torch_ref
+    P = means3D.shape[0]
+    shs = torch.zeros(P, M, 3, dtype=torch.float64, requires_grad=True)
+    total = 0.0
+    for v in range(campos.shape[0]):
+        d = means3D.double() - campos[v].double()
+        d = d / d.norm(dim=1, keepdim=True)
+        total = total + (torch_ref.sh_to_rgb(degree, shs, d) * drgb[v].double()).sum()
+    total.backward()
+    return shs.grad.float()
+
+
+def _factored_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from street_gaussians_amd import multiview, rasterizer
+    P, M, deg, k = 257, 16, 3, 2
+    g = torch.Generator().manual_seed(7)
+    means3D = torch.randn(P, 3, generator=g) * 3 + torch.tensor([0.0, 0.0, 10.0])
+    shs = torch.zeros(P, M, 3, requires_grad=True)
+    dense = [torch.zeros(P, 3, requires_grad=True), torch.zeros(P, 1, requires_grad=True)]
+    campos = torch.randn(world * k, 3, generator=g)
+    colors = torch.randn(world * k, P, 3, generator=g)
+    clamp = torch.rand(world * k, P, 3, generator=g) < 0.2
+    dense_g = [[torch.randn(p.shape, generator=g) for p in dense] for _ in range(world)]
+    with multiview.FactoredGradReducer(dense, shs, means3D, views_per_rank=k,
+                                       mask_fn=lambda geom, gc, n: gc * (~geom).float(),
+                                       rebuild_fn=_rebuild_ref) as red:
+        ok = len(rasterizer.BACKWARD_OBSERVERS) == 1
+        for j in range(k):  # what the rasterizer's backward would report for this rank's views
+            v = rank * k + j
+            for obs in list(rasterizer.BACKWARD_OBSERVERS):
+                obs(grad_colors=colors[v], geomBuffer=clamp[v], campos=campos[v], sh_degree=deg, num_points=P)
+        for p, gr in zip(dense, dense_g[rank]):
+            p.grad = gr.clone()
+        shs.grad = torch.full_like(shs, float("nan"))  # must be replaced, not accumulated into
+        red.all_reduce()
+        exp = _rebuild_ref(means3D, campos, colors * (~clamp).float(), deg, M)
+        ok &= torch.allclose(shs.grad, exp, atol=1e-6)
+        for i, p in enumerate(dense):
+            ok &= torch.allclose(p.grad, sum(dense_g[r][i] for r in range(world)), atol=1e-6)
+        try:  # a second exchange without new backward passes is a usage error
+            red.all_reduce()
+            ok = False
+        except RuntimeError:
+            pass
+    ok &= len(rasterizer.BACKWARD_OBSERVERS) == 0
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_factored_grad_reducer_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_factored_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res
