@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 
 #include "../../include/sgr.h"
@@ -251,14 +252,31 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     sgr_launch_scan(gv.tt_sorted, gv.tt_sorted, (size_t)P, gv.scan_tmp, true, stream);
     SGR_STAGE("depth_sort+scan");
     prof_end(stream);
+    // The window between "R is known" and "the GPU runs out of queued work" is only the ~0.12 ms of sort + scan
+    // above, and the allocation callback (a Python call into the torch allocator in the shipped binding) is the
+    // slowest thing in it.  So the binning buffer is requested BEFORE the wait, sized for the previous forward's R
+    // + 25 % (per host thread); only if that turns out too small is it requested again with the exact size.  The
+    // carving below depends on R alone, so a larger buffer is simply partly unused.
+    static thread_local size_t r_hint = 0;
+    size_t have_bytes = 0;
+    char* bbase = nullptr;
+    if (r_hint > 0) {
+        have_bytes = sgr_binning_bytes((int)std::min<size_t>(r_hint, 0x7fffffffu));
+        bbase = binning_buffer(have_bytes, binning_user);
+        if (!bbase) return fail(SGR_E_ALLOC, "binning buffer allocation failed");
+    }
     SGR_HIP(hipEventSynchronize(landed));  // the one host wait of the forward
     if (host_vals[0] & 1u)
         return fail(SGR_E_PREFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
     if (host_vals[1] > 0x7fffffffu) return fail(SGR_E_INVALID, "more than 2^31 tile instances");
     const int R = (int)host_vals[1];
 
-    char* bbase = binning_buffer(sgr_binning_bytes(R), binning_user);
-    if (!bbase) return fail(SGR_E_ALLOC, "binning buffer allocation failed");
+    if (!bbase || sgr_binning_bytes(R) > have_bytes) {
+        bbase = binning_buffer(sgr_binning_bytes(R), binning_user);
+        if (!bbase) return fail(SGR_E_ALLOC, "binning buffer allocation failed");
+    }
+    // high-water mark with a slow decay: the views of one scene differ, and a miss only costs the late allocation
+    r_hint = std::max((size_t)R + (size_t)R / 4 + 1024, r_hint - r_hint / 16);
     const SgrBinView bv = sgr_bin_carve(bbase, (size_t)R);
 
     int cur = 0;
