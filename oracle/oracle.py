@@ -124,6 +124,8 @@ def forward(*, means3D, opacities, viewmatrix, projmatrix, campos, bg, tanfovx, 
     colors_precomp = _np(colors_precomp)
     semantics = _np(semantics)
     S = 0 if semantics is None else (semantics.shape[1] if semantics.ndim == 2 else 0)
+    if S > 20:  # the reference's per-pixel arrays hold NUM_CLASSES = 20 entries (cuda_rasterizer/config.h:16)
+        raise ValueError("the reference algorithm supports at most 20 semantic channels")
     M = 0 if shs is None or shs.size == 0 else shs.shape[1]
     a = dict(means3D=means3D, opacities=_np(opacities), viewmatrix=_np(viewmatrix), projmatrix=_np(projmatrix),
              campos=_np(campos), bg=_np(bg), shs=shs, colors_precomp=colors_precomp, scales=_np(scales),

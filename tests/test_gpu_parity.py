@@ -143,6 +143,30 @@ def test_culling_is_invisible_and_backward_is_deterministic(name, monkeypatch):
         grad_close(npy(g_a[k]), npy(g_c[k]), rel=1e-4, abs_frac=2e-5, name=f"dpp:{k}", max_outlier_frac=0.0)
 
 
+@pytest.mark.parametrize("P,S,scale_px", [(1, 0, 0.8), (2, 20, 0.3), (65, 1, 0.05), (129, 7, 0.02)])
+def test_edge_sizes(P, S, scale_px):
+    """Ragged sizes: fewer Gaussians than a wave, one Gaussian covering the whole tile grid (a single owner of every
+    slot in the cooperative duplicate kernel), the reference's maximum number of semantic channels (NUM_CLASSES = 20, config.h:16), P just past a wave boundary."""
+    cam = syn.make_camera(200, 120, fx=150.0)
+    sc = syn.make_scene(P, cam, S=S, seed=20 + P, scale_px=scale_px, zmin=2.0, zmax=4.0, margin=0.5)
+    kw = oracle_kwargs(cam, sc, deg=3)
+    wts = syn.loss_weights(cam, S=S)
+    fw = oracle.forward(**kw)
+    ref = oracle.backward(fw, wts["color"], wts["depth"], wts["alpha"], wts["semantic"] if S else None)
+    res, internal = raw_forward(kw)
+    assert res["R"] == fw.num_rendered and fw.num_rendered > 0
+    assert (npy(res["radii"]) == fw.radii).all()
+    assert (npy(internal("point_list")).view(np.uint32) == fw.point_list).all()
+    assert (npy(internal("ranges")).view(np.uint32) == fw.ranges).all()
+    image_close(npy(res["color"]), fw.color, name="color")
+    image_close(npy(res["alpha"]), fw.alpha, name="alpha")
+    image_close(npy(res["semantic"]), fw.semantic, name="semantic")
+    g = raw_backward(kw, res, wts)
+    for k in ["means2D", "colors", "opacity", "means3D", "cov3D", "sh", "scales", "rotations", "semantics"]:
+        grad_close(npy(g[k]).reshape(ref[k].shape), ref[k], rel=2e-4, abs_frac=3e-4, name=f"edge{P}:{k}")  # large overlapping splats: see SATURATING_TOL
+    fw.free()
+
+
 def test_precomputed_colors_and_cov3D():
     cam, sc, _ = CASES["mid_20k_sem3"]
     g = torch.Generator().manual_seed(5)
