@@ -22,7 +22,8 @@ SYMBOLS = [
     "sgr_knn", "sgr_geometry_bytes", "sgr_binning_bytes", "sgr_image_bytes", "sgr_partial_row_floats",
     "sgr_export_internal", "sgr_test_scan", "sgr_test_sort", "sgr_test_sort32", "sgr_test_sort_hist_words", "sgr_test_scan_tmp_words",
     "sgr_test_wave_sum", "sgr_profile_enable", "sgr_profile_read", "sgr_masked_color_grad",
-    "sgr_sh_grad_from_views",
+    "sgr_sh_grad_from_views", "sgr_scene_compose_forward", "sgr_scene_compose_backward",
+    "sgr_scene_densification_stats",
 ]
 
 
@@ -62,6 +63,12 @@ def lib():
         L.sgr_masked_color_grad.argtypes = [i, vp, vp, vp, vp]
         L.sgr_sh_grad_from_views.restype = i
         L.sgr_sh_grad_from_views.argtypes = [i, i, i, i, vp, vp, vp, vp, vp]
+        L.sgr_scene_compose_forward.restype = i
+        L.sgr_scene_compose_forward.argtypes = [i, vp, i, i, vp, vp, vp, vp, vp, vp, ALLOC_FN, vp, vp]
+        L.sgr_scene_compose_backward.restype = i
+        L.sgr_scene_compose_backward.argtypes = [i, vp, vp, i, i, vp, vp, vp, vp, vp, vp, ALLOC_FN, vp, vp]
+        L.sgr_scene_densification_stats.restype = i
+        L.sgr_scene_densification_stats.argtypes = [i, vp, vp, vp, ALLOC_FN, vp, vp]
         L.sgr_knn.restype = i
         L.sgr_knn.argtypes = [i, vp, vp, ALLOC_FN, vp, vp]
         L.sgr_export_internal.restype = i

@@ -88,6 +88,7 @@ static int fail(int code, const std::string& msg) {
     g_err = msg;
     return -code;
 }
+int sgr_set_error(int code, const std::string& msg) { return fail(code, msg); }  // for the other translation units
 
 #define SGR_HIP(call)                                                                            \
     do {                                                                                         \

@@ -1,0 +1,211 @@
+"""Scene-graph rows next to the rasterizer (include/sgr_scene.h).
+
+``compose`` flattens a street_gaussians scene graph -- one static background model plus one rigid, per-frame posed
+model per visible actor -- into the rasterizer's inputs, as one autograd op backed by HIP kernels.  It computes what
+``StreetGaussianModel.get_xyz / get_rotation / get_scaling / get_opacity / get_features / get_semantic`` compute
+with per-attribute ``torch.cat`` / ``einsum`` / quaternion products (/root/reference/lib/models/
+street_gaussian_model.py:287-449, gaussian_model.py:224-251, gaussian_model_actor.py:62-80), and back-propagates to
+every raw parameter and to each actor's pose.  ``densification_stats`` is the per-model scatter of
+``add_densification_stats`` + ``set_max_radii2D`` (:551-571) in one pass.
+
+There is no CPU implementation: tensors must live on the GPU and the HIP library must be built.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _native
+from ._native import ALLOC_FN, SgrError, check
+
+SEG_STATIC, SEG_ACTOR = 0, 1
+SEM_LOGITS, SEM_PROBABILITIES = 0, 1
+_SEM = {"logits": SEM_LOGITS, "probabilities": SEM_PROBABILITIES}
+
+
+class _CSeg(C.Structure):
+    _fields_ = [("count", C.c_int32), ("kind", C.c_int32), ("fourier_dim", C.c_int32), ("class_label", C.c_int32),
+                ("sem_mode", C.c_int32), ("flip_axis", C.c_int32), ("flip_quat", C.c_float * 4),
+                ("xyz", C.c_void_p), ("rotation", C.c_void_p), ("scaling", C.c_void_p), ("opacity", C.c_void_p),
+                ("features_dc", C.c_void_p), ("features_rest", C.c_void_p), ("semantic", C.c_void_p),
+                ("flip_mask", C.c_void_p), ("pose", C.c_void_p), ("idft", C.c_void_p)]
+
+
+class _CSegGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("xyz", "rotation", "scaling", "opacity", "features_dc", "features_rest",
+                                         "semantic", "pose")]
+
+
+class _CStatSeg(C.Structure):
+    _fields_ = [("count", C.c_int32), ("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p),
+                ("max_radii2D", C.c_void_p)]
+
+
+_TENSORS = ("xyz", "rotation", "scaling", "opacity", "features_dc", "features_rest", "semantic", "pose")
+
+
+@dataclass
+class Segment:
+    """One sub-model, raw (pre-activation) parameters as the reference stores them."""
+    xyz: torch.Tensor            # [n, 3]
+    rotation: torch.Tensor       # [n, 4]
+    scaling: torch.Tensor        # [n, 3]
+    opacity: torch.Tensor        # [n, 1]
+    features_dc: torch.Tensor    # [n, fourier_dim, 3]  (fourier_dim = 1 for the background)
+    features_rest: torch.Tensor  # [n, M-1, 3]
+    semantic: Optional[torch.Tensor] = None   # background [n, S]; actor [n, 1]
+    pose: Optional[torch.Tensor] = None       # actor: [7] = obj_rot (w, x, y, z), obj_trans; None = static model
+    idft: Optional[torch.Tensor] = None       # actor: [fourier_dim]
+    flip_mask: Optional[torch.Tensor] = None  # actor, training: [n] bool
+    class_label: int = 0
+    semantic_mode: str = "logits"
+    flip_axis: int = 1
+    flip_quat: Sequence[float] = field(default_factory=lambda: (0.0, 0.0, 1.0, 0.0))
+
+    @property
+    def kind(self) -> int:
+        return SEG_ACTOR if self.pose is not None else SEG_STATIC
+
+
+class _Grow:
+    def __init__(self, device):
+        self.device = device
+        self.tensor = None
+        self.cb = ALLOC_FN(self._alloc)
+
+    def _alloc(self, nbytes, _user):
+        self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self.tensor.data_ptr()
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _f32c(t, name):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise SgrError(f"{name} must be a HIP (cuda) tensor: there is no CPU path")
+    if t.dtype == torch.float32 and t.is_contiguous():
+        return t  # only the data pointer is used
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _pack(segs: List[Segment], tensors: List[Optional[torch.Tensor]]):
+    arr = (_CSeg * len(segs))()
+    keep = []
+    it = iter(tensors)
+    for c, s in zip(arr, segs):
+        vals = {n: _f32c(next(it), n) for n in _TENSORS}
+        keep.append(vals)
+        n = vals["xyz"].shape[0]
+        c.count, c.kind = n, s.kind
+        c.fourier_dim = vals["features_dc"].shape[1] if vals["features_dc"].dim() == 3 else 1
+        c.class_label, c.sem_mode, c.flip_axis = int(s.class_label), _SEM[s.semantic_mode], int(s.flip_axis)
+        c.flip_quat = (C.c_float * 4)(*[float(v) for v in s.flip_quat])
+        for name in _TENSORS:
+            setattr(c, name, vals[name].data_ptr() if vals[name] is not None and vals[name].numel() else None)
+        fm = None
+        if s.flip_mask is not None:
+            fm = s.flip_mask.to(torch.uint8).contiguous()
+            keep.append(fm)
+        c.flip_mask = fm.data_ptr() if fm is not None and fm.numel() else None
+        idft = _f32c(s.idft, "idft")
+        keep.append(idft)
+        c.idft = idft.data_ptr() if idft is not None else None
+    return arr, keep
+
+
+class _Compose(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, segs, M, S, *tensors):
+        dev = tensors[0].device
+        arr, keep = _pack(segs, list(tensors))
+        N = sum(int(c.count) for c in arr)
+        f = dict(dtype=torch.float32, device=dev)
+        outs = [torch.empty(N, 3, **f), torch.empty(N, 4, **f), torch.empty(N, 3, **f), torch.empty(N, 1, **f),
+                torch.empty(N, M, 3, **f), torch.empty(N, S, **f)]
+        grow = _Grow(dev)
+        with torch.cuda.device(dev):
+            check(_native.lib().sgr_scene_compose_forward(
+                len(segs), arr, int(M), int(S), *[_ptr(o) if o.numel() else None for o in outs], grow.cb, None,
+                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        ctx.segs, ctx.M, ctx.S = segs, int(M), int(S)
+        ctx.save_for_backward(*[t for t in tensors if t is not None])
+        ctx.present = [t is not None for t in tensors]
+        ctx.packed = (arr, keep)  # same storages in backward (autograd forbids in-place changes of saved tensors)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, d_means, d_rot, d_scale, d_opac, d_shs, d_sem):
+        saved = iter(ctx.saved_tensors)
+        tensors = [next(saved) if p else None for p in ctx.present]
+        segs, M, S = ctx.segs, ctx.M, ctx.S
+        dev = tensors[0].device
+        arr, keep = ctx.packed
+        garr = (_CSegGrads * len(segs))()
+        grads: List[Optional[torch.Tensor]] = []
+        need = ctx.needs_input_grad[3:]
+        # one allocation for all gradients (16-byte aligned slices), carved into per-parameter views
+        want = [t is not None and need[i] for i, t in enumerate(tensors)]
+        sizes = [((t.numel() + 3) // 4) * 4 if w else 0 for t, w in zip(tensors, want)]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        off = 0
+        for k, g in enumerate(garr):
+            for j, name in enumerate(_TENSORS):
+                i = k * len(_TENSORS) + j
+                out = None
+                if want[i]:
+                    t = tensors[i]
+                    out = flat[off:off + t.numel()].view(t.shape)
+                    off += sizes[i]
+                grads.append(out)
+                setattr(g, name, out.data_ptr() if out is not None and out.numel() else None)
+        dz = lambda t: None if t is None else _f32c(t, "grad")
+        ins = [dz(d_means), dz(d_rot), dz(d_scale), dz(d_opac), dz(d_shs), dz(d_sem) if S else None]
+        grow = _Grow(dev)
+        with torch.cuda.device(dev):
+            check(_native.lib().sgr_scene_compose_backward(
+                len(segs), arr, garr, M, S, *[_ptr(t) if t is not None and t.numel() else None for t in ins], grow.cb,
+                None, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        del keep
+        return (None, None, None) + tuple(grads)
+
+
+def compose(segments: List[Segment], max_sh_coeffs: int, num_classes: int):
+    """Returns (means3D [N,3], rotations [N,4], scales [N,3], opacities [N,1], shs [N,M,3], semantics [N,S]) for the
+    concatenation of ``segments`` (background first, then the visible actors, like ``parse_camera`` orders them)."""
+    if not segments:
+        raise ValueError("need at least one segment")
+    flat = []
+    for s in segments:
+        flat += [getattr(s, n) for n in _TENSORS]
+    return _Compose.apply(list(segments), int(max_sh_coeffs), int(num_classes), *flat)
+
+
+def densification_stats(models: Sequence[dict], dL_dmeans2D: torch.Tensor, radii: torch.Tensor) -> None:
+    """In-place update of every model's ``xyz_gradient_accum`` [n,2], ``denom`` [n,1] and ``max_radii2D`` [n] from one
+    view's screen-space gradient [N,3] and radii [N] (models in concatenation order; dict keys as the attribute
+    names of the reference's GaussianModel)."""
+    dev = dL_dmeans2D.device
+    if not dL_dmeans2D.is_cuda:
+        raise SgrError("dL_dmeans2D must be a HIP (cuda) tensor: there is no CPU path")
+    arr = (_CStatSeg * len(models))()
+    for c, m in zip(arr, models):
+        for k in ("xyz_gradient_accum", "denom", "max_radii2D"):
+            t = m[k]
+            if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+                raise SgrError(f"{k} must be a contiguous float32 HIP tensor (updated in place)")
+        c.count = m["denom"].shape[0]
+        c.xyz_gradient_accum, c.denom, c.max_radii2D = (m["xyz_gradient_accum"].data_ptr(), m["denom"].data_ptr(),
+                                                        m["max_radii2D"].data_ptr())
+    g = dL_dmeans2D.detach().to(torch.float32).contiguous()
+    r = radii.to(torch.int32).contiguous()
+    grow = _Grow(dev)
+    with torch.cuda.device(dev):
+        check(_native.lib().sgr_scene_densification_stats(len(models), arr, _ptr(g), _ptr(r), grow.cb, None,
+                                                          C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
