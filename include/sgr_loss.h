@@ -1,0 +1,46 @@
+/* sgr_loss.h -- C ABI of the image-space colour loss that consumes the rasterizer's RGB output.
+ *
+ * train.py:100-104 of the reference:
+ *     Ll1  = l1_loss(image, gt_image, mask)                                   lib/utils/loss_utils.py:21-37
+ *     loss = (1 - lambda_dssim) * lambda_l1 * Ll1 + lambda_dssim * (1 - ssim(image, gt_image, mask=mask))   :80-125
+ * ssim() runs five depthwise 11x11 Gaussian convolutions (zero padding) plus a dozen elementwise ops through
+ * MIOpen / autograd; its backward repeats them.  Here each of the two losses is one forward and one backward kernel.
+ *
+ * Images are planar float32 [C,H,W] DEVICE arrays; mask is [H,W] bytes (0/1) or NULL; results are device scalars.
+ * Reductions are two-stage with a fixed order (bit-reproducible). */
+#ifndef SGR_LOSS_H
+#define SGR_LOSS_H
+#include <stddef.h>
+#include <stdint.h>
+#include "sgr.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* workspace (floats) the SSIM forward needs for its per-block partial sums */
+size_t sgr_ssim_workspace_floats(int C, int H, int W);
+
+/* ssim(img1, img2, window_size = 11, size_average = True, mask)  (loss_utils.py:80-125).
+ * out_ssim[0] = mean of the SSIM map over all C*H*W positions (masked pixels of both images are zeroed first, :92-94).
+ * partials: NULL, or 3*C*H*W floats receiving dM/dmu1, dM/dsigma1^2, dM/dsigma12 per position for the backward. */
+int sgr_ssim_forward(int C, int H, int W, const float* img1, const float* img2, const uint8_t* mask, float* out_ssim,
+                     float* partials, float* workspace, void* stream);
+/* dL/dimg1 [C,H,W] = upstream[0] / (C*H*W) * d(sum of the SSIM map)/dimg1  (zero where the mask is 0). */
+int sgr_ssim_backward(int C, int H, int W, const float* img1, const float* img2, const uint8_t* mask,
+                      const float* partials, const float* upstream, float* dL_dimg1, void* stream);
+
+/* workspace (floats) of the L1 forward */
+size_t sgr_l1_workspace_floats(int C, int H, int W);
+/* l1_loss(network_output, gt, mask)  (loss_utils.py:21-37): mean of |a - b| over the masked pixels' C values.
+ * out[0] = loss, out[1] = number of values averaged (C * masked pixels).  An empty mask gives NaN like torch's mean. */
+int sgr_l1_forward(int C, int H, int W, const float* a, const float* b, const uint8_t* mask, float* out, float* workspace,
+                   void* stream);
+/* dL/da = upstream[0] * sign(a - b) / out[1] on masked pixels, 0 elsewhere. */
+int sgr_l1_backward(int C, int H, int W, const float* a, const float* b, const uint8_t* mask, const float* out,
+                    const float* upstream, float* dL_da, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

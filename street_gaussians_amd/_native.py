@@ -23,7 +23,8 @@ SYMBOLS = [
     "sgr_export_internal", "sgr_test_scan", "sgr_test_sort", "sgr_test_sort32", "sgr_test_sort_hist_words", "sgr_test_scan_tmp_words",
     "sgr_test_wave_sum", "sgr_profile_enable", "sgr_profile_read", "sgr_masked_color_grad",
     "sgr_sh_grad_from_views", "sgr_scene_compose_forward", "sgr_scene_compose_backward",
-    "sgr_scene_densification_stats",
+    "sgr_scene_densification_stats", "sgr_ssim_workspace_floats", "sgr_ssim_forward", "sgr_ssim_backward",
+    "sgr_l1_workspace_floats", "sgr_l1_forward", "sgr_l1_backward",
 ]
 
 
@@ -69,6 +70,17 @@ def lib():
         L.sgr_scene_compose_backward.argtypes = [i, vp, vp, i, i, vp, vp, vp, vp, vp, vp, ALLOC_FN, vp, vp]
         L.sgr_scene_densification_stats.restype = i
         L.sgr_scene_densification_stats.argtypes = [i, vp, vp, vp, ALLOC_FN, vp, vp]
+        for n in ("sgr_ssim_workspace_floats", "sgr_l1_workspace_floats"):
+            getattr(L, n).restype = C.c_size_t
+            getattr(L, n).argtypes = [i, i, i]
+        L.sgr_ssim_forward.restype = i
+        L.sgr_ssim_forward.argtypes = [i, i, i, vp, vp, vp, vp, vp, vp, vp]
+        L.sgr_ssim_backward.restype = i
+        L.sgr_ssim_backward.argtypes = [i, i, i, vp, vp, vp, vp, vp, vp, vp]
+        L.sgr_l1_forward.restype = i
+        L.sgr_l1_forward.argtypes = [i, i, i, vp, vp, vp, vp, vp, vp]
+        L.sgr_l1_backward.restype = i
+        L.sgr_l1_backward.argtypes = [i, i, i, vp, vp, vp, vp, vp, vp, vp]
         L.sgr_knn.restype = i
         L.sgr_knn.argtypes = [i, vp, vp, ALLOC_FN, vp, vp]
         L.sgr_export_internal.restype = i

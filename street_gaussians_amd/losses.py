@@ -1,0 +1,122 @@
+"""Drop-in `l1_loss` and `ssim` for /root/reference/lib/utils/loss_utils.py:21-37 and :80-125:
+same names, arguments and results, each backed by one forward and one backward HIP kernel (csrc/sgr_loss.hip) instead
+of ~30 MIOpen / elementwise launches.  `train.py:100-104` keeps its two lines; only the import changes:
+
+    from street_gaussians_amd.losses import l1_loss, ssim
+
+Tensors must live on the GPU; there is no CPU implementation in the product."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _native
+from ._native import SgrError, check
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _prep(img, name):
+    if not img.is_cuda:
+        raise SgrError(f"{name} must be a HIP (cuda) tensor: there is no CPU path")
+    if img.dim() == 4:
+        img = img.reshape(-1, img.shape[-2], img.shape[-1])
+    if img.dim() != 3:
+        raise RuntimeError(f"{name} must have dimensions (C, H, W)")
+    return img.to(torch.float32).contiguous()
+
+
+def _prep_mask(mask, H, W):
+    if mask is None:
+        return None
+    m = mask.reshape(-1, H, W)
+    if m.shape[0] != 1:
+        raise RuntimeError("mask must have dimensions (1, H, W)")
+    return m[0].to(torch.uint8).contiguous()
+
+
+class _SSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img1, img2, mask):
+        L = _native.lib()
+        Cc, H, W = img1.shape
+        dev = img1.device
+        need = img1.requires_grad
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        ws = torch.empty(L.sgr_ssim_workspace_floats(Cc, H, W), dtype=torch.float32, device=dev)
+        partials = torch.empty(3 * Cc * H * W, dtype=torch.float32, device=dev) if need else None
+        with torch.cuda.device(dev):
+            check(L.sgr_ssim_forward(Cc, H, W, _p(img1), _p(img2), _p(mask), _p(out), _p(partials), _p(ws), _stream(dev)))
+        ctx.save_for_backward(img1, img2, mask if mask is not None else torch.empty(0, device=dev), partials
+                              if partials is not None else torch.empty(0, device=dev))
+        ctx.has_mask = mask is not None
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, upstream):
+        img1, img2, mask, partials = ctx.saved_tensors
+        Cc, H, W = img1.shape
+        dev = img1.device
+        if partials.numel() == 0:
+            raise RuntimeError("ssim forward ran without requires_grad")
+        up = upstream.reshape(1).to(torch.float32).contiguous()
+        grad = torch.empty_like(img1)
+        with torch.cuda.device(dev):
+            check(_native.lib().sgr_ssim_backward(Cc, H, W, _p(img1), _p(img2), _p(mask) if ctx.has_mask else None,
+                                                  _p(partials), _p(up), _p(grad), _stream(dev)))
+        return grad, None, None
+
+
+class _L1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, mask):
+        L = _native.lib()
+        Cc, H, W = a.shape
+        dev = a.device
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        ws = torch.empty(L.sgr_l1_workspace_floats(Cc, H, W), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(L.sgr_l1_forward(Cc, H, W, _p(a), _p(b), _p(mask), _p(out), _p(ws), _stream(dev)))
+        ctx.save_for_backward(a, b, mask if mask is not None else torch.empty(0, device=dev), out)
+        ctx.has_mask = mask is not None
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, upstream):
+        a, b, mask, out = ctx.saved_tensors
+        Cc, H, W = a.shape
+        dev = a.device
+        up = upstream.reshape(1).to(torch.float32).contiguous()
+        grad = torch.empty_like(a)
+        with torch.cuda.device(dev):
+            check(_native.lib().sgr_l1_backward(Cc, H, W, _p(a), _p(b), _p(mask) if ctx.has_mask else None, _p(out),
+                                                _p(up), _p(grad), _stream(dev)))
+        return grad, None, None
+
+
+def l1_loss(network_output: torch.Tensor, gt: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """loss_utils.py:21-37: mean |network_output - gt| over the C values of the pixels selected by mask (1, H, W)."""
+    a, b = _prep(network_output, "network_output"), _prep(gt, "gt")
+    if a.shape != b.shape:
+        raise RuntimeError("network_output and gt must have the same shape")
+    return _L1.apply(a, b.detach(), _prep_mask(mask, a.shape[1], a.shape[2]))
+
+
+def ssim(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11, size_average: bool = True,
+         mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """loss_utils.py:80-125: mean SSIM (11x11 Gaussian window, sigma 1.5, zero padding), both images zeroed where the
+    mask is False.  Gradient flows to img1 only (the ground truth is data)."""
+    if window_size != 11 or not size_average:
+        raise NotImplementedError("only window_size=11, size_average=True (the values train.py uses) are implemented")
+    a, b = _prep(img1, "img1"), _prep(img2, "img2")
+    if a.shape != b.shape:
+        raise RuntimeError("img1 and img2 must have the same shape")
+    return _SSIM.apply(a, b.detach(), _prep_mask(mask, a.shape[1], a.shape[2]))
