@@ -17,7 +17,7 @@ LU = "/root/reference/lib/utils/loss_utils.py"
 def _reference_namespace():
     src = open(LU).read()
     ns = {"torch": torch, "F": torch.nn.functional, "exp": __import__("math").exp, "Variable": lambda t: t}
-    for name in ("l1_loss", "gaussian", "create_window", "ssim", "_ssim"):
+    for name in ("l1_loss", "gaussian", "create_window", "ssim", "_ssim"):  # the reference's own source, executed in place
         m = re.search(rf"^def {name}\(.*?(?=^def |\Z)", src, re.S | re.M)
         exec(m.group(0), ns)
     return ns

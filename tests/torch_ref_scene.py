@@ -6,31 +6,25 @@ import torch
 import torch.nn.functional as F
 
 
-def quaternion_raw_multiply(a, b):  # utils/general_utils.py:220-238
-    aw, ax, ay, az = torch.unbind(a, -1)
-    bw, bx, by, bz = torch.unbind(b, -1)
-    ow = aw * bw - ax * bx - ay * by - az * bz
-    ox = aw * bx + ax * bw + ay * bz - az * by
-    oy = aw * by - ax * bz + ay * bw + az * bx
-    oz = aw * bz + ax * by - ay * bx + az * bw
-    return torch.stack((ow, ox, oy, oz), -1)
+def quaternion_raw_multiply(a, b):
+    """Hamilton product of (w, x, y, z) quaternions with broadcasting (utils/general_utils.py:220-238)."""
+    w1, x1, y1, z1 = a.unbind(-1)
+    w2, x2, y2, z2 = b.unbind(-1)
+    return torch.stack((w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2,
+                        w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                        w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+                        w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2), dim=-1)
 
 
-def quaternion_to_matrix(r):  # utils/general_utils.py:125-146
-    norm = torch.sqrt(r[:, 0] * r[:, 0] + r[:, 1] * r[:, 1] + r[:, 2] * r[:, 2] + r[:, 3] * r[:, 3])
-    q = r / norm[:, None]
-    R = torch.zeros((q.size(0), 3, 3), dtype=r.dtype, device=r.device)
-    r_, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
-    R[:, 0, 0] = 1 - 2 * (y * y + z * z)
-    R[:, 0, 1] = 2 * (x * y - r_ * z)
-    R[:, 0, 2] = 2 * (x * z + r_ * y)
-    R[:, 1, 0] = 2 * (x * y + r_ * z)
-    R[:, 1, 1] = 1 - 2 * (x * x + z * z)
-    R[:, 1, 2] = 2 * (y * z - r_ * x)
-    R[:, 2, 0] = 2 * (x * z - r_ * y)
-    R[:, 2, 1] = 2 * (y * z + r_ * x)
-    R[:, 2, 2] = 1 - 2 * (x * x + y * y)
-    return R
+def quaternion_to_matrix(quat):
+    """[n, 4] (w, x, y, z), not necessarily unit -> [n, 3, 3] rotation matrices; the quaternion is divided by its norm
+    first (utils/general_utils.py:125-146)."""
+    length = torch.sqrt(quat[:, 0] * quat[:, 0] + quat[:, 1] * quat[:, 1] + quat[:, 2] * quat[:, 2] + quat[:, 3] * quat[:, 3])
+    w, x, y, z = (quat / length[:, None]).unbind(-1)
+    rows = [torch.stack((1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)), dim=-1),
+            torch.stack((2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)), dim=-1),
+            torch.stack((2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)), dim=-1)]
+    return torch.stack(rows, dim=-2)
 
 
 def compose(segs, M, S):
