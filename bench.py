@@ -166,12 +166,23 @@ def main():
     # densification statistics (multiview.reduce_densification_stats) -- so it stays local.
     reducer = None
     if dist is not None:
+        def bucket():
+            return multiview.GradReducer(list(params.values()), force=force_dist)
         if args.reduce == "factored":
-            dense = [v for k, v in params.items() if k != "shs"]
-            reducer = multiview.FactoredGradReducer(dense, params["shs"], params["means3D"], force=force_dist)
-        else:
-            reducer = multiview.GradReducer(list(params.values()), force=force_dist)
-        reducer.warm_up()  # RCCL's lazy communicator / channel set-up is not part of a training step
+            try:
+                dense = [v for k, v in params.items() if k != "shs"]
+                reducer = multiview.FactoredGradReducer(dense, params["shs"], params["means3D"], force=force_dist)
+                reducer.warm_up()  # RCCL's lazy communicator / channel set-up is not part of a training step
+            except Exception as ex:  # measurement harness only: fall back to the plain bucket and say so
+                print(f"[bench] factored exchange unavailable ({type(ex).__name__}: {ex}); using --reduce bucket",
+                      file=sys.stderr)
+                if reducer is not None:
+                    reducer.close()
+                args.reduce = "bucket"
+                reducer = None
+        if reducer is None:
+            reducer = bucket()
+            reducer.warm_up()
     stats = {}
 
     def step():
