@@ -1,0 +1,217 @@
+// sgr_densify.hip -- adaptive density control as plan + gather (include/sgr_densify.h).
+//
+// Reference order of operations (gaussian_model.py:522-553): clone (appends copies), split (appends N children per
+// selected point -- only ORIGINAL points can be selected, the clones' padded gradient is 0, :455-460 -- and removes the
+// selected points), prune (low opacity / too big, evaluated on the new set), reset statistics.  Every decision is a
+// function of the ORIGINAL point's statistics: a clone has its parent's parameters, a split child its parent's opacity
+// and its parent's scale divided by 0.8 N.  So one pass computes, per original point, four masks
+//     A  survives as itself        = !split && !pruned(self)
+//     B  leaves a surviving clone  = clone && !pruned(self)
+//     S  is split                  (rank among S = the child's row in the repeat(N,1) layout)
+//     C  leaves surviving children = split && !pruned(child)
+// exclusive scans of the masks give every result row its position, in the reference's order.
+#include <string>
+
+#include "../../include/sgr_densify.h"
+#include "sgr_common.h"
+
+int sgr_set_error(int code, const std::string& msg);
+void sgr_launch_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, bool inclusive, hipStream_t s,
+                     uint32_t* total_out = nullptr);
+
+#define DN_HIP(call)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e__ = (call);                                                                           \
+        if (e__ != hipSuccess) return sgr_set_error(SGR_E_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+struct DnWork {
+    uint32_t *flags, *offA, *offB, *offS, *offC, *tmp, *totals;  // totals: nA nB nS nC nClone nPrunedCand
+};
+static DnWork dn_carve(char* base, size_t N) {
+    DnWork w;
+    char* p = base;
+    const size_t n = N ? N : 1;
+    sgr_carve(p, w.flags, n);
+    sgr_carve(p, w.offA, n);
+    sgr_carve(p, w.offB, n);
+    sgr_carve(p, w.offS, n);
+    sgr_carve(p, w.offC, n);
+    sgr_carve(p, w.tmp, sgr_scan_tmp_count(n));
+    sgr_carve(p, w.totals, 16);
+    return w;
+}
+
+#define DN_CLONE 1u
+#define DN_SPLIT 2u
+#define DN_PRUNE_SELF 4u
+#define DN_PRUNE_CHILD 8u
+
+__global__ void __launch_bounds__(256)
+sgr_densify_flags_kernel(int N, sgr_densify_params p, const float* __restrict__ accum, const float* __restrict__ denom,
+                         const float* __restrict__ scaling, const float* __restrict__ opacity, DnWork w) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    float g = accum[2 * i + p.grad_column] / denom[i];  // :523
+    if (g != g) g = 0.0f;                                // grads[grads.isnan()] = 0.0 (:524)
+    const float s0 = expf(scaling[3 * i]), s1 = expf(scaling[3 * i + 1]), s2 = expf(scaling[3 * i + 2]);
+    const float smax = fmaxf(s0, fmaxf(s1, s2));
+    const float dense = p.percent_dense * p.extent;
+    const bool clone = (fabsf(g) >= p.max_grad) && (smax <= dense);  // :497-499 (norm of a 1-vector)
+    const bool split = (g >= p.max_grad) && (smax > dense);          // :462-464
+    const float op = 1.0f / (1.0f + expf(-opacity[i]));
+    const bool low = op < p.min_opacity;                              // :533
+    const float big = p.extent * p.percent_big_ws;
+    const bool prune_self = low || (p.prune_big && smax > big);       // :536-540
+    // children: log(scale / (0.8 N)) -> exp gives scale / (0.8 N) again (up to rounding, like the reference's log/exp)
+    const float child = expf(logf(smax / (0.8f * (float)p.n_split)));
+    const bool prune_child = low || (p.prune_big && child > big);
+    const uint32_t f = (clone ? DN_CLONE : 0u) | (split ? DN_SPLIT : 0u) | (prune_self ? DN_PRUNE_SELF : 0u) |
+                       (prune_child ? DN_PRUNE_CHILD : 0u);
+    w.flags[i] = f;
+    w.offA[i] = (!split && !prune_self) ? 1u : 0u;
+    w.offB[i] = (clone && !prune_self) ? 1u : 0u;
+    w.offS[i] = split ? 1u : 0u;
+    w.offC[i] = (split && !prune_child) ? 1u : 0u;
+}
+
+__global__ void sgr_densify_count_kernel(int N, DnWork w) {
+    // one wave: clone count (not a scan total) in a fixed order
+    uint32_t c = 0;
+    for (int i = threadIdx.x; i < N; i += 64) c += (w.flags[i] & DN_CLONE) ? 1u : 0u;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+    if (threadIdx.x == 0) w.totals[4] = c;
+}
+
+__global__ void __launch_bounds__(256)
+sgr_densify_map_kernel(int N, int n_split, DnWork w, int32_t* __restrict__ src, uint8_t* __restrict__ kind,
+                       int32_t* __restrict__ sample_row) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t f = w.flags[i];
+    const uint32_t nA = w.totals[0], nB = w.totals[1], nS = w.totals[2], nC = w.totals[3];
+    const bool split = f & DN_SPLIT;
+    if (!split && !(f & DN_PRUNE_SELF)) {
+        const uint32_t o = w.offA[i];
+        src[o] = i; kind[o] = SGR_KIND_KEEP; sample_row[o] = -1;
+    }
+    if ((f & DN_CLONE) && !(f & DN_PRUNE_SELF)) {
+        const uint32_t o = nA + w.offB[i];
+        src[o] = i; kind[o] = SGR_KIND_CLONE; sample_row[o] = -1;
+    }
+    if (split && !(f & DN_PRUNE_CHILD)) {
+        for (int n = 0; n < n_split; n++) {  // repeat(N, 1): copy-major (:468-476)
+            const uint32_t o = nA + nB + (uint32_t)n * nC + w.offC[i];
+            src[o] = i; kind[o] = SGR_KIND_SPLIT_CHILD; sample_row[o] = (int32_t)((uint32_t)n * nS + w.offS[i]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+sgr_densify_gather_kernel(size_t total, int width, const float* __restrict__ in, const int32_t* __restrict__ src,
+                          const uint8_t* __restrict__ kind, int zero_new, float* __restrict__ out) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;  // one lane per float: coalesced writes, row-wise reads
+    if (e >= total) return;
+    const size_t r = e / (size_t)width;
+    const int j = (int)(e - r * (size_t)width);
+    out[e] = (zero_new && kind[r] != SGR_KIND_KEEP) ? 0.0f : in[(size_t)src[r] * width + j];
+}
+
+__global__ void __launch_bounds__(256)
+sgr_densify_children_kernel(int n_out, int n_split, const int32_t* __restrict__ src, const uint8_t* __restrict__ kind,
+                            const int32_t* __restrict__ sample_row, const float* __restrict__ xyz,
+                            const float* __restrict__ scaling, const float* __restrict__ rotation,
+                            const float* __restrict__ normals, float* __restrict__ xyz_out, float* __restrict__ scaling_out) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= n_out || kind[o] != SGR_KIND_SPLIT_CHILD) return;
+    const size_t i = (size_t)src[o], z = (size_t)sample_row[o];
+    const float s[3] = {expf(scaling[3 * i]), expf(scaling[3 * i + 1]), expf(scaling[3 * i + 2])};
+    const float v[3] = {normals[3 * z] * s[0], normals[3 * z + 1] * s[1], normals[3 * z + 2] * s[2]};  // normal(0, std)
+    // quaternion_to_matrix(self._rotation[sel]) (general_utils.py:125-146): raw quaternion divided by its norm
+    float qw = rotation[4 * i], qx = rotation[4 * i + 1], qy = rotation[4 * i + 2], qz = rotation[4 * i + 3];
+    const float nrm = sqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
+    qw /= nrm; qx /= nrm; qy /= nrm; qz /= nrm;
+    const float R[9] = {1.f - 2.f * (qy * qy + qz * qz), 2.f * (qx * qy - qw * qz), 2.f * (qx * qz + qw * qy),
+                        2.f * (qx * qy + qw * qz), 1.f - 2.f * (qx * qx + qz * qz), 2.f * (qy * qz - qw * qx),
+                        2.f * (qx * qz - qw * qy), 2.f * (qy * qz + qw * qx), 1.f - 2.f * (qx * qx + qy * qy)};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        xyz_out[3 * (size_t)o + a] = R[3 * a] * v[0] + R[3 * a + 1] * v[1] + R[3 * a + 2] * v[2] + xyz[3 * i + a];  // :471
+        scaling_out[3 * (size_t)o + a] = logf(s[a] / (0.8f * (float)n_split));                                          // :472
+    }
+}
+
+extern "C" {
+
+size_t sgr_densify_work_bytes(int N) {
+    char* base = (char*)4096;
+    DnWork w = dn_carve(base, (size_t)(N > 0 ? N : 1));
+    return (size_t)((char*)(w.totals + 16) - base) + 512;
+}
+
+int sgr_densify_plan(int N, const sgr_densify_params* p, const float* xyz_gradient_accum, const float* denom,
+                     const float* scaling, const float* opacity, char* work, int64_t counts[6], void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!p || !counts) return sgr_set_error(SGR_E_INVALID, "p and counts are required");
+    for (int k = 0; k < 6; k++) counts[k] = 0;
+    if (N <= 0) return 0;
+    if (!xyz_gradient_accum || !denom || !scaling || !opacity || !work)
+        return sgr_set_error(SGR_E_INVALID, "statistics, scaling, opacity and work are required");
+    if (p->n_split < 1 || p->grad_column < 0 || p->grad_column > 1) return sgr_set_error(SGR_E_INVALID, "n_split >= 1, grad_column in {0,1}");
+    const DnWork w = dn_carve((char*)sgr_align_up((size_t)work, 256), (size_t)N);
+    sgr_densify_flags_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, *p, xyz_gradient_accum, denom, scaling, opacity, w);
+    sgr_launch_scan(w.offA, w.offA, (size_t)N, w.tmp, false, stream, w.totals + 0);
+    sgr_launch_scan(w.offB, w.offB, (size_t)N, w.tmp, false, stream, w.totals + 1);
+    sgr_launch_scan(w.offS, w.offS, (size_t)N, w.tmp, false, stream, w.totals + 2);
+    sgr_launch_scan(w.offC, w.offC, (size_t)N, w.tmp, false, stream, w.totals + 3);
+    sgr_densify_count_kernel<<<1, 64, 0, stream>>>(N, w);
+    uint32_t t[8];
+    DN_HIP(hipMemcpyAsync(t, w.totals, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    DN_HIP(hipStreamSynchronize(stream));
+    const int64_t nA = t[0], nB = t[1], nS = t[2], nC = t[3], nClone = t[4];
+    const int64_t n_out = nA + nB + (int64_t)p->n_split * nC;
+    const int64_t candidates = ((int64_t)N - nS) + nClone + (int64_t)p->n_split * nS;  // the set prune_mask is evaluated on
+    counts[0] = N; counts[1] = nClone; counts[2] = nS; counts[3] = candidates - n_out; counts[4] = n_out;
+    counts[5] = (int64_t)p->n_split * nS;
+    if (n_out > 0x7fffffff) return sgr_set_error(SGR_E_INVALID, "more than 2^31 points after densification");
+    return 0;
+}
+
+int sgr_densify_map(int N, const sgr_densify_params* p, const char* work, int32_t* src, uint8_t* kind, int32_t* sample_row,
+                    void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N <= 0) return 0;
+    if (!p || !work || !src || !kind || !sample_row) return sgr_set_error(SGR_E_INVALID, "p, work, src, kind and sample_row are required");
+    const DnWork w = dn_carve((char*)sgr_align_up((size_t)work, 256), (size_t)N);
+    sgr_densify_map_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, p->n_split, w, src, kind, sample_row);
+    DN_HIP(hipGetLastError());
+    return 0;
+}
+
+int sgr_densify_gather(int n_out, int width, const float* in, const int32_t* src, const uint8_t* kind, int zero_new,
+                       float* out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_out <= 0 || width <= 0) return 0;
+    if (!in || !src || !kind || !out) return sgr_set_error(SGR_E_INVALID, "in, src, kind and out are required");
+    const size_t total = (size_t)n_out * width;
+    sgr_densify_gather_kernel<<<(unsigned)((total + 255) / 256), 256, 0, stream>>>(total, width, in, src, kind, zero_new, out);
+    DN_HIP(hipGetLastError());
+    return 0;
+}
+
+int sgr_densify_split_children(int n_out, int n_split, const int32_t* src, const uint8_t* kind, const int32_t* sample_row,
+                               const float* xyz_in, const float* scaling_in, const float* rotation_in,
+                               const float* normals, float* xyz_out, float* scaling_out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_out <= 0) return 0;
+    if (!src || !kind || !sample_row || !xyz_in || !scaling_in || !rotation_in || !xyz_out || !scaling_out)
+        return sgr_set_error(SGR_E_INVALID, "all arrays are required");
+    sgr_densify_children_kernel<<<(n_out + 255) / 256, 256, 0, stream>>>(n_out, n_split, src, kind, sample_row, xyz_in,
+                                                                        scaling_in, rotation_in, normals, xyz_out,
+                                                                        scaling_out);
+    DN_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"
