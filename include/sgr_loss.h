@@ -40,6 +40,29 @@ int sgr_l1_forward(int C, int H, int W, const float* a, const float* b, const ui
 int sgr_l1_backward(int C, int H, int W, const float* a, const float* b, const uint8_t* mask, const float* out,
                     const float* upstream, float* dL_da, void* stream);
 
+/* ---- the accumulation and depth terms of train.py:106-133 ---------------------------------------------------------
+ * Binary-cross-entropy style terms on the accumulated opacity acc [H*W] (clamped to [1e-6, 1-1e-6] first):
+ *   SGR_BCE_SKY     where(mask, -log(1 - acc), -log(acc)).mean()                                   train.py:107-109
+ *   SGR_BCE_OBJECT  where(mask, -(acc log acc + (1-acc) log(1-acc)), -log(1 - acc)).mean()         train.py:118-121
+ * out[0] = the mean.  workspace: sgr_l1_workspace_floats floats. */
+#define SGR_BCE_SKY 0
+#define SGR_BCE_OBJECT 1
+int sgr_bce_forward(int n, int mode, const float* acc, const uint8_t* mask, float* out, float* workspace, void* stream);
+/* dL/dacc = upstream[0] / n * d(term)/dacc, zero where the clamp is active (torch.clamp's backward). */
+int sgr_bce_backward(int n, int mode, const float* acc, const uint8_t* mask, const float* upstream, float* dL_dacc,
+                     void* stream);
+
+/* LiDAR depth term (train.py:124-131): over the pixels with lidar_depth > 0 and mask, the error
+ * |depth / (acc + 1e-10) - lidar_depth|; the mean of its int(keep * count) SMALLEST values (keep = 0.95: the largest 5 %
+ * are dropped).  The k-th smallest error is found with a 4-pass radix select on the float bits (no sort, no host
+ * sync).  out[0] = loss, out[1] = k, out[2] = threshold error, out[3] = weight of the errors equal to the threshold
+ * (their share of the remaining slots).  work: sgr_lidar_work_bytes(n) bytes (keeps the per-pixel errors for the backward). */
+size_t sgr_lidar_work_bytes(int n);
+int sgr_lidar_depth_forward(int n, const float* depth, const float* acc, const float* lidar_depth, const uint8_t* mask,
+                            float keep, float* out, char* work, void* stream);
+int sgr_lidar_depth_backward(int n, const float* depth, const float* acc, const float* lidar_depth, const float* out,
+                             const char* work, const float* upstream, float* dL_ddepth, float* dL_dacc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,7 +24,8 @@ SYMBOLS = [
     "sgr_test_wave_sum", "sgr_profile_enable", "sgr_profile_read", "sgr_masked_color_grad",
     "sgr_sh_grad_from_views", "sgr_scene_compose_forward", "sgr_scene_compose_backward",
     "sgr_scene_densification_stats", "sgr_ssim_workspace_floats", "sgr_ssim_forward", "sgr_ssim_backward",
-    "sgr_l1_workspace_floats", "sgr_l1_forward", "sgr_l1_backward", "sgr_densify_work_bytes", "sgr_densify_plan",
+    "sgr_l1_workspace_floats", "sgr_l1_forward", "sgr_l1_backward", "sgr_bce_forward", "sgr_bce_backward",
+    "sgr_lidar_work_bytes", "sgr_lidar_depth_forward", "sgr_lidar_depth_backward", "sgr_densify_work_bytes", "sgr_densify_plan",
     "sgr_densify_map", "sgr_densify_gather", "sgr_densify_split_children",
 ]
 
@@ -82,6 +83,16 @@ def lib():
         L.sgr_l1_forward.argtypes = [i, i, i, vp, vp, vp, vp, vp, vp]
         L.sgr_l1_backward.restype = i
         L.sgr_l1_backward.argtypes = [i, i, i, vp, vp, vp, vp, vp, vp, vp]
+        L.sgr_bce_forward.restype = i
+        L.sgr_bce_forward.argtypes = [i, i, vp, vp, vp, vp, vp]
+        L.sgr_bce_backward.restype = i
+        L.sgr_bce_backward.argtypes = [i, i, vp, vp, vp, vp, vp]
+        L.sgr_lidar_work_bytes.restype = C.c_size_t
+        L.sgr_lidar_work_bytes.argtypes = [i]
+        L.sgr_lidar_depth_forward.restype = i
+        L.sgr_lidar_depth_forward.argtypes = [i, vp, vp, vp, vp, f, vp, vp, vp]
+        L.sgr_lidar_depth_backward.restype = i
+        L.sgr_lidar_depth_backward.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.sgr_densify_work_bytes.restype = C.c_size_t
         L.sgr_densify_work_bytes.argtypes = [i]
         L.sgr_densify_plan.restype = i

@@ -203,6 +203,167 @@ sgr_l1_bwd_kernel(int C, size_t plane, const float* __restrict__ a, const float*
     da[i] = g;
 }
 
+// ---- accumulation terms (train.py:106-121) --------------------------------------------------------------------------
+__device__ __forceinline__ float bce_term(int mode, float a, bool m) {
+    if (mode == SGR_BCE_SKY) return m ? -logf(1.0f - a) : -logf(a);
+    return m ? -(a * logf(a) + (1.0f - a) * logf(1.0f - a)) : -logf(1.0f - a);
+}
+__global__ void __launch_bounds__(256)
+sgr_bce_fwd_kernel(int n, int mode, const float* __restrict__ acc, const uint8_t* __restrict__ mask,
+                   float* __restrict__ sums) {
+    __shared__ float lds4[4];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n; i += (size_t)gridDim.x * 256) {
+        const float a = fminf(fmaxf(acc[i], 1e-6f), 1.0f - 1e-6f);  // torch.clamp(acc, min=1e-6, max=1.-1e-6)
+        s += bce_term(mode, a, mask && mask[i]);
+    }
+    const float t = block_sum_256(s, lds4);
+    if (threadIdx.x == 0) sums[blockIdx.x] = t;
+}
+__global__ void __launch_bounds__(256)
+sgr_bce_bwd_kernel(int n, int mode, const float* __restrict__ acc, const uint8_t* __restrict__ mask,
+                   const float* __restrict__ upstream, float* __restrict__ dacc) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)n) return;
+    const float x = acc[i];
+    float g = 0.f;
+    if (x >= 1e-6f && x <= 1.0f - 1e-6f) {  // clamp passes the gradient on [min, max]
+        const bool m = mask && mask[i];
+        if (mode == SGR_BCE_SKY) g = m ? 1.0f / (1.0f - x) : -1.0f / x;
+        else g = m ? (logf(1.0f - x) - logf(x)) : 1.0f / (1.0f - x);
+        g *= upstream[0] / (float)n;
+    }
+    dacc[i] = g;
+}
+
+// ---- LiDAR depth term with top-95 % selection (train.py:124-131) ---------------------------------------------------
+struct LdWork {
+    uint32_t* key;    // [n] float bits of the error (>= 0, so unsigned order == float order); 0xffffffff = not selected
+    uint32_t* hist;   // [4][256]
+    uint32_t* state;  // [0] count  [1] k  [2] prefix  [3] k remaining  [4] count below threshold  [5] ties
+    float* sums;      // [SGR_L1_BLOCKS]
+};
+#define SGR_L1_BLOCKS_ 1024
+static LdWork ld_carve(char* base, size_t n) {
+    LdWork w;
+    char* p = base;
+    sgr_carve(p, w.key, n ? n : 1);
+    sgr_carve(p, w.hist, 4 * 256);
+    sgr_carve(p, w.state, 16);
+    sgr_carve(p, w.sums, SGR_L1_BLOCKS_);
+    return w;
+}
+__global__ void __launch_bounds__(256)
+sgr_lidar_err_kernel(int n, const float* __restrict__ depth, const float* __restrict__ acc, const float* __restrict__ lidar,
+                     const uint8_t* __restrict__ mask, LdWork w) {
+    __shared__ uint32_t cnt[4];
+    uint32_t c = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n; i += (size_t)gridDim.x * 256) {
+        const float l = lidar[i];
+        uint32_t key = 0xffffffffu;
+        if (l > 0.f && (!mask || mask[i])) {  // depth_mask = (lidar_depth > 0) & mask
+            const float e = fabsf(depth[i] / (acc[i] + 1e-10f) - l);
+            key = (e == e) ? __float_as_uint(e) : 0x7fc00000u;  // NaN sorts last among the selected, like topk
+            c++;
+        }
+        w.key[i] = key;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+    if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&w.state[0], cnt[0] + cnt[1] + cnt[2] + cnt[3]);  // integers: order-independent
+}
+__global__ void sgr_lidar_k_kernel(LdWork w, float keep) {
+    const uint32_t count = w.state[0];
+    const uint32_t k = (uint32_t)((double)keep * (double)count);  // int(0.95 * depth_error.size(0))
+    w.state[1] = k;
+    w.state[2] = 0;  // prefix
+    w.state[3] = k;  // we look for the k-th smallest (1-based) -> rank k inside the current prefix class
+}
+// histogram of byte `pass` (3 = most significant) over the selected keys whose higher bytes equal the prefix
+__global__ void __launch_bounds__(256)
+sgr_lidar_hist_kernel(int n, int pass, LdWork w) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t prefix = w.state[2];
+    const int shift = 8 * pass;
+    const uint32_t himask = pass == 3 ? 0u : (0xffffffffu << (shift + 8));
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n; i += (size_t)gridDim.x * 256) {
+        const uint32_t key = w.key[i];
+        if (key != 0xffffffffu && (key & himask) == prefix) atomicAdd(&h[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&w.hist[pass * 256 + threadIdx.x], h[threadIdx.x]);
+}
+__global__ void sgr_lidar_select_kernel(int pass, LdWork w) {  // one lane
+    uint32_t k = w.state[3], acc = 0;
+    if (w.state[1] == 0) return;
+    int b = 0;
+    for (; b < 256; b++) {
+        const uint32_t c = w.hist[pass * 256 + b];
+        if (acc + c >= k) break;
+        acc += c;
+    }
+    if (b > 255) b = 255;
+    w.state[2] |= (uint32_t)b << (8 * pass);
+    w.state[3] = k - acc;  // rank inside the chosen bin; after the last pass: how many of the tied errors are taken
+    if (pass == 0) {
+        w.state[5] = w.hist[b];                 // errors equal to the threshold
+        w.state[4] = w.state[1] - w.state[3];   // errors strictly below it
+    }
+}
+__global__ void __launch_bounds__(256)
+sgr_lidar_sum_kernel(int n, LdWork w) {
+    __shared__ float lds4[4];
+    const uint32_t t = w.state[2];
+    float s = 0.f;
+    if (w.state[1] > 0)
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n; i += (size_t)gridDim.x * 256) {
+            const uint32_t key = w.key[i];
+            if (key < t) s += __uint_as_float(key);
+        }
+    const float r = block_sum_256(s, lds4);
+    if (threadIdx.x == 0) w.sums[blockIdx.x] = r;
+}
+__global__ void __launch_bounds__(256)
+sgr_lidar_final_kernel(LdWork w, float* __restrict__ out) {
+    __shared__ float lds4[4];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < SGR_L1_BLOCKS_; i += 256) a += w.sums[i];
+    const float below = block_sum_256(a, lds4);
+    if (threadIdx.x == 0) {
+        const uint32_t k = w.state[1];
+        const float thr = __uint_as_float(w.state[2]);
+        const uint32_t take = w.state[3];  // how many of the tied errors belong to the k smallest
+        out[0] = k ? (below + (float)take * thr) / (float)k : __builtin_nanf("");  // mean of an empty tensor is NaN
+        out[1] = (float)k;
+        out[2] = thr;
+        out[3] = (k && w.state[5]) ? (float)take / (float)w.state[5] : 0.f;
+    }
+}
+__global__ void __launch_bounds__(256)
+sgr_lidar_bwd_kernel(int n, const float* __restrict__ depth, const float* __restrict__ acc, const float* __restrict__ lidar,
+                     const float* __restrict__ out, LdWork w, const float* __restrict__ upstream,
+                     float* __restrict__ ddepth, float* __restrict__ dacc) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)n) return;
+    const uint32_t key = w.key[i], t = __float_as_uint(out[2]);
+    float wgt = 0.f;
+    if (out[1] > 0.f && key != 0xffffffffu) wgt = key < t ? 1.0f : (key == t ? out[3] : 0.f);
+    float gd = 0.f, ga = 0.f;
+    if (wgt > 0.f) {
+        const float den = acc[i] + 1e-10f, diff = depth[i] / den - lidar[i];
+        const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+        const float g = upstream[0] * wgt * sgn / out[1];
+        gd = g / den;
+        ga = -g * depth[i] / (den * den);
+    }
+    ddepth[i] = gd;
+    dacc[i] = ga;
+}
+
 #define LS_HIP(call)                                                                                       \
     do {                                                                                                   \
         hipError_t e__ = (call);                                                                           \
@@ -272,6 +433,64 @@ int sgr_l1_backward(int C, int H, int W, const float* a, const float* b, const u
     if (!a || !b || !out || !upstream || !dL_da) return sgr_set_error(SGR_E_INVALID, "a, b, out, upstream and dL_da are required");
     const size_t n = (size_t)C * H * W;
     sgr_l1_bwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(C, (size_t)H * W, a, b, mask, out, upstream, dL_da);
+    LS_HIP(hipGetLastError());
+    return 0;
+}
+
+int sgr_bce_forward(int n, int mode, const float* acc, const uint8_t* mask, float* out, float* workspace, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n <= 0 || (mode != SGR_BCE_SKY && mode != SGR_BCE_OBJECT)) return sgr_set_error(SGR_E_INVALID, "n > 0 and a valid mode are required");
+    if (!acc || !out || !workspace) return sgr_set_error(SGR_E_INVALID, "acc, out and workspace are required");
+    sgr_bce_fwd_kernel<<<SGR_L1_BLOCKS, 256, 0, stream>>>(n, mode, acc, mask, workspace);
+    sgr_final_sum_kernel<<<1, 256, 0, stream>>>(workspace, SGR_L1_BLOCKS, 1.0f / (float)n, nullptr, out, 0);
+    LS_HIP(hipGetLastError());
+    return 0;
+}
+
+int sgr_bce_backward(int n, int mode, const float* acc, const uint8_t* mask, const float* upstream, float* dL_dacc,
+                     void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n <= 0 || (mode != SGR_BCE_SKY && mode != SGR_BCE_OBJECT)) return sgr_set_error(SGR_E_INVALID, "n > 0 and a valid mode are required");
+    if (!acc || !upstream || !dL_dacc) return sgr_set_error(SGR_E_INVALID, "acc, upstream and dL_dacc are required");
+    sgr_bce_bwd_kernel<<<(n + 255) / 256, 256, 0, stream>>>(n, mode, acc, mask, upstream, dL_dacc);
+    LS_HIP(hipGetLastError());
+    return 0;
+}
+
+size_t sgr_lidar_work_bytes(int n) {
+    char* base = (char*)4096;
+    LdWork w = ld_carve(base, (size_t)(n > 0 ? n : 1));
+    return (size_t)((char*)(w.sums + SGR_L1_BLOCKS_) - base) + 512;
+}
+
+int sgr_lidar_depth_forward(int n, const float* depth, const float* acc, const float* lidar_depth, const uint8_t* mask,
+                            float keep, float* out, char* work, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n <= 0) return sgr_set_error(SGR_E_INVALID, "n must be positive");
+    if (!depth || !acc || !lidar_depth || !out || !work) return sgr_set_error(SGR_E_INVALID, "depth, acc, lidar_depth, out and work are required");
+    const LdWork w = ld_carve((char*)sgr_align_up((size_t)work, 256), (size_t)n);
+    LS_HIP(hipMemsetAsync(w.hist, 0, 4 * 256 * sizeof(uint32_t), stream));
+    LS_HIP(hipMemsetAsync(w.state, 0, 16 * sizeof(uint32_t), stream));
+    sgr_lidar_err_kernel<<<SGR_L1_BLOCKS_, 256, 0, stream>>>(n, depth, acc, lidar_depth, mask, w);
+    sgr_lidar_k_kernel<<<1, 1, 0, stream>>>(w, keep);
+    for (int pass = 3; pass >= 0; pass--) {
+        sgr_lidar_hist_kernel<<<SGR_L1_BLOCKS_, 256, 0, stream>>>(n, pass, w);
+        sgr_lidar_select_kernel<<<1, 1, 0, stream>>>(pass, w);
+    }
+    sgr_lidar_sum_kernel<<<SGR_L1_BLOCKS_, 256, 0, stream>>>(n, w);
+    sgr_lidar_final_kernel<<<1, 256, 0, stream>>>(w, out);
+    LS_HIP(hipGetLastError());
+    return 0;
+}
+
+int sgr_lidar_depth_backward(int n, const float* depth, const float* acc, const float* lidar_depth, const float* out,
+                             const char* work, const float* upstream, float* dL_ddepth, float* dL_dacc, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n <= 0) return sgr_set_error(SGR_E_INVALID, "n must be positive");
+    if (!depth || !acc || !lidar_depth || !out || !work || !upstream || !dL_ddepth || !dL_dacc)
+        return sgr_set_error(SGR_E_INVALID, "all arrays are required");
+    const LdWork w = ld_carve((char*)sgr_align_up((size_t)const_cast<char*>(work), 256), (size_t)n);
+    sgr_lidar_bwd_kernel<<<(n + 255) / 256, 256, 0, stream>>>(n, depth, acc, lidar_depth, out, w, upstream, dL_ddepth, dL_dacc);
     LS_HIP(hipGetLastError());
     return 0;
 }

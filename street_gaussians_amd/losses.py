@@ -102,6 +102,91 @@ class _L1(torch.autograd.Function):
         return grad, None, None
 
 
+class _BCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, acc, mask, mode):
+        L = _native.lib()
+        dev, n = acc.device, acc.numel()
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        ws = torch.empty(L.sgr_l1_workspace_floats(1, 1, 1), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(L.sgr_bce_forward(n, mode, _p(acc), _p(mask), _p(out), _p(ws), _stream(dev)))
+        ctx.save_for_backward(acc, mask)
+        ctx.mode = mode
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, upstream):
+        acc, mask = ctx.saved_tensors
+        dev = acc.device
+        up = upstream.reshape(1).to(torch.float32).contiguous()
+        grad = torch.empty_like(acc)
+        with torch.cuda.device(dev):
+            check(_native.lib().sgr_bce_backward(acc.numel(), ctx.mode, _p(acc), _p(mask), _p(up), _p(grad), _stream(dev)))
+        return grad, None, None
+
+
+class _Lidar(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, acc, lidar, mask, keep):
+        L = _native.lib()
+        dev, n = depth.device, depth.numel()
+        out = torch.empty(4, dtype=torch.float32, device=dev)
+        work = torch.empty(L.sgr_lidar_work_bytes(n), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            check(L.sgr_lidar_depth_forward(n, _p(depth), _p(acc), _p(lidar), _p(mask), float(keep), _p(out), _p(work),
+                                            _stream(dev)))
+        ctx.save_for_backward(depth, acc, lidar, out, work)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, upstream):
+        depth, acc, lidar, out, work = ctx.saved_tensors
+        dev = depth.device
+        up = upstream.reshape(1).to(torch.float32).contiguous()
+        gd, ga = torch.empty_like(depth), torch.empty_like(acc)
+        with torch.cuda.device(dev):
+            check(_native.lib().sgr_lidar_depth_backward(depth.numel(), _p(depth), _p(acc), _p(lidar), _p(out), _p(work),
+                                                         _p(up), _p(gd), _p(ga), _stream(dev)))
+        return gd, ga, None, None, None
+
+
+def _flat(t, name, like=None):
+    if not t.is_cuda:
+        raise SgrError(f"{name} must be a HIP (cuda) tensor: there is no CPU path")
+    if like is not None and t.numel() != like.numel():
+        raise RuntimeError(f"{name} must have as many elements as the rendered map")
+    return t.to(torch.float32).contiguous()
+
+
+def _flat_mask(m, like):
+    if m is None:
+        return None
+    if m.numel() != like.numel():
+        raise RuntimeError("mask must have as many elements as the rendered map")
+    return m.to(torch.uint8).contiguous()
+
+
+def sky_loss(acc: torch.Tensor, sky_mask: torch.Tensor) -> torch.Tensor:
+    """train.py:107-109: clamp(acc, 1e-6, 1-1e-6), then mean of -log(1-acc) on sky pixels and -log(acc) elsewhere."""
+    a = _flat(acc, "acc")
+    return _BCE.apply(a, _flat_mask(sky_mask, a), 0)
+
+
+def obj_acc_loss(acc_obj: torch.Tensor, obj_bound: torch.Tensor) -> torch.Tensor:
+    """train.py:116-121: entropy of the clamped object accumulation inside the boxes, -log(1-acc) outside, mean."""
+    a = _flat(acc_obj, "acc_obj")
+    return _BCE.apply(a, _flat_mask(obj_bound, a), 1)
+
+
+def lidar_depth_loss(depth: torch.Tensor, acc: torch.Tensor, lidar_depth: torch.Tensor, mask: Optional[torch.Tensor] = None,
+                     keep: float = 0.95) -> torch.Tensor:
+    """train.py:124-131: mean of the int(keep * n) smallest |depth / (acc + 1e-10) - lidar_depth| over the n pixels
+    with lidar_depth > 0 and mask.  Gradients flow to depth and acc."""
+    d = _flat(depth, "depth")
+    return _Lidar.apply(d, _flat(acc, "acc", d), _flat(lidar_depth, "lidar_depth", d).detach(), _flat_mask(mask, d), keep)
+
+
 def l1_loss(network_output: torch.Tensor, gt: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """loss_utils.py:21-37: mean |network_output - gt| over the C values of the pixels selected by mask (1, H, W)."""
     a, b = _prep(network_output, "network_output"), _prep(gt, "gt")

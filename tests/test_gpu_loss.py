@@ -38,6 +38,45 @@ def test_l1_and_ssim_match_reference(C, H, W, masked):
     assert torch.equal(ag2.grad, ag.grad)
 
 
+@pytest.mark.parametrize("H,W,seed", [(64, 96, 0), (131, 77, 1), (320, 480, 2)])
+def test_accumulation_and_lidar_terms_match_reference(H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    acc = torch.rand(1, H, W, generator=g)
+    acc[0, :2] = 0.0          # clamp active (lower) -> zero gradient
+    acc[0, 2:4] = 1.0         # clamp active (upper)
+    sky = torch.rand(1, H, W, generator=g) < 0.3
+    depth = torch.rand(1, H, W, generator=g) * 40
+    lidar = torch.where(torch.rand(1, H, W, generator=g) < 0.4, torch.rand(1, H, W, generator=g) * 60, torch.zeros(1, H, W))
+    mask = torch.rand(1, H, W, generator=g) < 0.9
+    # float32 like the reference runs it: the clamp bound 1 - 1e-6 is not representable, and -log(1 - acc) at the
+    # bound (13.80 in float32, 13.82 in float64) is part of what the reference computes
+    a64, d64 = acc.clone().requires_grad_(True), depth.clone().requires_grad_(True)
+    rs, ro = ref.sky_loss(a64, sky), ref.obj_acc_loss(a64, sky)
+    rl = ref.lidar_depth_loss(d64, a64.clamp(min=0.05), lidar, mask)
+    (rs + 0.5 * ro + 0.1 * rl).backward()
+    ag, dg = acc.cuda().requires_grad_(True), depth.cuda().requires_grad_(True)
+    s, o = losses.sky_loss(ag, sky.cuda()), losses.obj_acc_loss(ag, sky.cuda())
+    l = losses.lidar_depth_loss(dg, ag.clamp(min=0.05), lidar.cuda(), mask.cuda())
+    (s + 0.5 * o + 0.1 * l).backward()
+    for got, want in ((s, rs), (o, ro), (l, rl)):
+        assert abs(got.item() - want.item()) <= 5e-6 * abs(want.item()), (got.item(), want.item())
+    for got, want in ((ag.grad, a64.grad), (dg.grad, d64.grad)):
+        scale = float(want.abs().max())
+        assert float((got.cpu() - want).abs().max()) <= 3e-5 * scale
+    assert float(ag.grad[0, :2].abs().max()) == 0.0  # acc = 0: both clamps are active
+
+
+def test_lidar_selection_edge_cases():
+    # no valid pixel -> mean of an empty tensor is NaN (torch); all errors equal -> ties share the slots
+    z = torch.zeros(1, 8, 8, device="cuda")
+    assert torch.isnan(losses.lidar_depth_loss(z + 1, z + 1, z, None))
+    d = (z + 3.0).requires_grad_(True)
+    l = losses.lidar_depth_loss(d, z + 1, z + 1, None)      # every error is exactly 2
+    assert l.item() == pytest.approx(2.0)
+    l.backward()
+    assert float(d.grad.sum()) == pytest.approx(1.0, rel=1e-5)  # d(mean)/d(errors) sums to one whichever ties are kept
+
+
 def test_loss_argument_checks():
     from street_gaussians_amd._native import SgrError
     x = torch.rand(3, 8, 8, device="cuda")

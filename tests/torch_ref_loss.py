@@ -51,3 +51,25 @@ def ssim(img1, img2, window_size=WINDOW, size_average=True, mask=None):
     c1, c2 = K1 ** 2, K2 ** 2
     smap = ((2 * m1m2 + c1) * (2 * cov + c2)) / ((m1m1 + m2m2 + c1) * (v1 + v2 + c2))
     return smap.mean() if size_average else smap.mean(1).mean(1).mean(1)
+
+
+def sky_loss(acc, sky_mask):
+    """train.py:107-109 (before the optional per-camera scale)."""
+    a = torch.clamp(acc, min=1e-6, max=1. - 1e-6)
+    return torch.where(sky_mask, -torch.log(1 - a), -torch.log(a)).mean()
+
+
+def obj_acc_loss(acc_obj, obj_bound):
+    """train.py:116-121."""
+    a = torch.clamp(acc_obj, min=1e-6, max=1. - 1e-6)
+    inside = -(a * torch.log(a) + (1. - a) * torch.log(1. - a))
+    return torch.where(obj_bound, inside, -torch.log(1. - a)).mean()
+
+
+def lidar_depth_loss(depth, acc, lidar_depth, mask, keep=0.95):
+    """train.py:124-131."""
+    valid = torch.logical_and(lidar_depth > 0., mask)
+    expected = depth / (acc + 1e-10)
+    err = torch.abs(expected[valid] - lidar_depth[valid])
+    err, _ = torch.topk(err, int(keep * err.size(0)), largest=False)
+    return err.mean()
