@@ -21,6 +21,8 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                      int gx, int gy, const float4* __restrict__ rec, const float* __restrict__ semantics,
                      const float* __restrict__ bg_color, float* __restrict__ out_color, float* __restrict__ out_depth,
                      float* __restrict__ out_alpha, float* __restrict__ out_semantic, uint32_t* __restrict__ n_contrib) {
+    // fused multiply-adds are written out (fmaf): the CULL / !CULL instantiations must produce bit-identical images
+#pragma clang fp contract(off)
     __shared__ float4 sA[SGR_TILE_THREADS];  // {x, y, -, -}
     __shared__ float4 sB[SGR_TILE_THREADS];  // {qa, qb, qc, opacity}
     __shared__ float4 sC[SGR_TILE_THREADS];  // {r, g, b, depth}
