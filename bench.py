@@ -66,33 +66,44 @@ def parse():
 
 
 def cpu_baseline(args, cam, sc):
-    """Times the oracle (port of the reference algorithm) on a bounded sample: the same scene and camera but
-    only the central 1/16 of the image (480x320 window at the same focal length), so depth complexity per pixel
-    is the workload's.  Preprocess still visits all P Gaussians, like the reference would."""
+    """Times the oracle (port of the reference algorithm; the reference has no CPU path) with OpenMP on the host's
+    cores, on a bounded sample of the SAME workload: first the central 1/16 window of the image (same focal length, so
+    the depth complexity per pixel is the workload's; preprocess still visits all P Gaussians), and -- when that
+    predicts at most ~30 s -- the full frame, which is then what is reported."""
     from oracle import oracle
-    Ws, Hs = max(16, args.width // 4), max(16, args.height // 4)
-    fx = args.width / (2.0 * cam.tanfovx)
-    cams = syn.make_camera(Ws, Hs, fx=fx)
-    w = syn.loss_weights(cams, S=0)
-    kw = dict(means3D=sc.means3D, opacities=sc.opacities, viewmatrix=cams.viewmatrix, projmatrix=cams.projmatrix,
-              campos=cams.campos, bg=torch.zeros(3), tanfovx=cams.tanfovx, tanfovy=cams.tanfovy, image_height=Hs,
-              image_width=Ws, sh_degree=3, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
-    best = None
-    for _ in range(2):
-        t0 = time.time()
-        fw = oracle.forward(internals=False, **kw)
-        oracle.backward(fw, w["color"], w["depth"], w["alpha"], None, parallel=True)
-        dt = time.time() - t0
-        R = fw.num_rendered
-        fw.free()
-        best = dt if best is None else min(best, dt)
-        if dt > 20:
-            break
+
+    def run(Ws, Hs, c, reps):
+        w = syn.loss_weights(c, S=0)
+        kw = dict(means3D=sc.means3D, opacities=sc.opacities, viewmatrix=c.viewmatrix, projmatrix=c.projmatrix,
+                  campos=c.campos, bg=torch.zeros(3), tanfovx=c.tanfovx, tanfovy=c.tanfovy, image_height=Hs,
+                  image_width=Ws, sh_degree=3, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+        best, R = None, 0
+        for _ in range(reps):
+            t0 = time.time()
+            fw = oracle.forward(internals=False, **kw)
+            oracle.backward(fw, w["color"], w["depth"], w["alpha"], None, parallel=True)
+            dt = time.time() - t0
+            R = fw.num_rendered
+            fw.free()
+            best = dt if best is None else min(best, dt)
+            if dt > 20:
+                break
+        return best, R
+
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    return {"value": round(1.0 / best, 4), "unit": "iters/s on the sample", "cores": cores, "kind": "port",
+    Ws, Hs = max(16, args.width // 4), max(16, args.height // 4)
+    small = syn.make_camera(Ws, Hs, fx=args.width / (2.0 * cam.tanfovx))
+    t_small, R_small = run(Ws, Hs, small, 2)
+    if 16.0 * t_small <= 30.0:  # the whole frame fits the budget: report the real thing
+        t_full, R_full = run(args.width, args.height, cam, 2)
+        return {"value": round(1.0 / t_full, 4), "unit": "iters/s", "cores": cores, "kind": "port",
+                "sample": f"oracle fwd+bwd (OpenMP), the full workload: all {sc.P} Gaussians, {args.width}x{args.height} "
+                          f"(R={R_full}), best of 2", "seconds": round(t_full, 3),
+                "window_1_16_seconds": round(t_small, 3)}
+    return {"value": round(1.0 / t_small, 4), "unit": "iters/s on the sample", "cores": cores, "kind": "port",
             "sample": f"oracle fwd+bwd (OpenMP), all {sc.P} Gaussians, central {Ws}x{Hs} window = 1/16 of the "
-                      f"{args.width}x{args.height} pixels (R={R}); full-frame rate ~ value/16",
-            "seconds": round(best, 3)}
+                      f"{args.width}x{args.height} pixels (R={R_small}); full-frame rate ~ value/16",
+            "seconds": round(t_small, 3)}
 
 
 def reference_kernels_on_gpu(args, cam, sc):
