@@ -304,7 +304,7 @@ def main():
                            " (dense 44 B/Gaussian; SH gradient rebuilt from an all-gather of per-view dRGB, 12 B/Gaussian/view)"
                            if args.reduce == "factored" else " (one 236 B/Gaussian bucket)")) if world > 1 else ""),
                        "exchange_bytes_per_rank": reducer.nbytes if reducer is not None else 0},
-            "roofline": {"bound": "hbm", "kernel": "sgr_blend_bwd_kernel",
+            "roofline": {"bound": "hbm", "kernel": "sgr_blend_bwd_kernel_s0" if S == 0 else "sgr_blend_bwd_kernel",
                          "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes,
