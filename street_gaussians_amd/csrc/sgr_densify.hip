@@ -108,14 +108,27 @@ sgr_densify_map_kernel(int N, int n_split, DnWork w, int32_t* __restrict__ src, 
     }
 }
 
+// One workgroup builds 128 consecutive result rows: their source rows / kinds are staged in LDS once, then one lane per
+// float walks the 128 * width outputs (coalesced stores, row-wise contiguous loads, 32-bit index arithmetic).
+#define SGR_DN_ROWS 128
 __global__ void __launch_bounds__(256)
-sgr_densify_gather_kernel(size_t total, int width, const float* __restrict__ in, const int32_t* __restrict__ src,
+sgr_densify_gather_kernel(int n_out, int width, const float* __restrict__ in, const int32_t* __restrict__ src,
                           const uint8_t* __restrict__ kind, int zero_new, float* __restrict__ out) {
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;  // one lane per float: coalesced writes, row-wise reads
-    if (e >= total) return;
-    const size_t r = e / (size_t)width;
-    const int j = (int)(e - r * (size_t)width);
-    out[e] = (zero_new && kind[r] != SGR_KIND_KEEP) ? 0.0f : in[(size_t)src[r] * width + j];
+    __shared__ int32_t sSrc[SGR_DN_ROWS];
+    __shared__ uint8_t sKind[SGR_DN_ROWS];
+    const int r0 = blockIdx.x * SGR_DN_ROWS;
+    const int rows = min(SGR_DN_ROWS, n_out - r0);
+    if ((int)threadIdx.x < rows) {
+        sSrc[threadIdx.x] = src[r0 + threadIdx.x];
+        sKind[threadIdx.x] = kind[r0 + threadIdx.x];
+    }
+    __syncthreads();
+    float* o = out + (size_t)r0 * width;
+    const uint32_t total = (uint32_t)rows * (uint32_t)width, w = (uint32_t)width;
+    for (uint32_t e = threadIdx.x; e < total; e += 256) {
+        const uint32_t r = e / w, j = e - r * w;
+        o[e] = (zero_new && sKind[r] != SGR_KIND_KEEP) ? 0.0f : in[(size_t)sSrc[r] * w + j];
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -194,8 +207,8 @@ int sgr_densify_gather(int n_out, int width, const float* in, const int32_t* src
     hipStream_t stream = (hipStream_t)stream_;
     if (n_out <= 0 || width <= 0) return 0;
     if (!in || !src || !kind || !out) return sgr_set_error(SGR_E_INVALID, "in, src, kind and out are required");
-    const size_t total = (size_t)n_out * width;
-    sgr_densify_gather_kernel<<<(unsigned)((total + 255) / 256), 256, 0, stream>>>(total, width, in, src, kind, zero_new, out);
+    sgr_densify_gather_kernel<<<(unsigned)((n_out + SGR_DN_ROWS - 1) / SGR_DN_ROWS), 256, 0, stream>>>(n_out, width, in, src,
+                                                                                                   kind, zero_new, out);
     DN_HIP(hipGetLastError());
     return 0;
 }
