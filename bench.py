@@ -272,13 +272,19 @@ def main():
         achieved = algo_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms else None
         fwd_ms = stage_ms["blend_fwd"]
         fwd_bytes = (44 + 4 * S) * R + (24 + 4 * S) * N
-        traffic = None
+        traffic, valu = None, None
         tfile = os.path.join(ROOT, "profiles", "pmc_blend_bwd.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
                 if tj.get("gaussians") == args.gaussians and tj.get("width") == args.width:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    if tj.get("sq_insts_valu") and bwd_ms:
+                        # what actually bounds the kernel: VALU wave-instructions (rocprofv3 SQ_INSTS_VALU) against
+                        # the issue slots of 256 CUs x 4 SIMDs (one wave64 VALU instruction = 2 cycles) at 2.4 GHz
+                        slots = 1024 * (bwd_ms * 1e-3) * 2.4e9 / 2.0
+                        valu = {"insts_per_launch": int(tj["sq_insts_valu"]), "issue_slot_frac": round(tj["sq_insts_valu"] / slots, 3),
+                                "source": "profiles/pmc_blend_bwd.json (SQ_INSTS_VALU) / live kernel_ms"}
             except Exception:
                 traffic = None
         line = {
@@ -306,7 +312,7 @@ def main():
                        "exchange_bytes_per_rank": reducer.nbytes if reducer is not None else 0},
             "roofline": {"bound": "hbm", "kernel": "sgr_blend_bwd_kernel_s0" if S == 0 else "sgr_blend_bwd_kernel",
                          "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": traffic, "valu": valu,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "kernel_ms": round(bwd_ms, 4) if bwd_ms else None,
                          "blend_fwd": {"kernel_ms": round(fwd_ms, 4) if fwd_ms else None,
