@@ -173,6 +173,8 @@ class _Compose(torch.autograd.Function):
                 len(segs), arr, garr, M, S, *[_ptr(t) if t is not None and t.numel() else None for t in ins], grow.cb,
                 None, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         del keep
+        # kernels work in float32; hand autograd the dtype of each input
+        grads = [g if g is None or g.dtype == t.dtype else g.to(t.dtype) for g, t in zip(grads, tensors)]
         return (None, None, None) + tuple(grads)
 
 
