@@ -4,15 +4,16 @@
 //
 // MI355X design -- no global atomics at all:
 //   * same quadrant-per-wave / LDS-staged / ballot-culled walk as the forward kernel, back to front;
-//   * the 11+S per-pair gradient terms are summed across the 64 pixels of a wave with DPP
-//     (quad_perm, row_half_mirror, row_mirror, row_bcast15/31: six v_add_f32_dpp per value),
-//     then the (up to four) wave partials of an instance are combined with ds_add_f32 in LDS;
+//   * the 11+S per-pair gradient terms are summed across the 64 pixels of a wave with a REDUCE-SCATTER
+//     (v_permlane32_swap / v_permlane16_swap fold two values into one register per cross-half step, then four
+//     v_add_f32_dpp row steps on a quarter of the registers: 30 instructions for 12 values), and the (up to four)
+//     wave partials of an instance meet in LDS with ds_add_f32 on two zero-initialised rows (deterministic);
 //   * each (tile, instance) partial row is written ONCE to `partials[u]`, where u is the instance's
 //     index in Gaussian-major order (u = exclusive tile offset of the Gaussian + index of this tile
 //     inside its rect).  Rows of one Gaussian are therefore contiguous, and the per-Gaussian kernel
 //     (sgr_gauss_bwd.hip) reduces them in a fixed order: gradients are bit-reproducible run to run,
 //     unlike the reference's unordered atomics.
-// Row layout (stride = 16 or 32 floats, 64-B aligned): [0..2] dL/dmean2D (x, y, |x|+|y|),
+// Row layout (stride = 16, 32 or 48 floats, 64-B aligned): [0..2] dL/dmean2D (x, y, |x|+|y|),
 // [3..5] dL/dconic (x, y, w), [6] dL/dopacity, [7..9] dL/drgb, [10] dL/ddepth, [11..11+S) dL/dsemantic.
 #include "sgr_math.h"
 
