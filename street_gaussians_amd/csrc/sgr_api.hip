@@ -109,14 +109,16 @@ int sgr_set_error(int code, const std::string& msg) { return fail(code, msg); } 
 // per-thread pinned landing zone for the forward's one device->host readback
 static uint32_t* pinned_pair() {
     static thread_local uint32_t* p = nullptr;
-    if (!p && hipHostMalloc((void**)&p, 64, hipHostMallocDefault) != hipSuccess) p = nullptr;
+    if (!p && hipHostMalloc((void**)&p, 64, hipHostMallocPortable) != hipSuccess) p = nullptr;
     return p;
 }
 // ... and the event that marks "the readback has landed" while later kernels are already queued behind it
 static hipEvent_t readback_event() {
-    static thread_local hipEvent_t ev = nullptr;
-    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
-    return ev;
+    static thread_local hipEvent_t ev[64] = {};  // events belong to a device: one per (thread, device)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!ev[dev] && hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming) != hipSuccess) ev[dev] = nullptr;
+    return ev[dev];
 }
 
 // rasterizer_impl.cu:35-50

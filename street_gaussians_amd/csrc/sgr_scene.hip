@@ -403,7 +403,11 @@ struct SgrPinnedStage {
     bool pending = false;
 };
 static int stage_get(size_t bytes, SgrPinnedStage** out) {
-    static thread_local SgrPinnedStage st;
+    static thread_local SgrPinnedStage stages[64];  // the guarding event belongs to a device: one stage per (thread, device)
+    int dev = 0;
+    SC_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return sgr_set_error(SGR_E_INVALID, "device index out of range");
+    SgrPinnedStage& st = stages[dev];
     if (st.pending) {
         SC_HIP(hipEventSynchronize(st.ev));
         st.pending = false;
@@ -413,7 +417,7 @@ static int stage_get(size_t bytes, SgrPinnedStage** out) {
         st.p = nullptr;
         st.cap = 0;
         const size_t want = sgr_align_up(bytes + bytes / 2 + 4096, 4096);
-        SC_HIP(hipHostMalloc((void**)&st.p, want, hipHostMallocDefault));
+        SC_HIP(hipHostMalloc((void**)&st.p, want, hipHostMallocPortable));
         st.cap = want;
     }
     if (!st.ev) SC_HIP(hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
