@@ -34,14 +34,12 @@ int sgr_launch_sort_pairs(uint64_t* const keys[2], uint32_t* const vals[2], uint
                           uint32_t* scan_tmp, hipStream_t s);
 void sgr_launch_blend_fwd(bool cull, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W, int H,
                           int S, const float4* rec, const float* semantics, const float* bg, float* out_color,
-                          float* out_depth, float* out_alpha, float* out_semantic, uint32_t* n_contrib,
-                          const uint32_t* order, uint32_t* tile_work, hipStream_t s);
-void sgr_launch_tile_order(int T, const uint2* ranges, const uint32_t* work, uint32_t* order, hipStream_t s);
+                          float* out_depth, float* out_alpha, float* out_semantic, uint32_t* n_contrib, hipStream_t s);
 int sgr_partial_row_stride(int S);
 void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
                           int H, int S, const float* bg, const float4* rec, const float* semantics, const float* alphas,
                           const uint32_t* n_contrib, const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha,
-                          const float* dL_dsem, float* partials, uint8_t* touched, const uint32_t* order, hipStream_t s);
+                          const float* dL_dsem, float* partials, uint8_t* touched, hipStream_t s);
 void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const int* radii, const float* shs,
                           const float* scales, const float* rotations, const float* cov3D_precomp, const SgrCam* cam,
                           const SgrGeomView& gv, const float* partials, int row_stride, const uint8_t* touched,
@@ -302,14 +300,8 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     }
     prof_begin(5, stream);
     const bool cull = !env_flag("SGR_NO_CULL");
-    // Heaviest-tiles-first launch order pays for the BACKWARD only (its work per tile, the forward's tile_work, is
-    // exact).  For the forward the only estimate is the list length, which early termination makes a poor proxy:
-    // measured 0.334 ms with it vs 0.321 ms in supertile order (SGR_FWD_LPT=1 keeps the experiment reachable).
-    const bool lpt = env_flag("SGR_FWD_LPT");
-    if (lpt) sgr_launch_tile_order((int)T, iv.ranges, nullptr, iv.order_fwd, stream);
     sgr_launch_blend_fwd(cull, gx, gy, iv.ranges, bv.vals[cur], W, H, S, gv.rec, semantics,
-                         background, out_color, out_depth, out_alpha, out_semantic, iv.n_contrib,
-                         lpt ? iv.order_fwd : nullptr, iv.tile_work, stream);
+                         background, out_color, out_depth, out_alpha, out_semantic, iv.n_contrib, stream);
     SGR_STAGE("blend_fwd");
     prof_end(stream);
     return R;
@@ -356,19 +348,14 @@ int sgr_backward(int P, int D, int M, int R, int S, const float* background, int
     if (R > 0) {
         const SgrBinView bv = sgr_bin_carve(binning_buffer, (size_t)R);
         const int cur = sorted_index(W, H);
-        // stage 6: set-up of the blend backward -- clear the touched flags, and order the tiles heaviest-first by the
-        // list length the forward recorded per tile (a blend launch has only ~5 tiles per resident workgroup slot;
-        // longest-first shortens its ragged end: 1.084 -> 1.044 ms + 8 us for the ordering)
         prof_begin(6, stream);
         SGR_HIP(hipMemsetAsync(touched, 0, (size_t)R, stream));  // rows themselves are never cleared
-        const bool lpt = !env_flag("SGR_NO_LPT");
-        if (lpt) sgr_launch_tile_order((int)T, iv.ranges, iv.tile_work, iv.order_bwd, stream);
         prof_end(stream);
         prof_begin(7, stream);
         const bool cull = !env_flag("SGR_NO_CULL"), dpp = !env_flag("SGR_NO_DPP"), det = !env_flag("SGR_NO_DET");
         sgr_launch_blend_bwd(cull, dpp, det, gx, gy, iv.ranges, bv.vals[cur], W, H, S, background, gv.rec, semantics,
                              alphas, iv.n_contrib, dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, partials, touched,
-                             lpt ? iv.order_bwd : nullptr, stream);
+                             stream);
         SGR_STAGE("blend_bwd");
         prof_end(stream);
     }

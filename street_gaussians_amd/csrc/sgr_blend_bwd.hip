@@ -171,7 +171,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                      const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
                      const float* __restrict__ dL_dpixel_depths, const float* __restrict__ dL_dalphas,
                      const float* __restrict__ dL_dpixel_semantics, float* __restrict__ partials, int row_stride,
-                     uint8_t* __restrict__ touched, const uint32_t* __restrict__ order) {
+                     uint8_t* __restrict__ touched) {
     // Every fused multiply-add below is written out (fmaf / __builtin_elementwise_fma): with contraction left to the
     // optimiser, the CULL / !CULL and DPP / shuffle instantiations of this body can fuse differently and the "culling
     // is invisible, bit for bit" property (tests) would depend on code-generation luck.
@@ -198,13 +198,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t tx, ty;
-    if (order) {  // heaviest tiles first (sgr_tile_order_kernel on the forward's tile_work); grid = gx * gy workgroups
-        const uint32_t t = order[blockIdx.x];
-        ty = t / (uint32_t)gx;
-        tx = t - ty * (uint32_t)gx;
-    } else if (!sgr_xcd_tile(blockIdx.x, (uint32_t)gx, (uint32_t)gy, tx, ty)) {
-        return;  // whole workgroup: padding block
-    }
+    if (!sgr_xcd_tile(blockIdx.x, (uint32_t)gx, (uint32_t)gy, tx, ty)) return;  // whole workgroup: padding block
     const uint32_t tile = ty * (uint32_t)gx + tx;
     const uint32_t px = tx * SGR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
     const uint32_t py = ty * SGR_BLOCK_Y + (wave >> 1) * 8 + (lane >> 3);
@@ -456,10 +450,10 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
         const float *__restrict__ alphas, const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpixels,   \
         const float *__restrict__ dL_dpixel_depths, const float *__restrict__ dL_dalphas,                                  \
         const float *__restrict__ dL_dpixel_semantics, float *__restrict__ partials, int row_stride,                      \
-        uint8_t *__restrict__ touched, const uint32_t *__restrict__ order
+        uint8_t *__restrict__ touched
 #define SGR_BWD_PASS                                                                                                  \
     ranges, point_list, W, H, S, gx, gy, bg_color, rec, semantics, alphas, n_contrib, dL_dpixels, dL_dpixel_depths,    \
-        dL_dalphas, dL_dpixel_semantics, partials, row_stride, touched, order
+        dL_dalphas, dL_dpixel_semantics, partials, row_stride, touched
 template <int SMAX, bool CULL, bool DPP, bool DET>
 __global__ void __launch_bounds__(SGR_TILE_THREADS) sgr_blend_bwd_kernel(SGR_BWD_ARGS) {
     sgr_blend_bwd_body<SMAX, CULL, DPP, DET>(SGR_BWD_PASS);
@@ -478,7 +472,7 @@ static void launch_bwd(bool cull, bool dpp, bool det, unsigned tiles, hipStream_
                        int W, int H, int S, int gx, int gy, const float* bg, const float4* rec, const float* semantics,
                        const float* alphas,
                        const uint32_t* n_contrib, const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha,
-                       const float* dL_dsem, float* partials, int row_stride, uint8_t* touched, const uint32_t* order) {
+                       const float* dL_dsem, float* partials, int row_stride, uint8_t* touched) {
     // the deterministic combine needs 2*256*ACCW floats of LDS: used up to 8 semantic channels (60 KB total)
     constexpr bool kDet = SMAX <= 8;
     if (SMAX > 4) { cull = true; dpp = true; }  // the A/B switches (tests) exist for the small instantiations only
@@ -488,19 +482,19 @@ static void launch_bwd(bool cull, bool dpp, bool det, unsigned tiles, hipStream_
             if (det)                                                                                                 \
                 sgr_blend_bwd_kernel_s0<C, D, true><<<tiles, SGR_TILE_THREADS, 0, s>>>(                               \
                     ranges, point_list, W, H, S, gx, gy, bg, rec, semantics, alphas, n_contrib, dL_dpix, dL_ddepth,    \
-                    dL_dalpha, dL_dsem, partials, row_stride, touched, order);                                               \
+                    dL_dalpha, dL_dsem, partials, row_stride, touched);                                               \
             else                                                                                                     \
                 sgr_blend_bwd_kernel_s0<C, D, false><<<tiles, SGR_TILE_THREADS, 0, s>>>(                              \
                     ranges, point_list, W, H, S, gx, gy, bg, rec, semantics, alphas, n_contrib, dL_dpix, dL_ddepth,    \
-                    dL_dalpha, dL_dsem, partials, row_stride, touched, order);                                               \
+                    dL_dalpha, dL_dsem, partials, row_stride, touched);                                               \
         } else if (kDet && det)                                                                                      \
             sgr_blend_bwd_kernel<SMAX, C, D, kDet><<<tiles, SGR_TILE_THREADS, 0, s>>>(                                \
                 ranges, point_list, W, H, S, gx, gy, bg, rec, semantics, alphas, n_contrib, dL_dpix, dL_ddepth,        \
-                dL_dalpha, dL_dsem, partials, row_stride, touched, order);                                                   \
+                dL_dalpha, dL_dsem, partials, row_stride, touched);                                                   \
         else                                                                                                         \
             sgr_blend_bwd_kernel<SMAX, C, D, false><<<tiles, SGR_TILE_THREADS, 0, s>>>(                               \
                 ranges, point_list, W, H, S, gx, gy, bg, rec, semantics, alphas, n_contrib, dL_dpix, dL_ddepth,        \
-                dL_dalpha, dL_dsem, partials, row_stride, touched, order);                                                   \
+                dL_dalpha, dL_dsem, partials, row_stride, touched);                                                   \
     } while (0)
     if (cull && dpp) SGR_GO(true, true);
     else if constexpr (SMAX <= 4) {
@@ -517,13 +511,12 @@ int sgr_partial_row_stride(int S) { return S <= 4 ? 16 : (S <= 20 ? 32 : 48); }
 void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
                           int H, int S, const float* bg, const float4* rec, const float* semantics, const float* alphas, const uint32_t* n_contrib,
                           const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha, const float* dL_dsem,
-                          float* partials, uint8_t* touched, const uint32_t* order, hipStream_t s) {
+                          float* partials, uint8_t* touched, hipStream_t s) {
     if (gx <= 0 || gy <= 0) return;
-    // heaviest-first order: one workgroup per tile; otherwise the XCD-aware supertile grid incl. padding blocks
-    const unsigned tiles = order ? (unsigned)(gx * gy) : sgr_xcd_grid_blocks(gx, gy);
+    const unsigned tiles = sgr_xcd_grid_blocks(gx, gy);  // supertile-ordered grid incl. padding blocks
     const int stride = sgr_partial_row_stride(S);
 #define SGR_BWD(N) launch_bwd<N>(cull, dpp, det, tiles, s, ranges, point_list, W, H, S, gx, gy, bg, rec, semantics, alphas, \
-                                 n_contrib, dL_dpix, dL_ddepth, dL_dalpha, dL_dsem, partials, stride, touched, order)
+                                 n_contrib, dL_dpix, dL_ddepth, dL_dalpha, dL_dsem, partials, stride, touched)
     if (S == 0) SGR_BWD(0);
     else if (S <= 4) SGR_BWD(4);
     else if (S <= 8) SGR_BWD(8);

@@ -20,8 +20,7 @@ __global__ void __launch_bounds__(SGR_TILE_THREADS)
 sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int S,
                      int gx, int gy, const float4* __restrict__ rec, const float* __restrict__ semantics,
                      const float* __restrict__ bg_color, float* __restrict__ out_color, float* __restrict__ out_depth,
-                     float* __restrict__ out_alpha, float* __restrict__ out_semantic, uint32_t* __restrict__ n_contrib,
-                     const uint32_t* __restrict__ order, uint32_t* __restrict__ tile_work) {
+                     float* __restrict__ out_alpha, float* __restrict__ out_semantic, uint32_t* __restrict__ n_contrib) {
     // fused multiply-adds are written out (fmaf): the CULL / !CULL instantiations must produce bit-identical images
 #pragma clang fp contract(off)
     __shared__ float4 sA[SGR_TILE_THREADS];  // {x, y, -, -}
@@ -33,13 +32,7 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t tx, ty;
-    if (order) {  // heaviest tiles first (sgr_tile_order_kernel); grid = exactly gx * gy workgroups
-        const uint32_t t = order[blockIdx.x];
-        ty = t / (uint32_t)gx;
-        tx = t - ty * (uint32_t)gx;
-    } else if (!sgr_xcd_tile(blockIdx.x, (uint32_t)gx, (uint32_t)gy, tx, ty)) {
-        return;  // whole workgroup: padding block
-    }
+    if (!sgr_xcd_tile(blockIdx.x, (uint32_t)gx, (uint32_t)gy, tx, ty)) return;  // whole workgroup: padding block
     const uint32_t tile = ty * (uint32_t)gx + tx;
     const uint32_t px = tx * SGR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
     const uint32_t py = ty * SGR_BLOCK_Y + (wave >> 1) * 8 + (lane >> 3);
@@ -155,15 +148,6 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
         }
     }
 
-    if (tile_work) {  // list positions this tile's backward will walk = max n_contrib over its pixels
-        uint32_t mx = last;
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, m, 64));
-        __syncthreads();  // sDone is free: every wave left the batch loop
-        if (lane == 0) sDone[wave] = mx;
-        __syncthreads();
-        if (tid == 0) tile_work[tile] = max(max(sDone[0], sDone[1]), max(sDone[2], sDone[3]));
-    }
     if (inside) {
         const size_t pix_id = (size_t)W * py + px;
         const size_t plane = (size_t)H * W;
@@ -184,27 +168,26 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
 template <int SMAX>
 static void launch_fwd(bool cull, unsigned tiles, hipStream_t s, const uint2* ranges, const uint32_t* point_list, int W,
                        int H, int S, int gx, int gy, const float4* rec, const float* semantics, const float* bg, float* out_color, float* out_depth, float* out_alpha,
-                       float* out_semantic, uint32_t* n_contrib, const uint32_t* order, uint32_t* tile_work) {
+                       float* out_semantic, uint32_t* n_contrib) {
     if (cull)
         sgr_blend_fwd_kernel<SMAX, true><<<tiles, SGR_TILE_THREADS, 0, s>>>(ranges, point_list, W, H, S, gx, gy, rec, semantics,
                                                                            bg, out_color, out_depth, out_alpha,
-                                                                           out_semantic, n_contrib, order, tile_work);
+                                                                           out_semantic, n_contrib);
     else
         sgr_blend_fwd_kernel<SMAX, false><<<tiles, SGR_TILE_THREADS, 0, s>>>(ranges, point_list, W, H, S, gx, gy, rec, semantics,
                                                                             bg, out_color, out_depth, out_alpha,
-                                                                            out_semantic, n_contrib, order, tile_work);
+                                                                            out_semantic, n_contrib);
 }
 
 // S must be <= SGR_SEM_MAX (checked by the caller).
 void sgr_launch_blend_fwd(bool cull, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W, int H,
                           int S, const float4* rec, const float* semantics,
                           const float* bg, float* out_color, float* out_depth, float* out_alpha, float* out_semantic,
-                          uint32_t* n_contrib, const uint32_t* order, uint32_t* tile_work, hipStream_t s) {
+                          uint32_t* n_contrib, hipStream_t s) {
     if (gx <= 0 || gy <= 0) return;
-    // heaviest-first order: one workgroup per tile; otherwise the XCD-aware supertile grid incl. padding blocks
-    const unsigned tiles = order ? (unsigned)(gx * gy) : sgr_xcd_grid_blocks(gx, gy);
+    const unsigned tiles = sgr_xcd_grid_blocks(gx, gy);  // supertile-ordered grid incl. padding blocks
 #define SGR_FWD(N) launch_fwd<N>(cull, tiles, s, ranges, point_list, W, H, S, gx, gy, rec, semantics, bg, \
-                                 out_color, out_depth, out_alpha, out_semantic, n_contrib, order, tile_work)
+                                 out_color, out_depth, out_alpha, out_semantic, n_contrib)
     if (S == 0) SGR_FWD(0);
     else if (S <= 4) SGR_FWD(4);
     else if (S <= 8) SGR_FWD(8);

@@ -56,9 +56,6 @@ struct SgrBinView {
 struct SgrImgView {
     uint32_t* n_contrib;
     uint2* ranges;
-    uint32_t* tile_work;   // [T] list positions the forward walked in the tile (max n_contrib) = the backward's walk
-    uint32_t* order_fwd;   // [T] tiles by descending list length: launch order of the forward blend
-    uint32_t* order_bwd;   // [T] tiles by descending tile_work: launch order of the backward blend
 };
 
 static inline size_t sgr_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -131,9 +128,6 @@ static inline SgrImgView sgr_img_carve(char* base, size_t N, size_t T, char** en
     char* p = base;
     sgr_carve(p, v.n_contrib, N ? N : 1);
     sgr_carve(p, v.ranges, T ? T : 1);
-    sgr_carve(p, v.tile_work, T ? T : 1);
-    sgr_carve(p, v.order_fwd, T ? T : 1);
-    sgr_carve(p, v.order_bwd, T ? T : 1);
     if (end) *end = p;
     return v;
 }

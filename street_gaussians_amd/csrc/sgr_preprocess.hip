@@ -301,45 +301,6 @@ void sgr_launch_gather_tiles(int P, const uint32_t* order, const uint32_t* tiles
                                                                                                 tt_sorted);
 }
 
-// ---- heaviest-first launch order of the tile kernels ----------------------------------------------------------------
-// A blend launch has only ~5 tiles per resident workgroup slot, so its end is ragged: in launch order 13-17 % of the
-// slot-time is idle at the tail (simulated on the benchmark's tile loads), longest-first 6-9 %.  One workgroup
-// bucket-sorts the T tiles by descending work (64 buckets, LDS histogram + scan + cursor scatter); the order inside a
-// bucket is whatever the atomics give -- tiles are independent, so the RESULT does not depend on it.
-__global__ void __launch_bounds__(1024)
-sgr_tile_order_kernel(int T, const uint2* __restrict__ ranges, const uint32_t* __restrict__ work, uint32_t* __restrict__ order) {
-    __shared__ uint32_t hist[64], cursor[64], smax;
-    const int tid = threadIdx.x;
-    if (tid < 64) hist[tid] = 0;
-    if (tid == 0) smax = 0;
-    __syncthreads();
-    uint32_t mx = 0;
-    for (int t = tid; t < T; t += 1024) mx = max(mx, work ? work[t] : ranges[t].y - ranges[t].x);
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, m, 64));
-    if ((tid & 63) == 0) atomicMax(&smax, mx);
-    __syncthreads();
-    const float scale = 63.0f / (float)max(smax, 1u);
-    for (int t = tid; t < T; t += 1024) {
-        const uint32_t w = work ? work[t] : ranges[t].y - ranges[t].x;
-        atomicAdd(&hist[63 - min(63, (int)((float)w * scale))], 1u);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t run = 0;
-        for (int b = 0; b < 64; b++) { cursor[b] = run; run += hist[b]; }
-    }
-    __syncthreads();
-    for (int t = tid; t < T; t += 1024) {
-        const uint32_t w = work ? work[t] : ranges[t].y - ranges[t].x;
-        order[atomicAdd(&cursor[63 - min(63, (int)((float)w * scale))], 1u)] = (uint32_t)t;
-    }
-}
-void sgr_launch_tile_order(int T, const uint2* ranges, const uint32_t* work, uint32_t* order, hipStream_t s) {
-    if (T <= 0) return;
-    sgr_tile_order_kernel<<<1, 1024, 0, s>>>(T, ranges, work, order);
-}
-
 void sgr_launch_duplicate(int P, const SgrGeomView& gv, const uint32_t* order, const uint32_t* offs_incl, uint32_t* keys,
                           uint32_t* vals, int gx, hipStream_t s) {
     if (P <= 0) return;
