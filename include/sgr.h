@@ -52,7 +52,8 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
 
 /* CudaRasterizer::Rasterizer::backward  (cuda_rasterizer/rasterizer.h:64-102, rasterizer_impl.cu:396-506).
  * geom/binning/image buffers and R are the ones forward produced.  `scratch` provides temporary device
- * memory (R * row_stride floats) that may be released when the call returns.  All gradient outputs are
+ * memory (one float4 per Gaussian + R partial rows of row_stride floats + R flag bytes) that may be released when
+ * the call returns.  All gradient outputs are
  * fully written (no zero-initialisation needed, cf. rasterize_points.cu:166-176):
  * dL_dmean2D[P,3] (z = sum |gx|+|gy|), dL_dopacity[P], dL_dcolor[P,3], dL_dmean3D[P,3], dL_dcov3D[P,6],
  * dL_dsh[P,M,3] (NULL if shs NULL), dL_dscale[P,3], dL_drot[P,4], dL_dsemantic[P,S].
