@@ -9,7 +9,9 @@
 // torch::zeros (rasterize_points.cu:166-176).
 #include "sgr_math.h"
 
+#ifndef SGR_GB_THREADS
 #define SGR_GB_THREADS 256
+#endif
 #ifndef SGR_RS_LANES
 #define SGR_RS_LANES 4  // lanes that share one Gaussian's partial rows in the row-sum stage (4 or 8)
 #endif

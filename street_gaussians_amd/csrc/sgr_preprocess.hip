@@ -7,7 +7,9 @@
 // instance with three 16-byte loads.
 #include "sgr_math.h"
 
+#ifndef SGR_PRE_THREADS
 #define SGR_PRE_THREADS 256
+#endif
 
 __device__ __forceinline__ uint32_t sgr_pack_rect(uint32_t x0, uint32_t y0, uint32_t w) {
     return x0 | (y0 << 10) | (w << 20);
