@@ -116,6 +116,12 @@ int sgr_profile_read(double* sum_ms, int* counts);
 int sgr_export_internal(int which, int P, int R, int width, int height, char* geom_buffer, char* binning_buffer,
                         char* image_buffer, void* dst, void* stream);
 
+/* ---- A/B switches of the blend kernels (tests, tools/gpu_ab.sh): bit 0 no quadrant cull, bit 1 no DPP wave
+ * reduction, bit 2 no deterministic LDS combine, bit 3 the backward ignores the forward's hit record and redoes the
+ * geometric cull.  mask >= 0 sets them process-wide, mask < 0 only queries; returns the previous mask.  The initial
+ * value comes from the environment (SGR_NO_CULL, SGR_NO_DPP, SGR_NO_DET, SGR_NO_HITS), read once. */
+int sgr_test_switches(int mask);
+
 /* ---- primitive self-tests (used by tests/ on the GPU box) ---------------------------------------------------- */
 int sgr_test_scan(const uint32_t* in, uint32_t* out, size_t n, int inclusive, uint32_t* tmp, void* stream);
 /* keys0/vals0 hold the input; returns 0 or 1 = which of (keys0,vals0)/(keys1,vals1) holds the sorted result */

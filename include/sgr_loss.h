@@ -53,13 +53,14 @@ int sgr_bce_backward(int n, int mode, const float* acc, const uint8_t* mask, con
                      void* stream);
 
 /* LiDAR depth term (train.py:124-131): over the pixels with lidar_depth > 0 and mask, the error
- * |depth / (acc + 1e-10) - lidar_depth|; the mean of its int(keep * count) SMALLEST values (keep = 0.95: the largest 5 %
+ * |depth / (acc + 1e-10) - lidar_depth|; the mean of its int(keep * count) SMALLEST values (keep is a double, like the
+ * Python float of train.py:128: 0.95f * 100 truncates to 94, 0.95 * 100 to 95) (keep = 0.95: the largest 5 %
  * are dropped).  The k-th smallest error is found with a 4-pass radix select on the float bits (no sort, no host
  * sync).  out[0] = loss, out[1] = k, out[2] = threshold error, out[3] = weight of the errors equal to the threshold
  * (their share of the remaining slots).  work: sgr_lidar_work_bytes(n) bytes (keeps the per-pixel errors for the backward). */
 size_t sgr_lidar_work_bytes(int n);
 int sgr_lidar_depth_forward(int n, const float* depth, const float* acc, const float* lidar_depth, const uint8_t* mask,
-                            float keep, float* out, char* work, void* stream);
+                            double keep, float* out, char* work, void* stream);
 int sgr_lidar_depth_backward(int n, const float* depth, const float* acc, const float* lidar_depth, const float* out,
                              const char* work, const float* upstream, float* dL_ddepth, float* dL_dacc, void* stream);
 

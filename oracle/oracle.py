@@ -171,7 +171,9 @@ def backward(fw: ForwardResult, grad_color, grad_depth, grad_alpha, grad_semanti
     """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:126-220) on the CPU oracle.
 
     parallel=False gives the deterministic accumulation order; parallel=True uses all OpenMP
-    threads with unordered atomic float adds (what the reference's atomicAdd does)."""
+    threads with unordered atomic float adds (what the reference's atomicAdd does); parallel="exact"
+    uses all threads and sums the same float terms in double, rounded to float once -- the order-free
+    value the unordered float sums scatter around (used at the BASELINE sizes)."""
     L = lib()
     a = fw._args
     P, M, S, H, W = a["P"], a["M"], a["S"], a["H"], a["W"]
@@ -189,7 +191,7 @@ def backward(fw: ForwardResult, grad_color, grad_depth, grad_alpha, grad_semanti
         _ptr(a["projmatrix"]), _ptr(a["campos"]), C.c_float(a["tanfovx"]), C.c_float(a["tanfovy"]), _ptr(fw.radii),
         _ptr(gc), _ptr(gd), _ptr(ga), _ptr(gs), _ptr(g["means2D"]), _ptr(g["conic"]), _ptr(g["opacity"]),
         _ptr(g["colors"]), _ptr(g["depths"]), _ptr(g["means3D"]), _ptr(g["cov3D"]), _ptr(g["sh"]), _ptr(g["scales"]),
-        _ptr(g["rotations"]), _ptr(g["semantics"]), C.c_int(1 if parallel else 0))
+        _ptr(g["rotations"]), _ptr(g["semantics"]), C.c_int(2 if parallel == "exact" else (1 if parallel else 0)))
     return g
 
 

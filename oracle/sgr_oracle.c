@@ -547,26 +547,34 @@ void sgo_mark_visible(int P, const float* means3D, const float* viewmatrix, cons
 /* ------------------------------------------------------------------------------------------ */
 /* backward.cu:415-641  renderCUDA (backward) for one tile; float adds replace atomicAdd.    */
 #define S_MAX 20 /* NUM_CLASSES, config.h:16 */
+/* double shadows of the six arrays the tile kernel accumulates into (members named like the parameters) */
+typedef struct { double *dL_dmean2D, *dL_dconic2D, *dL_dopacity, *dL_dcolors, *dL_ddepths, *dL_dsemantics; } sgo_acc64;
 static void render_backward_tile(const sgo_state* s, uint32_t tx, uint32_t ty, int W, int H, int S,
                                  const float* bg_color, const float* colors, const float* semantics,
                                  const float* alphas, const float* dL_dpixels, const float* dL_dpixel_depths,
                                  const float* dL_dalphas, const float* dL_dpixel_semantics, float* dL_dmean2D,
                                  float* dL_dconic2D, float* dL_dopacity, float* dL_dcolors, float* dL_ddepths,
-                                 float* dL_dsemantics, int use_atomics) {
+                                 float* dL_dsemantics, int use_atomics, const sgo_acc64* a64) {
     const int C = NUM_CHANNELS;
     const uint32_t horizontal_blocks = (W + BLOCK_X - 1) / BLOCK_X;
     const u2 range = s->ranges[ty * horizontal_blocks + tx];
     const int toDo0 = (int)(range.y - range.x);
     const float ddelx_dx = (float)(0.5 * W);
     const float ddely_dy = (float)(0.5 * H);
-#define ADDF(ptr, val)                                   \
-    do {                                                 \
-        float v__ = (val);                               \
-        if (use_atomics) {                               \
-            _Pragma("omp atomic") *(ptr) += v__;         \
-        } else {                                         \
-            *(ptr) += v__;                               \
-        }                                                \
+    /* a64 != NULL: the float terms (computed exactly as the reference computes them) are summed in double and rounded
+     * to float once at the end (sgo_backward), so the result is independent of the order of the adds to ~1e-16: an
+     * order-free statement of what the reference's unordered float atomicAdd computes, usable with all threads at
+     * the BASELINE sizes. */
+#define ADDF(arr, index, val)                                    \
+    do {                                                         \
+        float v__ = (val);                                       \
+        if (a64) {                                               \
+            _Pragma("omp atomic") a64->arr[index] += (double)v__; \
+        } else if (use_atomics) {                                \
+            _Pragma("omp atomic") arr[index] += v__;             \
+        } else {                                                 \
+            arr[index] += v__;                                   \
+        }                                                        \
     } while (0)
     for (uint32_t ly = 0; ly < BLOCK_Y; ly++) {
         for (uint32_t lx = 0; lx < BLOCK_X; lx++) {
@@ -615,7 +623,7 @@ static void render_backward_tile(const sgo_state* s, uint32_t tx, uint32_t ty, i
                     last_color[ch] = c;
                     const float dL_dchannel = dL_dpixel[ch];
                     dL_dopa += (c - accum_rec[ch]) * dL_dchannel;
-                    ADDF(&dL_dcolors[global_id * C + ch], dchannel_dcolor * dL_dchannel);
+                    ADDF(dL_dcolors, global_id * C + ch, dchannel_dcolor * dL_dchannel);
                 }
                 const float dchannel_dsemantic = alpha * T;
                 for (int ch = 0; ch < S; ch++) {
@@ -624,13 +632,13 @@ static void render_backward_tile(const sgo_state* s, uint32_t tx, uint32_t ty, i
                     last_semantic[ch] = sv;
                     const float dL_dchannel = dL_dpixel_semantic[ch];
                     dL_dopa += (sv - accum_semantic_rec[ch]) * dL_dchannel;
-                    ADDF(&dL_dsemantics[(size_t)global_id * S + ch], dchannel_dsemantic * dL_dchannel);
+                    ADDF(dL_dsemantics, (size_t)global_id * S + ch, dchannel_dsemantic * dL_dchannel);
                 }
                 const float c_d = s->depths[global_id];
                 accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
                 last_depth = c_d;
                 dL_dopa += (c_d - accum_depth_rec) * dL_dpixel_depth;
-                ADDF(&dL_ddepths[global_id], dpixel_depth_ddepth * dL_dpixel_depth);
+                ADDF(dL_ddepths, global_id, dpixel_depth_ddepth * dL_dpixel_depth);
 
                 accum_alpha_rec = last_alpha + (1.f - last_alpha) * accum_alpha_rec;
                 dL_dopa += (1 - accum_alpha_rec) * dL_dalpha;
@@ -647,15 +655,15 @@ static void render_backward_tile(const sgo_state* s, uint32_t tx, uint32_t ty, i
                 const float dG_ddelx = -gdx * con_o.x - gdy * con_o.y;
                 const float dG_ddely = -gdy * con_o.z - gdx * con_o.y;
 
-                ADDF(&dL_dmean2D[3 * global_id + 0], dL_dG * dG_ddelx * ddelx_dx);
-                ADDF(&dL_dmean2D[3 * global_id + 1], dL_dG * dG_ddely * ddely_dy);
+                ADDF(dL_dmean2D, 3 * global_id + 0, dL_dG * dG_ddelx * ddelx_dx);
+                ADDF(dL_dmean2D, 3 * global_id + 1, dL_dG * dG_ddely * ddely_dy);
                 const float abs_dL_dmean2D = fabsf(dL_dG * dG_ddelx * ddelx_dx) + fabsf(dL_dG * dG_ddely * ddely_dy);
-                ADDF(&dL_dmean2D[3 * global_id + 2], abs_dL_dmean2D);
+                ADDF(dL_dmean2D, 3 * global_id + 2, abs_dL_dmean2D);
 
-                ADDF(&dL_dconic2D[4 * global_id + 0], -0.5f * gdx * d.x * dL_dG);
-                ADDF(&dL_dconic2D[4 * global_id + 1], -0.5f * gdx * d.y * dL_dG);
-                ADDF(&dL_dconic2D[4 * global_id + 3], -0.5f * gdy * d.y * dL_dG);
-                ADDF(&dL_dopacity[global_id], G * dL_dopa);
+                ADDF(dL_dconic2D, 4 * global_id + 0, -0.5f * gdx * d.x * dL_dG);
+                ADDF(dL_dconic2D, 4 * global_id + 1, -0.5f * gdx * d.y * dL_dG);
+                ADDF(dL_dconic2D, 4 * global_id + 3, -0.5f * gdy * d.y * dL_dG);
+                ADDF(dL_dopacity, global_id, G * dL_dopa);
             }
         }
     }
@@ -895,8 +903,9 @@ static void preprocess_bw(int idx, int D, int M, const float* means, const int* 
 
 /* rasterizer_impl.cu:396-506  Rasterizer::backward.  All dL_d* outputs must be
  * zero-initialised by the caller (rasterize_points.cu:166-176).
- * threads>1 uses unordered omp-atomic float adds like the reference's atomicAdd;
- * threads==1 gives the deterministic order stated at the top of this file. */
+ * parallel == 1 uses unordered omp-atomic float adds like the reference's atomicAdd;
+ * parallel == 0 gives the deterministic order stated at the top of this file;
+ * parallel == 2 sums the same float terms in double (all threads), rounded to float once: order-free. */
 void sgo_backward(const sgo_state* s, int D, int M, int S, const float* background, const float* means3D,
                   const float* shs, const float* colors_precomp, const float* semantics, const float* alphas,
                   const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
@@ -911,17 +920,32 @@ void sgo_backward(const sgo_state* s, int D, int M, int S, const float* backgrou
     const float focal_x = width / (2.0f * tan_fovx);
     const float* color_ptr = (colors_precomp != NULL) ? colors_precomp : s->rgb;
     int ntiles = (int)(s->gx * s->gy);
-    if (parallel) {
+    if (parallel == 2) {
+        const size_t n[6] = {3 * (size_t)P, 4 * (size_t)P, (size_t)P, 3 * (size_t)P, (size_t)P, (size_t)S * (size_t)P};
+        float* f[6] = {dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth, dL_dsemantic};
+        double* d[6];
+        for (int i = 0; i < 6; i++) d[i] = (double*)calloc(n[i] ? n[i] : 1, sizeof(double));
+        const sgo_acc64 a64 = {d[0], d[1], d[2], d[3], d[4], d[5]};
 #pragma omp parallel for schedule(dynamic, 8)
         for (int t = 0; t < ntiles; t++)
             render_backward_tile(s, (uint32_t)t % s->gx, (uint32_t)t / s->gx, width, height, S, background, color_ptr,
                                  semantics, alphas, dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, dL_dmean2D,
-                                 dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth, dL_dsemantic, 1);
+                                 dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth, dL_dsemantic, 1, &a64);
+        for (int i = 0; i < 6; i++) {
+            for (size_t k = 0; k < n[i]; k++) f[i][k] += (float)d[i][k];
+            free(d[i]);
+        }
+    } else if (parallel) {
+#pragma omp parallel for schedule(dynamic, 8)
+        for (int t = 0; t < ntiles; t++)
+            render_backward_tile(s, (uint32_t)t % s->gx, (uint32_t)t / s->gx, width, height, S, background, color_ptr,
+                                 semantics, alphas, dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, dL_dmean2D,
+                                 dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth, dL_dsemantic, 1, NULL);
     } else {
         for (int t = 0; t < ntiles; t++)
             render_backward_tile(s, (uint32_t)t % s->gx, (uint32_t)t / s->gx, width, height, S, background, color_ptr,
                                  semantics, alphas, dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, dL_dmean2D,
-                                 dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth, dL_dsemantic, 0);
+                                 dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth, dL_dsemantic, 0, NULL);
     }
     const float* cov3D_ptr = (cov3D_precomp != NULL) ? cov3D_precomp : s->cov3D;
 #pragma omp parallel for schedule(static) if (parallel)

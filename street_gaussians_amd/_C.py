@@ -233,6 +233,14 @@ def sh_grad_from_views(means3D, campos, drgb, degree, M):
     return out
 
 
+NO_CULL, NO_DPP, NO_DET, NO_HITS = 1, 2, 4, 8
+
+
+def test_switches(mask: int = -1) -> int:
+    """sgr_test_switches: A/B switches of the blend kernels (tests and tools only); returns the previous mask."""
+    return int(_native.lib().sgr_test_switches(int(mask)))
+
+
 def export_internal(name, P, R, image_height, image_width, geomBuffer, binningBuffer, imageBuffer):
     """Parity-test introspection (sgr_export_internal): dense copy of one internal array."""
     which, dtype, shp = _EXPORT[name]

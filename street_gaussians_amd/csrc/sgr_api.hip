@@ -12,13 +12,13 @@
 #include "sgr_math.h"
 
 // launchers implemented in the kernel translation units
-void sgr_launch_mark_visible(int P, const float* means3D, const SgrCam* cam, uint8_t* present, hipStream_t s);
+void sgr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 void sgr_launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, const float* rotations,
                            const float* opacities, const float* shs, const float* cov3D_precomp,
                            const float* colors_precomp, const SgrCam* cam, const SgrGeomView& gv, int* radii,
                            int prefiltered, hipStream_t s);
 void sgr_launch_filter(int P, const float* means3D, const float* scales, const float* rotations,
-                       const float* cov3D_precomp, const SgrCam* cam, const SgrGeomView& gv, int* radii,
+                       const float* cov3D_precomp, const SgrCamArgs& ca, const SgrGeomView& gv, int* radii,
                        float* means2D, int prefiltered, hipStream_t s);
 void sgr_launch_gather_tiles(int P, const uint32_t* order, const uint32_t* tiles_touched, uint32_t* tt_sorted, hipStream_t s);
 void sgr_launch_duplicate(int P, const SgrGeomView& gv, const uint32_t* order, const uint32_t* offs_incl, uint32_t* keys,
@@ -34,12 +34,13 @@ int sgr_launch_sort_pairs(uint64_t* const keys[2], uint32_t* const vals[2], uint
                           uint32_t* scan_tmp, hipStream_t s);
 void sgr_launch_blend_fwd(bool cull, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W, int H,
                           int S, const float4* rec, const float* semantics, const float* bg, float* out_color,
-                          float* out_depth, float* out_alpha, float* out_semantic, uint32_t* n_contrib, hipStream_t s);
+                          float* out_depth, float* out_alpha, float* out_semantic, uint32_t* n_contrib, uint8_t* hit4,
+                          hipStream_t s);
 int sgr_partial_row_stride(int S);
 void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
                           int H, int S, const float* bg, const float4* rec, const float* semantics, const float* alphas,
-                          const uint32_t* n_contrib, const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha,
-                          const float* dL_dsem, float* partials, uint8_t* touched, hipStream_t s);
+                          const uint32_t* n_contrib, const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth,
+                          const float* dL_dalpha, const float* dL_dsem, float* partials, uint8_t* touched, hipStream_t s);
 void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const int* radii, const float* shs,
                           const float* scales, const float* rotations, const float* cov3D_precomp, const SgrCam* cam,
                           const SgrGeomView& gv, const float* partials, int row_stride, const uint8_t* touched,
@@ -60,6 +61,22 @@ static bool env_flag(const char* name) {
     return v && v[0] && v[0] != '0';
 }
 
+// A/B switches of the blend kernels (tests and tools/gpu_ab.sh): bit 0 no quadrant cull, 1 no DPP reduction,
+// 2 no deterministic LDS combine, 3 backward ignores the forward's hit record.  Process-wide, set through
+// sgr_test_switches(); the environment (SGR_NO_CULL / SGR_NO_DPP / SGR_NO_DET / SGR_NO_HITS) only provides the
+// initial value, read ONCE -- the per-step path is one relaxed atomic load, no getenv.
+#include <atomic>
+static std::atomic<int> g_switches{-1};
+static int switches() {
+    int v = g_switches.load(std::memory_order_relaxed);
+    if (v < 0) {
+        v = (env_flag("SGR_NO_CULL") ? 1 : 0) | (env_flag("SGR_NO_DPP") ? 2 : 0) | (env_flag("SGR_NO_DET") ? 4 : 0) |
+            (env_flag("SGR_NO_HITS") ? 8 : 0);
+        g_switches.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
 // ---- optional per-stage timing with HIP events on the caller's stream (sgr_profile_*) -------------------
 // stages: 0 preprocess(+camera pack, memsets) 1 depth sort + scan 2 duplicate 3 tile sort 4 tile_ranges 5 blend_fwd
 //         6 partials memset 7 blend_bwd 8 gauss_bwd
@@ -72,7 +89,7 @@ struct SgrProf {
     int stage[SGR_PROF_SLOTS];
     bool created = false;
 };
-static SgrProf g_prof;
+static thread_local SgrProf g_prof;  // per host thread: a recorder belongs to the thread (and device) that enabled it
 static void prof_begin(int stage, hipStream_t s) {
     if (!g_prof.on || g_prof.n >= SGR_PROF_SLOTS) return;
     g_prof.stage[g_prof.n] = stage;
@@ -299,9 +316,9 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
         prof_end(stream);
     }
     prof_begin(5, stream);
-    const bool cull = !env_flag("SGR_NO_CULL");
+    const bool cull = !(switches() & 1);
     sgr_launch_blend_fwd(cull, gx, gy, iv.ranges, bv.vals[cur], W, H, S, gv.rec, semantics,
-                         background, out_color, out_depth, out_alpha, out_semantic, iv.n_contrib, stream);
+                         background, out_color, out_depth, out_alpha, out_semantic, iv.n_contrib, bv.hit4, stream);
     SGR_STAGE("blend_fwd");
     prof_end(stream);
     return R;
@@ -331,6 +348,14 @@ int sgr_backward(int P, int D, int M, int R, int S, const float* background, int
     if (S < 0 || S > SGR_SEM_MAX) return fail(SGR_E_INVALID, "semantic channels must be in [0, 32]");
     if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer))
         return fail(SGR_E_INVALID, "backward needs the buffers produced by forward");
+    // every array the kernels dereference unconditionally (a NULL here would be a GPU memory fault, not an error code)
+    if (!means3D || !background || !alphas || !dL_dpix || !dL_dpix_depth || !dL_dalphas)
+        return fail(SGR_E_INVALID, "means3D, background, alphas, dL_dpix, dL_dpix_depth and dL_dalphas are required");
+    if (S > 0 && (!semantics || !dL_dpix_semantic || !dL_dsemantic))
+        return fail(SGR_E_INVALID, "S > 0 needs semantics, dL_dpix_semantic and dL_dsemantic");
+    if (!dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot)
+        return fail(SGR_E_INVALID, "all gradient outputs except dL_dsh / dL_dsemantic are required");
+    if (shs && !dL_dsh) return fail(SGR_E_INVALID, "shs given but dL_dsh is NULL");
     const int gx = (W + SGR_BLOCK_X - 1) / SGR_BLOCK_X, gy = (H + SGR_BLOCK_Y - 1) / SGR_BLOCK_Y;
     const size_t N = (size_t)W * H, T = (size_t)gx * gy;
     const SgrGeomView gv = sgr_geom_carve(geom_buffer, (size_t)P);
@@ -352,10 +377,14 @@ int sgr_backward(int P, int D, int M, int R, int S, const float* background, int
         SGR_HIP(hipMemsetAsync(touched, 0, (size_t)R, stream));  // rows themselves are never cleared
         prof_end(stream);
         prof_begin(7, stream);
-        const bool cull = !env_flag("SGR_NO_CULL"), dpp = !env_flag("SGR_NO_DPP"), det = !env_flag("SGR_NO_DET");
+        const int sw = switches();
+        const bool cull = !(sw & 1), dpp = !(sw & 2), det = !(sw & 4);
+        // the forward's record of which (quadrant, instance) pairs blended at all; switch 8: the kernel redoes the
+        // geometric cull instead (A/B and tests: the two walks must give bit-identical gradients)
+        const uint8_t* hits = (sw & 8) ? nullptr : bv.hit4;
         sgr_launch_blend_bwd(cull, dpp, det, gx, gy, iv.ranges, bv.vals[cur], W, H, S, background, gv.rec, semantics,
-                             alphas, iv.n_contrib, dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, partials, touched,
-                             stream);
+                             alphas, iv.n_contrib, hits, dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, partials,
+                             touched, stream);
         SGR_STAGE("blend_bwd");
         prof_end(stream);
     }
@@ -392,6 +421,12 @@ int sgr_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, con
     return 0;
 }
 
+int sgr_test_switches(int mask) {
+    const int prev = switches();
+    if (mask >= 0) g_switches.store(mask & 15, std::memory_order_relaxed);
+    return prev;
+}
+
 int sgr_profile_enable(int on) {
     if (on && !g_prof.created) {
         for (int i = 0; i < SGR_PROF_SLOTS; i++)
@@ -420,24 +455,26 @@ int sgr_profile_read(double* sum_ms, int* counts) {
     return n;
 }
 
-// scratch for the two small entry points below: a camera block only
-struct TmpCam {
-    SgrCam* cam = nullptr;
-    ~TmpCam() { if (cam) (void)hipFree(cam); }
-};
+// One 256-byte device block per (host thread, device), allocated on first use and kept: the flag word of
+// sgr_visible_filter's `prefiltered` check.  Neither entry point below allocates, frees or synchronises on its
+// normal path; everything is queued on the caller's stream.
+static uint32_t* filter_flag_block() {
+    static thread_local uint32_t* blk[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!blk[dev] && hipMalloc((void**)&blk[dev], 256) != hipSuccess) blk[dev] = nullptr;
+    return blk[dev];
+}
 
 int sgr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
                      void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const int debug = 0;
+    (void)projmatrix;  // the reference's in_frustum only uses the view transform (auxiliary.h:139-164)
     if (P <= 0) return 0;
-    TmpCam tc;
-    SGR_HIP(hipMalloc((void**)&tc.cam, sizeof(SgrCam)));
-    sgr_pack_camera_kernel<<<1, 64, 0, stream>>>(tc.cam, viewmatrix, projmatrix, nullptr, 1.f, 1.f, 1.f, 1.f, 16, 16, 1, 1,
-                                                 1.f);
-    sgr_launch_mark_visible(P, means3D, tc.cam, present, stream);
+    if (!means3D || !viewmatrix || !present) return fail(SGR_E_INVALID, "means3D, viewmatrix and present are required");
+    sgr_launch_mark_visible(P, means3D, viewmatrix, present, stream);
     SGR_STAGE("mark_visible");
-    SGR_HIP(hipStreamSynchronize(stream));  // tc.cam is freed on return
     return 0;
 }
 
@@ -450,25 +487,34 @@ int sgr_visible_filter(int P, int width, int height, const float* means3D, const
     const int W = width, H = height;
     const int gx = (W + SGR_BLOCK_X - 1) / SGR_BLOCK_X, gy = (H + SGR_BLOCK_Y - 1) / SGR_BLOCK_Y;
     if (gx > SGR_MAX_GRID_DIM || gy > SGR_MAX_GRID_DIM) return fail(SGR_E_INVALID, "image too large");
+    if (!means3D || !viewmatrix || !projmatrix || !radii || !means2D)
+        return fail(SGR_E_INVALID, "means3D, viewmatrix, projmatrix, radii and means2D are required");
     if (((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr))
         return fail(SGR_E_INVALID, "provide exactly one of scales+rotations / cov3D_precomp");
-    TmpCam tc;
-    SGR_HIP(hipMalloc((void**)&tc.cam, sizeof(SgrCam) + 64));
-    uint32_t* flag = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(tc.cam) + sizeof(SgrCam));
-    SGR_HIP(hipMemsetAsync(flag, 0, 4, stream));
-    const float focal_y = H / (2.0f * tan_fovy), focal_x = W / (2.0f * tan_fovx);
-    sgr_pack_camera_kernel<<<1, 64, 0, stream>>>(tc.cam, viewmatrix, projmatrix, nullptr, tan_fovx, tan_fovy, focal_x,
-                                                 focal_y, W, H, gx, gy, scale_modifier);
+    SgrCamArgs ca;
+    ca.view = viewmatrix; ca.proj = projmatrix;
+    ca.tan_fovx = tan_fovx; ca.tan_fovy = tan_fovy;
+    ca.focal_y = H / (2.0f * tan_fovy); ca.focal_x = W / (2.0f * tan_fovx);
+    ca.W = W; ca.H = H; ca.gx = gx; ca.gy = gy; ca.scale_modifier = scale_modifier;
     SgrGeomView gv;
     memset(&gv, 0, sizeof(gv));
-    gv.header = flag;
+    uint32_t* flag = nullptr;
+    if (prefiltered) {  // only then can the kernel raise the "filtered although prefiltered" flag
+        flag = filter_flag_block();
+        if (!flag) return fail(SGR_E_HIP, "flag block allocation failed");
+        SGR_HIP(hipMemsetAsync(flag, 0, 4, stream));
+        gv.header = flag;
+    }
     SGR_HIP(hipMemsetAsync(means2D, 0, (size_t)P * 2 * sizeof(float), stream));  // torch::full(0), rasterize_points.cu:271
-    sgr_launch_filter(P, means3D, scales, rotations, cov3D_precomp, tc.cam, gv, radii, means2D, prefiltered, stream);
+    sgr_launch_filter(P, means3D, scales, rotations, cov3D_precomp, ca, gv, radii, means2D, prefiltered, stream);
     SGR_STAGE("filter");
-    uint32_t hflag = 0;
-    SGR_HIP(hipMemcpyAsync(&hflag, flag, 4, hipMemcpyDeviceToHost, stream));
-    SGR_HIP(hipStreamSynchronize(stream));
-    if (hflag & 1u) return fail(SGR_E_PREFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
+    if (prefiltered) {
+        uint32_t* host = pinned_pair();
+        if (!host) return fail(SGR_E_HIP, "pinned readback slot creation failed");
+        SGR_HIP(hipMemcpyAsync(host, flag, 4, hipMemcpyDeviceToHost, stream));
+        SGR_HIP(hipStreamSynchronize(stream));
+        if (host[0] & 1u) return fail(SGR_E_PREFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
+    }
     return 0;
 }
 

@@ -20,11 +20,19 @@
 #define SGR_TILE_THREADS 256
 typedef float sgr_f2 __attribute__((ext_vector_type(2)));
 // list entries staged in LDS per round.  128 (not 256) keeps the workgroup at 20 KB of LDS so that occupancy is set by
-// registers (5 waves / SIMD) instead of LDS (4): measured +11 % time at 3 workgroups / CU vs 4.
+// registers (5 waves / SIMD) instead of LDS (4): measured +11 % time at 3 workgroups / CU vs 4.  With more than 8
+// semantic channels the rows are 32+ floats wide and the two-row deterministic combine would need 49-68 KB at 128
+// entries, so those instantiations stage 64 entries per round (24-34 KB): every instantiation is deterministic.
 #ifndef SGR_BWD_BATCH
 #define SGR_BWD_BATCH 128
 #endif
+template <int SMAX>
+struct SgrBwdBatch { static constexpr int value = SMAX <= 8 ? SGR_BWD_BATCH : 64; };
 #define SGR_ROW_BASE 11
+// 1: folded row stage of the wave reduction (7 DPP adds + 1 LDS add per hit at S = 0), 0: four row steps per register
+#ifndef SGR_FOLD
+#define SGR_FOLD 1
+#endif
 
 // Sum over the 64 lanes of a wave; the result is valid in lanes 48..63 (read it from lane 63).
 __device__ __forceinline__ float sgr_wave_sum_dpp(float v) {
@@ -134,6 +142,81 @@ __device__ __forceinline__ void sgr_wave_reduce_scatter(float (&v)[NVAL], float 
     static_assert(N != 1, "unsupported value count");
 }
 
+// ---- FOLDED row stage -----------------------------------------------------------------------------------------------
+// The row steps above spend 4 DPP adds per register although each register's row holds ONE value (16 partials of it).
+// Folding keeps every lane busy instead: a DPP add with a bank mask puts the half-row sums of register a into lanes
+// 0-7 and those of register b into lanes 8-15 (two instructions, two registers -> one), then quarter rows the same
+// way, and only the last two steps (inside a quad) run on ceil(N/4) registers:
+//   NVAL = 12:  3 + 2 + 2 = 7 DPP adds instead of 12, and ONE ds_add_f32 (16 lanes) per hit instead of three.
+// VALU write -> DPP read needs two wait states and nothing pads the inside of an asm statement: every statement
+// opens with s_nop 1 (the wave idles, the SIMD does not: its other waves issue meanwhile).
+//   after fold8(a, b):  lanes 0-7 of each row: a[i] + a[i^8];  lanes 8-15: b[i] + b[i^8]
+__device__ __forceinline__ void sgr_fold8(float& a, const float b) {
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc"
+                 : "+v"(a)
+                 : "v"(b));
+}
+__device__ __forceinline__ void sgr_self8(float& a) {  // odd register left over: both halves get a[i] + a[i^8]
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(a));
+}
+//   after fold4(a, b):  banks 0 and 2 (lanes 0-3, 8-11): a[i] + a[i+4];  banks 1 and 3: b[i-4] + b[i]
+__device__ __forceinline__ void sgr_fold4(float& a, const float b) {
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %0, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa"
+                 : "+v"(a)
+                 : "v"(b));
+}
+__device__ __forceinline__ void sgr_half4(float& a) {  // odd register left over: banks 0 and 2 only
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5" : "+v"(a));
+}
+__device__ __forceinline__ void sgr_quad_sum(float& a) {  // every lane of a quad gets the quad's sum
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 0"
+                 : "+v"(a));
+}
+__device__ __forceinline__ void sgr_quad_sum2(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 0"
+                 : "+v"(a), "+v"(b));
+}
+// in: v[NVAL] per lane.  out: g[(NVAL/4 + 3) / 4].  With t = 4i + {0,2,1,3}[bank] (bank = (lane >> 2) & 3) and
+// k = lane >> 4, every lane of that bank of g[i] holds the wave total of value 4t + {0,2,1,3}[k] when t < NVAL/4
+// (the remaining banks hold duplicates or garbage and must be ignored).
+template <int NVAL>
+__device__ __forceinline__ void sgr_wave_reduce_fold(float (&v)[NVAL], float (&g)[(NVAL / 4 + 3) / 4]) {
+    static_assert(NVAL % 4 == 0, "pad the value count to a multiple of 4");
+    constexpr int N = NVAL / 4, NF = (N + 1) / 2, NG = (NF + 1) / 2;
+    float h[NVAL / 2], r[N];
+#pragma unroll
+    for (int p = 0; p < NVAL / 2; p++) {
+        sgr_swap32(v[2 * p], v[2 * p + 1]);
+        h[p] = v[2 * p] + v[2 * p + 1];
+    }
+#pragma unroll
+    for (int t = 0; t < N; t++) {
+        sgr_swap16(h[2 * t], h[2 * t + 1]);
+        r[t] = h[2 * t] + h[2 * t + 1];
+    }
+    // half rows: f[i] = r[2i] (lanes 0-7: t = 2i, lanes 8-15: t = 2i+1)
+#pragma unroll
+    for (int i = 0; i < N / 2; i++) sgr_fold8(r[2 * i], r[2 * i + 1]);
+    if (N & 1) sgr_self8(r[N - 1]);
+    // quarter rows: g[i] = f[2i] (banks 0, 2 <- f[2i]; banks 1, 3 <- f[2i+1])
+#pragma unroll
+    for (int i = 0; i < NG; i++) {
+        if (2 * i + 1 < NF) sgr_fold4(r[4 * i], r[4 * i + 2 < N ? 4 * i + 2 : N - 1]);
+        else sgr_half4(r[4 * i]);
+        g[i] = r[4 * i];
+    }
+    int i = 0;
+#pragma unroll
+    for (; i + 2 <= NG; i += 2) sgr_quad_sum2(g[i], g[i + 1]);
+    if (i < NG) sgr_quad_sum(g[i]);
+}
+
 // self-test of the DPP reduction (sgr_selftest in sgr_api.hip)
 __global__ void sgr_wave_sum_test_kernel(const float* in, float* out_dpp, float* out_shfl) {
     const float v = in[blockIdx.x * 64 + threadIdx.x];
@@ -151,6 +234,29 @@ __global__ void sgr_wave_sum_test_kernel(const float* in, float* out_dpp, float*
     bool rs_ok = true;
 #pragma unroll
     for (int t = 0; t < 3; t++) rs_ok = rs_ok && (r[t] == (float)(4 * t + perm + 1) * b);
+    // folded variant, 12 and 32 values: bank b of row k of g[i] must hold (4t + {0,2,1,3}[k] + 1) * sum(v) with
+    // t = 4i + {0,2,1,3}[b], for every t < NVAL/4
+    {
+        float y[12], g[1];
+#pragma unroll
+        for (int i = 0; i < 12; i++) y[i] = (float)(i + 1) * v;
+        sgr_wave_reduce_fold<12>(y, g);
+        const int bank = (threadIdx.x >> 2) & 3, t0 = (0x3120 >> (bank * 4)) & 3;
+        if (t0 < 3) rs_ok = rs_ok && (g[0] == (float)(4 * t0 + perm + 1) * b);
+        float z[32], gz[2];
+#pragma unroll
+        for (int i = 0; i < 32; i++) z[i] = (float)(i + 1) * v;
+        sgr_wave_reduce_fold<32>(z, gz);
+#pragma unroll
+        for (int i = 0; i < 2; i++) rs_ok = rs_ok && (gz[i] == (float)(4 * (4 * i + t0) + perm + 1) * b);
+        float w[20], gw[2];  // N = 5: a left-over register at both fold levels
+#pragma unroll
+        for (int i = 0; i < 20; i++) w[i] = (float)(i + 1) * v;
+        sgr_wave_reduce_fold<20>(w, gw);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+            if (4 * i + t0 < 5) rs_ok = rs_ok && (gw[i] == (float)(4 * (4 * i + t0) + perm + 1) * b);
+    }
     rs_ok = __all(rs_ok);
     if (threadIdx.x == 63) {
         // all four asm chains, the builtin version and the reduce-scatter must agree with the shuffle tree
@@ -163,15 +269,15 @@ void sgr_launch_wave_sum_test(const float* in, float* out_dpp, float* out_shfl, 
     sgr_wave_sum_test_kernel<<<nwaves, 64, 0, s>>>(in, out_dpp, out_shfl);
 }
 
-template <int SMAX, bool CULL, bool DPP, bool DET>
+template <int SMAX, bool CULL, bool DPP, bool DET, int BATCH>
 __device__ __forceinline__ void
 sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int S,
                      int gx, int gy, const float* __restrict__ bg_color, const float4* __restrict__ rec,
                      const float* __restrict__ semantics, const float* __restrict__ alphas,
-                     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
-                     const float* __restrict__ dL_dpixel_depths, const float* __restrict__ dL_dalphas,
-                     const float* __restrict__ dL_dpixel_semantics, float* __restrict__ partials, int row_stride,
-                     uint8_t* __restrict__ touched) {
+                     const uint32_t* __restrict__ n_contrib, const uint8_t* __restrict__ hit4,
+                     const float* __restrict__ dL_dpixels, const float* __restrict__ dL_dpixel_depths,
+                     const float* __restrict__ dL_dalphas, const float* __restrict__ dL_dpixel_semantics,
+                     float* __restrict__ partials, int row_stride, uint8_t* __restrict__ touched) {
     // Every fused multiply-add below is written out (fmaf / __builtin_elementwise_fma): with contraction left to the
     // optimiser, the CULL / !CULL and DPP / shuffle instantiations of this body can fuse differently and the "culling
     // is invisible, bit for bit" property (tests) would depend on code-generation luck.
@@ -179,11 +285,11 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
     constexpr int NS = SMAX > 0 ? SMAX : 1;
     constexpr int NVAL = (SGR_ROW_BASE + SMAX + 3) / 4 * 4;  // values per row, padded to float4s
     constexpr int ACCW = NVAL;                                 // LDS row stride (16-B aligned rows)
-    __shared__ float4 sA[SGR_BWD_BATCH];  // {x, y, -, -}
-    __shared__ float4 sB[SGR_BWD_BATCH];  // {qa, qb, qc, opacity}
-    __shared__ float4 sC[SGR_BWD_BATCH];  // {r, g, b, depth}
-    __shared__ uint32_t sU[SGR_BWD_BATCH];
-    __shared__ uint32_t sFlag[SGR_BWD_BATCH];
+    __shared__ float4 sA[BATCH];  // {x, y, -, -}
+    __shared__ float4 sB[BATCH];  // {qa, qb, qc, opacity}
+    __shared__ float4 sC[BATCH];  // {r, g, b, depth}
+    __shared__ uint32_t sU[BATCH];
+    __shared__ uint32_t sFlag[BATCH];
     __shared__ uint64_t sBits[4][4];
     __shared__ int sMax[4];
     // The (up to four) wave partials of an instance meet in LDS with ds_add_f32.  DET: two zero-initialised
@@ -193,8 +299,8 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
     // !DET: a single row shared by all four waves (arrival order can change the last bit, like the reference's
     // atomicAdd).
     constexpr int NROW = DET ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) float sAcc[NROW * SGR_BWD_BATCH * ACCW];
-    __shared__ __attribute__((aligned(16))) float sSem[SMAX > 0 ? SGR_BWD_BATCH * SMAX : 4];  // zero-padded to SMAX
+    __shared__ __attribute__((aligned(16))) float sAcc[NROW * BATCH * ACCW];
+    __shared__ __attribute__((aligned(16))) float sSem[SMAX > 0 ? BATCH * SMAX : 4];  // zero-padded to SMAX
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t tx, ty;
@@ -251,17 +357,22 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
     const int maxc = max(max(sMax[0], sMax[1]), max(sMax[2], sMax[3]));
     const float tx0 = (float)(tx * SGR_BLOCK_X), ty0 = (float)(ty * SGR_BLOCK_Y);
     // LDS row of this lane's 16-lane group inside a slot (see the reduce-scatter layout below)
-    const int acc_lane_off = (DET ? (wave >> 1) : 0) * SGR_BWD_BATCH * ACCW + (lane >> 4);
+    const int acc_lane_off = (DET ? (wave >> 1) : 0) * BATCH * ACCW + (lane >> 4);
+    // folded reduction (sgr_wave_reduce_fold): the bank (4 lanes) this lane sits in holds, in result register i,
+    // float4 number 4i + fold_t0 of the slot's row; its first lane adds it at component lane >> 4
+    const int fold_t0 = (0x3120 >> (((lane >> 2) & 3) * 4)) & 3;  // {0, 2, 1, 3}[bank]
+    const bool fold_leader = (lane & 3) == 0;
+    const int acc_fold_off = (DET ? (wave >> 1) : 0) * BATCH * ACCW + 4 * fold_t0 + (lane >> 4);
 
-    for (int hi = maxc - 1; hi >= 0; hi -= SGR_BWD_BATCH) {
+    for (int hi = maxc - 1; hi >= 0; hi -= BATCH) {
         // slot t of this batch holds list position hi - t (descending: back to front)
         __syncthreads();  // previous batch fully consumed (rows written) before LDS is overwritten
-        const bool stager = tid < SGR_BWD_BATCH;  // whole waves: the batch is a multiple of 64
+        const bool stager = tid < BATCH;  // whole waves: the batch is a multiple of 64
         const int pos = stager ? hi - tid : -1;
         uint32_t mask4 = 0;
         if (stager) sFlag[tid] = 0;
 #pragma unroll
-        for (int row = tid; row < NROW * SGR_BWD_BATCH; row += SGR_TILE_THREADS) {
+        for (int row = tid; row < NROW * BATCH; row += SGR_TILE_THREADS) {
             float4* z = reinterpret_cast<float4*>(&sAcc[row * ACCW]);
 #pragma unroll
             for (int k4 = 0; k4 < ACCW / 4; k4++) z[k4] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -282,7 +393,10 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
 #pragma unroll
                 for (int ch = 0; ch < SMAX; ch++) sSem[tid * SMAX + ch] = ch < S ? semantics[(size_t)g * S + ch] : 0.0f;
             }
-            mask4 = CULL ? sgr_quadrant_mask(a, b, tx0, ty0) : 0xFu;
+            // which quadrants to walk: the forward's record of the quadrants it blended this instance into (exactly the
+            // visits that can contribute; nothing to compute), else the geometric cull the forward uses
+            mask4 = CULL ? (hit4 != nullptr ? (uint32_t)hit4[range.x + (uint32_t)pos] : sgr_quadrant_mask(a, b, tx0, ty0))
+                         : 0xFu;
         }
         if (stager) {
 #pragma unroll
@@ -373,7 +487,17 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                 // LDS row layout: float4 t = values (4t, 4t+2, 4t+1, 4t+3) -- the order the reduce-scatter leaves
                 // them in rows 0..3 of register t; the flush below swaps the middle pair back.
                 float r[NVAL / 4];
-                if (DPP) {
+                if (DPP && SGR_FOLD) {
+                    constexpr int NG = (NVAL / 4 + 3) / 4;
+                    float g[NG];
+                    sgr_wave_reduce_fold<NVAL>(v, g);
+                    float* dst = sAcc + (acc_fold_off + j * ACCW);  // j is wave-uniform: scalar multiply
+#pragma unroll
+                    for (int i = 0; i < NG; i++)
+                        if (fold_leader && 4 * i + fold_t0 < NVAL / 4) atomicAdd(&dst[16 * i], g[i]);
+                    if (lane == 0) sFlag[j] = 1u;
+                    return;
+                } else if (DPP) {
                     sgr_wave_reduce_scatter<NVAL>(v, r);
                 } else {
 #pragma unroll
@@ -393,7 +517,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                     if (k == 0) sFlag[j] = 1u;
                 }
         };
-        for (int chunk = 0; chunk < SGR_BWD_BATCH / 64; chunk++) {
+        for (int chunk = 0; chunk < BATCH / 64; chunk++) {
             uint64_t m = sBits[wave][chunk];
             m = sgr_uniform_u64(m);
             while (m) {
@@ -430,7 +554,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
 #pragma unroll
                 for (int k4 = 0; k4 < NVAL / 4; k4++) r[k4] = src[k4];
                 if (DET) {
-                    const float4* src1 = reinterpret_cast<const float4*>(&sAcc[(SGR_BWD_BATCH + tid) * ACCW]);
+                    const float4* src1 = reinterpret_cast<const float4*>(&sAcc[(BATCH + tid) * ACCW]);
 #pragma unroll
                     for (int k4 = 0; k4 < NVAL / 4; k4++) {
                         const float4 t = src1[k4];
@@ -447,16 +571,17 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
 #define SGR_BWD_ARGS                                                                                                  \
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int S, int gx, int gy,       \
         const float *__restrict__ bg_color, const float4 *__restrict__ rec, const float *__restrict__ semantics,          \
-        const float *__restrict__ alphas, const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpixels,   \
-        const float *__restrict__ dL_dpixel_depths, const float *__restrict__ dL_dalphas,                                  \
+        const float *__restrict__ alphas, const uint32_t *__restrict__ n_contrib, const uint8_t *__restrict__ hit4,        \
+        const float *__restrict__ dL_dpixels, const float *__restrict__ dL_dpixel_depths,                                  \
+        const float *__restrict__ dL_dalphas,                                                                              \
         const float *__restrict__ dL_dpixel_semantics, float *__restrict__ partials, int row_stride,                      \
         uint8_t *__restrict__ touched
 #define SGR_BWD_PASS                                                                                                  \
-    ranges, point_list, W, H, S, gx, gy, bg_color, rec, semantics, alphas, n_contrib, dL_dpixels, dL_dpixel_depths,    \
-        dL_dalphas, dL_dpixel_semantics, partials, row_stride, touched
+    ranges, point_list, W, H, S, gx, gy, bg_color, rec, semantics, alphas, n_contrib, hit4, dL_dpixels,               \
+        dL_dpixel_depths, dL_dalphas, dL_dpixel_semantics, partials, row_stride, touched
 template <int SMAX, bool CULL, bool DPP, bool DET>
 __global__ void __launch_bounds__(SGR_TILE_THREADS) sgr_blend_bwd_kernel(SGR_BWD_ARGS) {
-    sgr_blend_bwd_body<SMAX, CULL, DPP, DET>(SGR_BWD_PASS);
+    sgr_blend_bwd_body<SMAX, CULL, DPP, DET, SgrBwdBatch<SMAX>::value>(SGR_BWD_PASS);
 }
 // S = 0 (the training configuration of the benchmark): 64 VGPRs fit without spilling, so ask for 8 waves / SIMD
 // (hipcc settles at 80 VGPRs = 6 waves otherwise; measured 1.103 -> 1.087 ms).  With semantic channels the register
@@ -464,36 +589,35 @@ __global__ void __launch_bounds__(SGR_TILE_THREADS) sgr_blend_bwd_kernel(SGR_BWD
 template <bool CULL, bool DPP, bool DET>
 __global__ void __launch_bounds__(SGR_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
 sgr_blend_bwd_kernel_s0(SGR_BWD_ARGS) {
-    sgr_blend_bwd_body<0, CULL, DPP, DET>(SGR_BWD_PASS);
+    sgr_blend_bwd_body<0, CULL, DPP, DET, SgrBwdBatch<0>::value>(SGR_BWD_PASS);
 }
 
 template <int SMAX>
 static void launch_bwd(bool cull, bool dpp, bool det, unsigned tiles, hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                        int W, int H, int S, int gx, int gy, const float* bg, const float4* rec, const float* semantics,
                        const float* alphas,
-                       const uint32_t* n_contrib, const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha,
-                       const float* dL_dsem, float* partials, int row_stride, uint8_t* touched) {
-    // the deterministic combine needs 2*256*ACCW floats of LDS: used up to 8 semantic channels (60 KB total)
-    constexpr bool kDet = SMAX <= 8;
+                       const uint32_t* n_contrib, const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth,
+                       const float* dL_dalpha, const float* dL_dsem, float* partials, int row_stride, uint8_t* touched) {
+    constexpr bool kDet = true;  // every instantiation has the two-row deterministic combine (see SgrBwdBatch)
     if (SMAX > 4) { cull = true; dpp = true; }  // the A/B switches (tests) exist for the small instantiations only
 #define SGR_GO(C, D)                                                                                                 \
     do {                                                                                                             \
         if constexpr (SMAX == 0) {                                                                                   \
             if (det)                                                                                                 \
                 sgr_blend_bwd_kernel_s0<C, D, true><<<tiles, SGR_TILE_THREADS, 0, s>>>(                               \
-                    ranges, point_list, W, H, S, gx, gy, bg, rec, semantics, alphas, n_contrib, dL_dpix, dL_ddepth,    \
+                    ranges, point_list, W, H, S, gx, gy, bg, rec, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,    \
                     dL_dalpha, dL_dsem, partials, row_stride, touched);                                               \
             else                                                                                                     \
                 sgr_blend_bwd_kernel_s0<C, D, false><<<tiles, SGR_TILE_THREADS, 0, s>>>(                              \
-                    ranges, point_list, W, H, S, gx, gy, bg, rec, semantics, alphas, n_contrib, dL_dpix, dL_ddepth,    \
+                    ranges, point_list, W, H, S, gx, gy, bg, rec, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,    \
                     dL_dalpha, dL_dsem, partials, row_stride, touched);                                               \
         } else if (kDet && det)                                                                                      \
             sgr_blend_bwd_kernel<SMAX, C, D, kDet><<<tiles, SGR_TILE_THREADS, 0, s>>>(                                \
-                ranges, point_list, W, H, S, gx, gy, bg, rec, semantics, alphas, n_contrib, dL_dpix, dL_ddepth,        \
+                ranges, point_list, W, H, S, gx, gy, bg, rec, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,        \
                 dL_dalpha, dL_dsem, partials, row_stride, touched);                                                   \
         else                                                                                                         \
             sgr_blend_bwd_kernel<SMAX, C, D, false><<<tiles, SGR_TILE_THREADS, 0, s>>>(                               \
-                ranges, point_list, W, H, S, gx, gy, bg, rec, semantics, alphas, n_contrib, dL_dpix, dL_ddepth,        \
+                ranges, point_list, W, H, S, gx, gy, bg, rec, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,        \
                 dL_dalpha, dL_dsem, partials, row_stride, touched);                                                   \
     } while (0)
     if (cull && dpp) SGR_GO(true, true);
@@ -510,13 +634,13 @@ int sgr_partial_row_stride(int S) { return S <= 4 ? 16 : (S <= 20 ? 32 : 48); }
 
 void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
                           int H, int S, const float* bg, const float4* rec, const float* semantics, const float* alphas, const uint32_t* n_contrib,
-                          const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha, const float* dL_dsem,
-                          float* partials, uint8_t* touched, hipStream_t s) {
+                          const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha,
+                          const float* dL_dsem, float* partials, uint8_t* touched, hipStream_t s) {
     if (gx <= 0 || gy <= 0) return;
     const unsigned tiles = sgr_xcd_grid_blocks(gx, gy);  // supertile-ordered grid incl. padding blocks
     const int stride = sgr_partial_row_stride(S);
 #define SGR_BWD(N) launch_bwd<N>(cull, dpp, det, tiles, s, ranges, point_list, W, H, S, gx, gy, bg, rec, semantics, alphas, \
-                                 n_contrib, dL_dpix, dL_ddepth, dL_dalpha, dL_dsem, partials, stride, touched)
+                                 n_contrib, hit4, dL_dpix, dL_ddepth, dL_dalpha, dL_dsem, partials, stride, touched)
     if (S == 0) SGR_BWD(0);
     else if (S <= 4) SGR_BWD(4);
     else if (S <= 8) SGR_BWD(8);

@@ -20,7 +20,8 @@ __global__ void __launch_bounds__(SGR_TILE_THREADS)
 sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int S,
                      int gx, int gy, const float4* __restrict__ rec, const float* __restrict__ semantics,
                      const float* __restrict__ bg_color, float* __restrict__ out_color, float* __restrict__ out_depth,
-                     float* __restrict__ out_alpha, float* __restrict__ out_semantic, uint32_t* __restrict__ n_contrib) {
+                     float* __restrict__ out_alpha, float* __restrict__ out_semantic, uint32_t* __restrict__ n_contrib,
+                     uint8_t* __restrict__ hit4) {
     // fused multiply-adds are written out (fmaf): the CULL / !CULL instantiations must produce bit-identical images
 #pragma clang fp contract(off)
     __shared__ float4 sA[SGR_TILE_THREADS];  // {x, y, -, -}
@@ -28,6 +29,9 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
     __shared__ float4 sC[SGR_TILE_THREADS];  // {r, g, b, depth}
     __shared__ uint64_t sBits[4][4];         // [quadrant][chunk of 64 instances]
     __shared__ uint32_t sDone[4];
+    // [quadrant][chunk]: the instances of the current batch that were blended into >= 1 pixel of the quadrant.  They go
+    // to hit4[] (one byte per sorted instance, bit q = quadrant q); the backward kernel walks exactly those.
+    __shared__ uint64_t sHit[4][4];
     __shared__ __attribute__((aligned(16))) float sSem[SMAX > 0 ? SGR_TILE_THREADS * SMAX : 4];  // zero-padded to SMAX
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -55,11 +59,25 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
     // quadrant bounds (pixel centres) used by the staging lanes for the cull test
     const float tx0 = (float)(tx * SGR_BLOCK_X), ty0 = (float)(ty * SGR_BLOCK_Y);
 
+    // one byte per instance of the batch that starts at list index b0 (after the barrier that follows its walk)
+    auto store_hits = [&](const uint32_t b0) __attribute__((always_inline)) {
+        const uint32_t idx = b0 + (uint32_t)tid;
+        if (hit4 != nullptr && idx < range.y) {
+            const int c = tid >> 6, b = tid & 63;
+            const uint32_t h = (uint32_t)((sHit[0][c] >> b) & 1ull) | ((uint32_t)((sHit[1][c] >> b) & 1ull) << 1) |
+                               ((uint32_t)((sHit[2][c] >> b) & 1ull) << 2) | ((uint32_t)((sHit[3][c] >> b) & 1ull) << 3);
+            hit4[idx] = (uint8_t)h;
+        }
+    };
+    bool pending = false;
+    uint32_t pbase = 0;
     for (uint32_t base = range.x; base < range.y; base += SGR_TILE_THREADS) {
         // tile-wide early exit (forward.cu:394-396); also the barrier that protects LDS reuse
         // (each wave posts "all my pixels are finished"; hipcc's __syncthreads_and is a 20-instruction DPP reduction)
         if (lane == 0) sDone[wave] = (done_mask == ~0ull) ? 1u : 0u;
         __syncthreads();
+        if (pending) store_hits(pbase);  // hit masks of the previous batch (complete: every wave is past its walk)
+        pending = false;
         if (sDone[0] & sDone[1] & sDone[2] & sDone[3]) break;
 
         const uint32_t idx = base + tid;
@@ -84,18 +102,26 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
             if (lane == 0) sBits[q][wave] = m;
         }
         __syncthreads();
+        // this wave's hit masks of the new batch start empty (the reads of the previous batch's are behind the barrier)
+        if (lane < 4) sHit[wave][lane] = 0ull;
+        pending = true;
+        pbase = base;
 
         if (done_mask != ~0ull) {
             const uint32_t pos0 = base - range.x;  // list position of slot 0 of this batch
-            for (int chunk = 0; chunk < 4; chunk++) {
+            bool stop = false;
+            for (int chunk = 0; chunk < 4 && !stop; chunk++) {
                 uint64_t m = sBits[wave][chunk];
                 m = sgr_uniform_u64(m);
+                uint64_t hb = 0;  // wave-uniform (scalar registers)
                 while (m) {
                     // two survivors per trip: their LDS reads and exp() are independent, only the blend is ordered
-                    const int j0 = chunk * 64 + (__ffsll((unsigned long long)m) - 1);
+                    const int b0 = __ffsll((unsigned long long)m) - 1;
+                    const int j0 = chunk * 64 + b0;
                     m &= m - 1;
                     const bool two = m != 0;
-                    const int j1 = two ? chunk * 64 + (__ffsll((unsigned long long)m) - 1) : j0;
+                    const int b1 = two ? (__ffsll((unsigned long long)m) - 1) : b0;
+                    const int j1 = chunk * 64 + b1;
                     m &= m - 1;  // no-op when m == 0
                     const float4 a0 = sA[j0], q0 = sB[j0];
                     const float4 a1 = sA[j1], q1 = sB[j1];
@@ -136,16 +162,23 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                             T = blend ? test_T : T;
                             last = blend ? (pos0 + (uint32_t)j + 1u) : last;
                             const uint64_t sm = hm & __builtin_amdgcn_ballot_w64(k3);
+                            // some lane blended this instance (scalar): the backward has to visit (quadrant, instance)
+                            hb |= (hm != sm) ? (1ull << (u ? b1 : b0)) : 0ull;
                             if (sm != 0) {
                                 thr = (k1 && k2 && k3) ? __builtin_inff() : thr;
                                 done_mask |= sm;
-                                if (done_mask == ~0ull) { m = 0; chunk = 4; }
+                                if (done_mask == ~0ull) { m = 0; stop = true; }
                             }
                         }
                     }
                 }
+                if (lane == 0) sHit[wave][chunk] = hb;
             }
         }
+    }
+    if (pending) {  // the list ended before the tile was finished: the last batch's hit masks are still in LDS
+        __syncthreads();
+        store_hits(pbase);
     }
 
     if (inside) {
@@ -168,26 +201,26 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
 template <int SMAX>
 static void launch_fwd(bool cull, unsigned tiles, hipStream_t s, const uint2* ranges, const uint32_t* point_list, int W,
                        int H, int S, int gx, int gy, const float4* rec, const float* semantics, const float* bg, float* out_color, float* out_depth, float* out_alpha,
-                       float* out_semantic, uint32_t* n_contrib) {
+                       float* out_semantic, uint32_t* n_contrib, uint8_t* hit4) {
     if (cull)
         sgr_blend_fwd_kernel<SMAX, true><<<tiles, SGR_TILE_THREADS, 0, s>>>(ranges, point_list, W, H, S, gx, gy, rec, semantics,
                                                                            bg, out_color, out_depth, out_alpha,
-                                                                           out_semantic, n_contrib);
+                                                                           out_semantic, n_contrib, hit4);
     else
         sgr_blend_fwd_kernel<SMAX, false><<<tiles, SGR_TILE_THREADS, 0, s>>>(ranges, point_list, W, H, S, gx, gy, rec, semantics,
                                                                             bg, out_color, out_depth, out_alpha,
-                                                                            out_semantic, n_contrib);
+                                                                            out_semantic, n_contrib, hit4);
 }
 
 // S must be <= SGR_SEM_MAX (checked by the caller).
 void sgr_launch_blend_fwd(bool cull, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W, int H,
                           int S, const float4* rec, const float* semantics,
                           const float* bg, float* out_color, float* out_depth, float* out_alpha, float* out_semantic,
-                          uint32_t* n_contrib, hipStream_t s) {
+                          uint32_t* n_contrib, uint8_t* hit4, hipStream_t s) {
     if (gx <= 0 || gy <= 0) return;
     const unsigned tiles = sgr_xcd_grid_blocks(gx, gy);  // supertile-ordered grid incl. padding blocks
 #define SGR_FWD(N) launch_fwd<N>(cull, tiles, s, ranges, point_list, W, H, S, gx, gy, rec, semantics, bg, \
-                                 out_color, out_depth, out_alpha, out_semantic, n_contrib)
+                                 out_color, out_depth, out_alpha, out_semantic, n_contrib, hit4)
     if (S == 0) SGR_FWD(0);
     else if (S <= 4) SGR_FWD(4);
     else if (S <= 8) SGR_FWD(8);

@@ -14,7 +14,9 @@
 //     cov3D[6g..], tiles_touched[g], point_offsets[g] (inclusive), clamped[g] (3-bit mask), radii (if not given)
 //   binning buffer: 32-bit tile keys and 32-bit Gaussian ids, ping-pong for the stable LSD radix sort by
 //     tile (the instances are emitted in (depth, id) order, so the reference's 64-bit (tile|depth) key
-//     order falls out of a stable sort on the tile bits alone), plus the per-block digit histograms.
+//     order falls out of a stable sort on the tile bits alone), plus the per-block digit histograms and one
+//     "hit" byte per sorted instance (which quadrants of its tile the forward blended it into: the backward
+//     walks exactly those).
 //   image buffer: n_contrib[H*W], ranges[tiles].
 #pragma once
 #include <hip/hip_runtime.h>
@@ -51,6 +53,7 @@ struct SgrBinView {
     uint32_t* hist;      // [256][nblocks] per-pass digit histogram, exclusive-scanned in place
     uint32_t* scan_tmp;
     uint32_t* header;    // [0]=index (0/1) of the buffer pair holding the sorted result
+    uint8_t* hit4;       // per sorted instance: bit q = the forward blended it into >= 1 pixel of quadrant q of its tile
 };
 
 struct SgrImgView {
@@ -119,6 +122,7 @@ static inline SgrBinView sgr_bin_carve(char* base, size_t R, char** end = nullpt
     sgr_carve(p, v.vals[1], Rn);
     sgr_carve(p, v.hist, nh);
     sgr_carve(p, v.scan_tmp, sgr_scan_tmp_count(nh));
+    sgr_carve(p, v.hit4, Rn);
     if (end) *end = p;
     return v;
 }

@@ -274,9 +274,9 @@ sgr_lidar_err_kernel(int n, const float* __restrict__ depth, const float* __rest
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(&w.state[0], cnt[0] + cnt[1] + cnt[2] + cnt[3]);  // integers: order-independent
 }
-__global__ void sgr_lidar_k_kernel(LdWork w, float keep) {
+__global__ void sgr_lidar_k_kernel(LdWork w, double keep) {
     const uint32_t count = w.state[0];
-    const uint32_t k = (uint32_t)((double)keep * (double)count);  // int(0.95 * depth_error.size(0))
+    const uint32_t k = (uint32_t)(keep * (double)count);  // int(0.95 * depth_error.size(0)): Python float = double
     w.state[1] = k;
     w.state[2] = 0;  // prefix
     w.state[3] = k;  // we look for the k-th smallest (1-based) -> rank k inside the current prefix class
@@ -464,7 +464,7 @@ size_t sgr_lidar_work_bytes(int n) {
 }
 
 int sgr_lidar_depth_forward(int n, const float* depth, const float* acc, const float* lidar_depth, const uint8_t* mask,
-                            float keep, float* out, char* work, void* stream_) {
+                            double keep, float* out, char* work, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n <= 0) return sgr_set_error(SGR_E_INVALID, "n must be positive");
     if (!depth || !acc || !lidar_depth || !out || !work) return sgr_set_error(SGR_E_INVALID, "depth, acc, lidar_depth, out and work are required");

@@ -22,6 +22,15 @@ struct SgrCam {
     float scale_modifier;
 };
 
+// camera of the stand-alone filter kernel (K3): device pointers to the caller's matrices + host-side scalars
+struct SgrCamArgs {
+    const float* view = nullptr;
+    const float* proj = nullptr;
+    float tan_fovx = 0.f, tan_fovy = 0.f, focal_x = 0.f, focal_y = 0.f;
+    int W = 0, H = 0, gx = 0, gy = 0;
+    float scale_modifier = 1.f;
+};
+
 struct SgrProj {
     float depth;       // view-space z
     float px, py;      // pixel-space mean (ndc2Pix)
@@ -176,7 +185,12 @@ SGR_HD void sgr_sh_basis(int deg, float x, float y, float z, float* Y) {
 // sqrt(2*tau*cov_yy) (conic = cov^-1).  Inflated (tau*1.02+0.05, then +1% +0.25 px) so that fp32
 // rounding of `power` in the blend kernels can never accept a pair outside the box; a negative
 // extent means "can never contribute".  NaN opacity yields NaN extents = "never culled".
-SGR_HD void sgr_extent(float opacity, float cov_a, float cov_c, float& hx, float& hy) {
+// The blend kernels evaluate alpha from the CONIC (cov / det with det an fp32 difference a*c - b*b): for huge,
+// nearly degenerate splats cancellation in det can move the conic by more than the slack above, so the box is also
+// derived from the conic itself (half width sqrt(2*tau*conic.z / (conic.x*conic.z - conic.y^2))) and the larger of
+// the two is kept; a conic that is not positive definite in fp32 gives an infinite box (never culled).
+SGR_HD void sgr_extent(float opacity, float cov_a, float cov_c, float con_x, float con_y, float con_z, float& hx,
+                       float& hy) {
     if (opacity < 0.0039f) {  // < 1/255 (with slack): alpha = min(.99, o*G) <= o can never pass
         hx = -1.0f;
         hy = -1.0f;
@@ -184,8 +198,16 @@ SGR_HD void sgr_extent(float opacity, float cov_a, float cov_c, float& hx, float
     }
     float tau = logf(255.0f * opacity);
     tau = fmaxf(tau, 0.0f) * 1.02f + 0.05f;
-    hx = sqrtf(2.0f * tau * cov_a) * 1.01f + 0.25f;
-    hy = sqrtf(2.0f * tau * cov_c) * 1.01f + 0.25f;
+    const float den = con_x * con_z - con_y * con_y;
+    float ex = cov_a, ey = cov_c;
+    if (den > 0.0f && con_x > 0.0f && con_z > 0.0f) {
+        ex = fmaxf(ex, con_z / den);
+        ey = fmaxf(ey, con_x / den);
+    } else {
+        ex = ey = INFINITY;
+    }
+    hx = sqrtf(2.0f * tau * ex) * 1.01f + 0.25f;
+    hy = sqrtf(2.0f * tau * ey) * 1.01f + 0.25f;
 }
 
 // Exact part of the quadrant cull.  tau2 = 2*tau' (same inflation as sgr_extent; negative = never visible).

@@ -17,12 +17,11 @@ __device__ __forceinline__ uint32_t sgr_pack_rect(uint32_t x0, uint32_t y0, uint
 
 // ---- K1 -------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(SGR_PRE_THREADS)
-sgr_mark_visible_kernel(int P, const float* __restrict__ means3D, const SgrCam* __restrict__ camp, uint8_t* __restrict__ present) {
+sgr_mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ v, uint8_t* __restrict__ present) {
 #pragma clang fp contract(off)
-    const SgrCam& cam = *camp;
+    // v = the caller's viewmatrix (device): in_frustum only needs its third column (auxiliary.h:139-164)
     const int idx = blockIdx.x * SGR_PRE_THREADS + threadIdx.x;
     if (idx >= P) return;
-    const float* v = cam.view;
     const float x = means3D[3 * idx], y = means3D[3 * idx + 1], z = means3D[3 * idx + 2];
     const float tz = v[2] * x + v[6] * y + v[10] * z + v[14];
     present[idx] = tz <= 0.2f ? 0 : 1;
@@ -133,7 +132,7 @@ sgr_preprocess_one(const int idx, int D, int M, const float* __restrict__ means3
 
     const float opacity = opacities[idx];
     float hx, hy;
-    sgr_extent(opacity, pr.cov_a, pr.cov_c, hx, hy);
+    sgr_extent(opacity, pr.cov_a, pr.cov_c, pr.con_x, pr.con_y, pr.con_z, hx, hy);
     const uint32_t w = pr.rx1 - pr.rx0, h = pr.ry1 - pr.ry0;
     float4* rec = gv.rec + 4 * (size_t)idx;
     rec[0] = make_float4(pr.px, pr.py, hx, hy);
@@ -155,13 +154,26 @@ sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       const float* __restrict__ rotations, const float* __restrict__ opacities,
                       const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
                       const float* __restrict__ colors_precomp, const SgrCam* __restrict__ camp, SgrGeomView gv,
-                      int* __restrict__ radii, float* __restrict__ filter_means2D, int prefiltered) {
+                      int* __restrict__ radii, float* __restrict__ filter_means2D, int prefiltered, SgrCamArgs ca) {
     const int idx = blockIdx.x * SGR_PRE_THREADS + threadIdx.x;
     uint32_t n = 0;
+    if (FILTER) {
+        // K3 has no geometry buffer to keep a packed camera in: the matrices are read from the caller's device arrays
+        // (wave-uniform addresses: scalar loads), the scalars travel as kernel arguments -- no allocation, no sync
+        SgrCam cam;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { cam.view[i] = ca.view[i]; cam.proj[i] = ca.proj[i]; }
+        cam.campos[0] = cam.campos[1] = cam.campos[2] = 0.f;
+        cam.tan_fovx = ca.tan_fovx; cam.tan_fovy = ca.tan_fovy; cam.focal_x = ca.focal_x; cam.focal_y = ca.focal_y;
+        cam.W = ca.W; cam.H = ca.H; cam.gx = ca.gx; cam.gy = ca.gy; cam.scale_modifier = ca.scale_modifier;
+        if (idx < P)
+            sgr_preprocess_one<true>(idx, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
+                                     cam, gv, radii, filter_means2D, prefiltered);
+        return;
+    }
     if (idx < P)
         n = sgr_preprocess_one<FILTER>(idx, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
                                        *camp, gv, radii, filter_means2D, prefiltered);
-    if (FILTER) return;
     // device-scope atomics on one address are resolved beyond the per-XCD L2s (~6 ns each, serialised): one per
     // workgroup, not one per wave (16k of them cost 0.1 ms at P = 1M)
     __shared__ uint32_t wave_sum[SGR_PRE_THREADS / 64];
@@ -272,9 +284,10 @@ sgr_compose_keys_kernel(int L, const uint32_t* __restrict__ tile_keys, const uin
 }
 
 // ---- host launchers ---------------------------------------------------------------------------
-void sgr_launch_mark_visible(int P, const float* means3D, const SgrCam* cam, uint8_t* present, hipStream_t s) {
+void sgr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s) {
     if (P <= 0) return;
-    sgr_mark_visible_kernel<<<(P + SGR_PRE_THREADS - 1) / SGR_PRE_THREADS, SGR_PRE_THREADS, 0, s>>>(P, means3D, cam, present);
+    sgr_mark_visible_kernel<<<(P + SGR_PRE_THREADS - 1) / SGR_PRE_THREADS, SGR_PRE_THREADS, 0, s>>>(P, means3D, viewmatrix,
+                                                                                                 present);
 }
 
 void sgr_launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, const float* rotations,
@@ -284,16 +297,16 @@ void sgr_launch_preprocess(int P, int D, int M, const float* means3D, const floa
     if (P <= 0) return;
     sgr_preprocess_kernel<false><<<(P + SGR_PRE_THREADS - 1) / SGR_PRE_THREADS, SGR_PRE_THREADS, 0, s>>>(
         P, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, cam, gv, radii, nullptr,
-        prefiltered);
+        prefiltered, SgrCamArgs{});
 }
 
 void sgr_launch_filter(int P, const float* means3D, const float* scales, const float* rotations,
-                       const float* cov3D_precomp, const SgrCam* cam, const SgrGeomView& gv, int* radii,
+                       const float* cov3D_precomp, const SgrCamArgs& ca, const SgrGeomView& gv, int* radii,
                        float* means2D, int prefiltered, hipStream_t s) {
     if (P <= 0) return;
     sgr_preprocess_kernel<true><<<(P + SGR_PRE_THREADS - 1) / SGR_PRE_THREADS, SGR_PRE_THREADS, 0, s>>>(
-        P, 0, 0, means3D, scales, rotations, nullptr, nullptr, cov3D_precomp, nullptr, cam, gv, radii, means2D,
-        prefiltered);
+        P, 0, 0, means3D, scales, rotations, nullptr, nullptr, cov3D_precomp, nullptr, nullptr, gv, radii, means2D,
+        prefiltered, ca);
 }
 
 void sgr_launch_gather_tiles(int P, const uint32_t* order, const uint32_t* tiles_touched, uint32_t* tt_sorted,

@@ -35,7 +35,7 @@ void hm_forward(int P, int D, int M, const float* means, const float* scales, co
         tiles[i] = (pr.rx1 - pr.rx0) * (pr.ry1 - pr.ry0);
         means2D[2 * i] = pr.px; means2D[2 * i + 1] = pr.py;
         conic[3 * i] = pr.con_x; conic[3 * i + 1] = pr.con_y; conic[3 * i + 2] = pr.con_z;
-        sgr_extent(opac[i], pr.cov_a, pr.cov_c, extents[2 * i], extents[2 * i + 1]);
+        sgr_extent(opac[i], pr.cov_a, pr.cov_c, pr.con_x, pr.con_y, pr.con_z, extents[2 * i], extents[2 * i + 1]);
         // SH colour exactly as sgr_preprocess_kernel does it
         float dx = means[3 * i] - cam.campos[0], dy = means[3 * i + 1] - cam.campos[1], dz = means[3 * i + 2] - cam.campos[2];
         const float len = sqrtf(dx * dx + dy * dy + dz * dz);

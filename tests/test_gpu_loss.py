@@ -77,6 +77,18 @@ def test_lidar_selection_edge_cases():
     assert float(d.grad.sum()) == pytest.approx(1.0, rel=1e-5)  # d(mean)/d(errors) sums to one whichever ties are kept
 
 
+def test_lidar_topk_count_is_python_int_of_double_product():
+    """train.py:128 takes int(0.95 * n) in double: for n = 100 that is 95 (0.95f * 100 would truncate to 94).  With the
+    errors 1..100 the mean of the 95 smallest is 48, of the 94 smallest 47.5."""
+    for n, k in ((100, 95), (20, 19), (40, 38), (2000, 1900)):
+        err = torch.arange(1, n + 1, dtype=torch.float32, device="cuda")[torch.randperm(n, device="cuda")]
+        depth = (err + 10.0).reshape(1, 1, n)
+        lidar = torch.full((1, 1, n), 10.0, device="cuda")
+        l = losses.lidar_depth_loss(depth, torch.ones_like(depth), lidar, None)
+        assert int(0.95 * n) == k
+        assert l.item() == pytest.approx((k + 1) / 2.0, rel=1e-6), (n, l.item())
+
+
 def test_loss_argument_checks():
     from street_gaussians_amd._native import SgrError
     x = torch.rand(3, 8, 8, device="cuda")
