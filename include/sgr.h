@@ -104,7 +104,7 @@ int sgr_partial_row_floats(int S);
 
 /* ---- per-stage timing with HIP events recorded on the caller's stream (bench.py's roofline leg) ---------------
  * stages: 0 preprocess 1 scan 2 duplicate 3 sort 4 tile_ranges 5 blend_fwd 6 partials memset 7 blend_bwd
- * 8 gauss_bwd.  sgr_profile_read sums the durations (ms) of the up-to-512 stage executions recorded since
+ * 8 gauss_bwd.  sgr_profile_read sums the durations (ms) of the up-to-4096 stage executions recorded (by any host thread) since
  * sgr_profile_enable(1), writes 9 sums + 9 counts, resets the recorder and returns the number of records. */
 int sgr_profile_enable(int on);
 int sgr_profile_read(double* sum_ms, int* counts);
@@ -112,7 +112,9 @@ int sgr_profile_read(double* sum_ms, int* counts);
 /* ---- introspection for parity tests: copies one internal array, densely packed, to dst (device). -------------
  * which: 0 depths f32[P] | 1 clamped u8[3P] | 2 means2D f32[2P] | 3 cov3D f32[6P] | 4 conic_opacity f32[4P]
  *        5 rgb f32[3P] | 6 tiles_touched u32[P] | 7 point_offsets u32[P] | 8 point_list u32[R]
- *        9 sorted keys u64[R] | 12 ranges u32[2T] | 13 n_contrib u32[H*W] | 14 extents f32[2P]          */
+ *        9 sorted keys u64[R] | 12 ranges u32[2T] | 13 n_contrib u32[H*W] | 14 extents f32[2P]
+ *        15 hit record u8[R] (bit q: the forward blended the instance into quadrant q of its tile; entries behind the
+ *           last batch a tile processed are undefined)                                                     */
 int sgr_export_internal(int which, int P, int R, int width, int height, char* geom_buffer, char* binning_buffer,
                         char* image_buffer, void* dst, void* stream);
 

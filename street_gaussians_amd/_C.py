@@ -200,7 +200,7 @@ _EXPORT = {"depths": (0, torch.float32, lambda P, R, N, T: (P,)), "clamped": (1,
            "tiles_touched": (6, torch.int32, lambda P, R, N, T: (P,)), "point_offsets": (7, torch.int32, lambda P, R, N, T: (P,)),
            "point_list": (8, torch.int32, lambda P, R, N, T: (R,)), "keys": (9, torch.int64, lambda P, R, N, T: (R,)),
            "ranges": (12, torch.int32, lambda P, R, N, T: (T, 2)), "n_contrib": (13, torch.int32, lambda P, R, N, T: (N,)),
-           "extents": (14, torch.float32, lambda P, R, N, T: (P, 2))}
+           "extents": (14, torch.float32, lambda P, R, N, T: (P, 2)), "hits": (15, torch.uint8, lambda P, R, N, T: (R,))}
 
 
 def masked_color_grad(geomBuffer, grad_colors, P):

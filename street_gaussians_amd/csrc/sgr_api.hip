@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <string>
 
 #include "../../include/sgr.h"
@@ -26,12 +27,6 @@ void sgr_launch_duplicate(int P, const SgrGeomView& gv, const uint32_t* order, c
 void sgr_launch_tile_ranges(int L, const uint32_t* keys, uint2* ranges, hipStream_t s);
 void sgr_launch_compose_keys(int L, const uint32_t* tile_keys, const uint32_t* point_list, const float4* rec, uint64_t* out,
                              hipStream_t s);
-int sgr_launch_sort_pairs32(uint32_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
-                            uint32_t* scan_tmp, hipStream_t s);
-void sgr_launch_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, bool inclusive, hipStream_t s,
-                     uint32_t* total_out = nullptr);
-int sgr_launch_sort_pairs(uint64_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
-                          uint32_t* scan_tmp, hipStream_t s);
 void sgr_launch_blend_fwd(bool cull, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W, int H,
                           int S, const float4* rec, const float* semantics, const float* bg, float* out_color,
                           float* out_depth, float* out_alpha, float* out_semantic, uint32_t* n_contrib, uint8_t* hit4,
@@ -65,7 +60,6 @@ static bool env_flag(const char* name) {
 // 2 no deterministic LDS combine, 3 backward ignores the forward's hit record.  Process-wide, set through
 // sgr_test_switches(); the environment (SGR_NO_CULL / SGR_NO_DPP / SGR_NO_DET / SGR_NO_HITS) only provides the
 // initial value, read ONCE -- the per-step path is one relaxed atomic load, no getenv.
-#include <atomic>
 static std::atomic<int> g_switches{-1};
 static int switches() {
     int v = g_switches.load(std::memory_order_relaxed);
@@ -81,24 +75,32 @@ static int switches() {
 // stages: 0 preprocess(+camera pack, memsets) 1 depth sort + scan 2 duplicate 3 tile sort 4 tile_ranges 5 blend_fwd
 //         6 partials memset 7 blend_bwd 8 gauss_bwd
 #define SGR_PROF_STAGES 9
-#define SGR_PROF_SLOTS 512
+#define SGR_PROF_SLOTS 4096
+// One process-wide recorder: the forward runs on the caller's thread and the backward on autograd's, and both must land
+// in the same recording.  Slots are claimed with an atomic counter (each thread records only into slots it claimed);
+// enable / read are called by the measuring thread while no step is in flight.
 struct SgrProf {
-    bool on = false;
-    int n = 0;  // recorded (begin,end) pairs
+    std::atomic<bool> on{false};
+    std::atomic<int> n{0};  // claimed (begin, end) slots
     hipEvent_t ev[SGR_PROF_SLOTS][2];
     int stage[SGR_PROF_SLOTS];
     bool created = false;
 };
-static thread_local SgrProf g_prof;  // per host thread: a recorder belongs to the thread (and device) that enabled it
+static SgrProf g_prof;
+static thread_local int t_prof_slot = -1;  // slot opened by prof_begin on this thread
 static void prof_begin(int stage, hipStream_t s) {
-    if (!g_prof.on || g_prof.n >= SGR_PROF_SLOTS) return;
-    g_prof.stage[g_prof.n] = stage;
-    (void)hipEventRecord(g_prof.ev[g_prof.n][0], s);
+    t_prof_slot = -1;
+    if (!g_prof.on.load(std::memory_order_relaxed)) return;
+    const int i = g_prof.n.fetch_add(1, std::memory_order_relaxed);
+    if (i >= SGR_PROF_SLOTS) return;
+    g_prof.stage[i] = stage;
+    (void)hipEventRecord(g_prof.ev[i][0], s);
+    t_prof_slot = i;
 }
 static void prof_end(hipStream_t s) {
-    if (!g_prof.on || g_prof.n >= SGR_PROF_SLOTS) return;
-    (void)hipEventRecord(g_prof.ev[g_prof.n][1], s);
-    g_prof.n++;
+    if (t_prof_slot < 0) return;
+    (void)hipEventRecord(g_prof.ev[t_prof_slot][1], s);
+    t_prof_slot = -1;
 }
 
 static int fail(int code, const std::string& msg) {
@@ -268,8 +270,8 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     prof_begin(1, stream);
     const int dcur = sgr_launch_sort_pairs32(gv.dkeys, gv.dvals, (uint32_t)P, 32, gv.dhist, gv.scan_tmp, stream);
     const uint32_t* order = gv.dvals[dcur];
-    sgr_launch_gather_tiles(P, order, gv.tiles_touched, gv.tt_sorted, stream);
-    sgr_launch_scan(gv.tt_sorted, gv.tt_sorted, (size_t)P, gv.scan_tmp, true, stream);
+    // tiles_touched is read through `order` inside the scan (no gathered copy, one launch less)
+    sgr_launch_scan(gv.tiles_touched, gv.tt_sorted, (size_t)P, gv.scan_tmp, true, stream, nullptr, order);
     SGR_STAGE("depth_sort+scan");
     prof_end(stream);
     // The window between "R is known" and "the GPU runs out of queued work" is only the ~0.12 ms of sort + scan
@@ -434,8 +436,8 @@ int sgr_profile_enable(int on) {
                 if (hipEventCreate(&g_prof.ev[i][k]) != hipSuccess) return fail(SGR_E_HIP, "hipEventCreate failed");
         g_prof.created = true;
     }
-    g_prof.on = on != 0;
-    g_prof.n = 0;
+    g_prof.n.store(0);
+    g_prof.on.store(on != 0);
     return 0;
 }
 
@@ -444,14 +446,14 @@ int sgr_profile_read(double* sum_ms, int* counts) {
     for (int i = 0; i < SGR_PROF_STAGES; i++) { sum_ms[i] = 0.0; counts[i] = 0; }
     if (!g_prof.created) return 0;
     SGR_HIP(hipDeviceSynchronize());
-    for (int i = 0; i < g_prof.n; i++) {
+    const int n = std::min(g_prof.n.load(), SGR_PROF_SLOTS);
+    for (int i = 0; i < n; i++) {
         float ms = 0.f;
-        SGR_HIP(hipEventElapsedTime(&ms, g_prof.ev[i][0], g_prof.ev[i][1]));
+        if (hipEventElapsedTime(&ms, g_prof.ev[i][0], g_prof.ev[i][1]) != hipSuccess) continue;  // slot never closed
         sum_ms[g_prof.stage[i]] += ms;
         counts[g_prof.stage[i]]++;
     }
-    const int n = g_prof.n;
-    g_prof.n = 0;
+    g_prof.n.store(0);
     return n;
 }
 
@@ -561,9 +563,10 @@ int sgr_export_internal(int which, int P, int R, int width, int height, char* ge
         SGR_STAGE("export");
         return 0;
     }
-    if (which == 8 || which == 9) {
+    if (which == 8 || which == 9 || which == 15) {
         if (R <= 0) return 0;
         const SgrBinView bv = sgr_bin_carve(binning_buffer, (size_t)R);
+        if (which == 15) { SGR_HIP(hipMemcpyAsync(dst, bv.hit4, (size_t)R, hipMemcpyDeviceToDevice, stream)); return 0; }
         const int cur = sorted_index(width, height);
         if (which == 8) {
             SGR_HIP(hipMemcpyAsync(dst, bv.vals[cur], (size_t)R * 4, hipMemcpyDeviceToDevice, stream));

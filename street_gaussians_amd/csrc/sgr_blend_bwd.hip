@@ -19,15 +19,19 @@
 
 #define SGR_TILE_THREADS 256
 typedef float sgr_f2 __attribute__((ext_vector_type(2)));
-// list entries staged in LDS per round.  128 (not 256) keeps the workgroup at 20 KB of LDS so that occupancy is set by
-// registers (5 waves / SIMD) instead of LDS (4): measured +11 % time at 3 workgroups / CU vs 4.  With more than 8
-// semantic channels the rows are 32+ floats wide and the two-row deterministic combine would need 49-68 KB at 128
-// entries, so those instantiations stage 64 entries per round (24-34 KB): every instantiation is deterministic.
+// list entries staged in LDS per round.  128 (not 256) keeps the S = 0 workgroup at 20 KB of LDS so that occupancy is
+// set by registers instead of LDS: measured +11 % time at 3 workgroups / CU vs 4.  The instantiations with many
+// semantic channels have wide rows (two 128 x 32-float row sets = 33 KB at 20 channels) but are limited to 2-3 waves
+// per SIMD by their registers anyway, so they stage 128 entries as well (64-entry rounds measured 6 % slower at
+// 2 M Gaussians + 19 channels); every instantiation has the deterministic two-row combine.
 #ifndef SGR_BWD_BATCH
 #define SGR_BWD_BATCH 128
 #endif
+#ifndef SGR_BWD_BATCH_WIDE
+#define SGR_BWD_BATCH_WIDE 128
+#endif
 template <int SMAX>
-struct SgrBwdBatch { static constexpr int value = SMAX <= 8 ? SGR_BWD_BATCH : 64; };
+struct SgrBwdBatch { static constexpr int value = SMAX <= 8 ? SGR_BWD_BATCH : SGR_BWD_BATCH_WIDE; };
 #define SGR_ROW_BASE 11
 // 1: folded row stage of the wave reduction (7 DPP adds + 1 LDS add per hit at S = 0), 0: four row steps per register
 #ifndef SGR_FOLD
@@ -269,6 +273,15 @@ void sgr_launch_wave_sum_test(const float* in, float* out_dpp, float* out_shfl, 
     sgr_wave_sum_test_kernel<<<nwaves, 64, 0, s>>>(in, out_dpp, out_shfl);
 }
 
+// __syncthreads() preceded by an explicit LDS drain.  hipcc (ROCm 7.2, gfx950) emits the post-walk barrier of this
+// kernel as a bare s_barrier at a branch target: the last trip's ds_add_f32 / ds_write_b32 of a wave may still be in
+// flight when the other waves are released and flush the rows (seen on MI355X as a rare wrong row with 64-entry
+// rounds; every other barrier of the library has hipcc's own s_waitcnt lgkmcnt(0) in front of it).
+__device__ __forceinline__ void sgr_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 template <int SMAX, bool CULL, bool DPP, bool DET, int BATCH>
 __device__ __forceinline__ void
 sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int S,
@@ -353,7 +366,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
     if (lane == 0) sMax[wave] = mx;
-    __syncthreads();
+    sgr_lds_barrier();
     const int maxc = max(max(sMax[0], sMax[1]), max(sMax[2], sMax[3]));
     const float tx0 = (float)(tx * SGR_BLOCK_X), ty0 = (float)(ty * SGR_BLOCK_Y);
     // LDS row of this lane's 16-lane group inside a slot (see the reduce-scatter layout below)
@@ -366,7 +379,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
 
     for (int hi = maxc - 1; hi >= 0; hi -= BATCH) {
         // slot t of this batch holds list position hi - t (descending: back to front)
-        __syncthreads();  // previous batch fully consumed (rows written) before LDS is overwritten
+        sgr_lds_barrier();  // previous batch fully consumed (rows written) before LDS is overwritten
         const bool stager = tid < BATCH;  // whole waves: the batch is a multiple of 64
         const int pos = stager ? hi - tid : -1;
         uint32_t mask4 = 0;
@@ -405,7 +418,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                 if (lane == 0) sBits[q][wave] = m;
             }
         }
-        __syncthreads();
+        sgr_lds_barrier();
 
         auto process = [&](const int j, const float4 q, const float dx, const float dy, const float power2, const float G,
                            const float alpha, const bool valid) __attribute__((always_inline)) {
@@ -539,7 +552,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                 process(j1, q1, dx1, dy1, pw1, G1, al1, two);
             }
         }
-        __syncthreads();
+        sgr_lds_barrier();
         // one row per touched (tile, instance): plain stores, written exactly once
         const uint32_t flags = stager ? sFlag[tid] : 0u;
         if (flags) {

@@ -145,6 +145,18 @@ static inline size_t sgr_required(F carve) {
 }
 
 #ifdef __HIPCC__
+// ---- primitives shared by several translation units (defined in sgr_scan_sort.hip); declared HERE only, so a changed
+// signature cannot leave a stale copy behind in another file --------------------------------------------------------
+// device-wide scan: out may alias in; tmp needs sgr_scan_tmp_count(n) words; tmp[nblocks] (and *total_out) receive the
+// grand total; gather != nullptr scans in[gather[i]] instead of in[i]
+void sgr_launch_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, bool inclusive, hipStream_t s,
+                     uint32_t* total_out = nullptr, const uint32_t* gather = nullptr);
+// stable LSD radix sorts on key bits [0, end_bit); return the index (0/1) of the buffer pair holding the result
+int sgr_launch_sort_pairs(uint64_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
+                          uint32_t* scan_tmp, hipStream_t s);
+int sgr_launch_sort_pairs32(uint32_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
+                            uint32_t* scan_tmp, hipStream_t s);
+
 // XCD-aware workgroup -> tile map.  The dispatcher places workgroup b on XCD b % 8 (observed, used for speed only),
 // and each XCD has a private 4 MiB L2.  A splat's instances live in neighbouring tiles, so neighbouring tiles
 // should share an L2: workgroups are handed out in 8x8-tile supertiles (128x128 px), supertile k going to XCD

@@ -16,8 +16,6 @@
 #include "sgr_common.h"
 
 int sgr_set_error(int code, const std::string& msg);
-void sgr_launch_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, bool inclusive, hipStream_t s,
-                     uint32_t* total_out = nullptr);
 
 #define DN_HIP(call)                                                                                       \
     do {                                                                                                   \

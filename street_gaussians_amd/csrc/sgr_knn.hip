@@ -12,8 +12,6 @@
 
 #define SGR_KNN_BOX 1024  // simple_knn.cu:12
 
-int sgr_launch_sort_pairs(uint64_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
-                          uint32_t* scan_tmp, hipStream_t s);
 
 struct SgrBox { float mn[3], mx[3]; };
 

@@ -12,8 +12,6 @@
 // lanes is the stable rank) and per-wave LDS digit counters -- no atomics, fully deterministic.
 #include "sgr_common.h"
 
-void sgr_launch_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, bool inclusive, hipStream_t s,
-                     uint32_t* total_out = nullptr);
 
 // ------------------------------------------------------------------------------------------------
 // wave / block primitives
@@ -41,14 +39,17 @@ __device__ __forceinline__ uint32_t sgr_block_excl_scan256(uint32_t v, uint32_t*
 
 // ------------------------------------------------------------------------------------------------
 // scan kernels: ITEMS = 2048 per block = 256 threads x 8 consecutive elements
+// gather != nullptr: element i of the scanned sequence is in[gather[i]] (the forward scans tiles_touched in depth
+// order without materialising the permuted array)
 __global__ void __launch_bounds__(256) sgr_scan_reduce_kernel(const uint32_t* __restrict__ in, size_t n,
-                                                              uint32_t* __restrict__ block_sums) {
+                                                              uint32_t* __restrict__ block_sums,
+                                                              const uint32_t* __restrict__ gather) {
     __shared__ uint32_t lds4[4];
     const size_t base = (size_t)blockIdx.x * SGR_SCAN_ITEMS + (size_t)threadIdx.x * 8;
     uint32_t s = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++)
-        if (base + i < n) s += in[base + i];
+        if (base + i < n) s += gather ? in[gather[base + i]] : in[base + i];
     uint32_t total;
     sgr_block_excl_scan256(s, lds4, total);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
@@ -75,14 +76,15 @@ __global__ void __launch_bounds__(256) sgr_scan_spine_kernel(uint32_t* __restric
 
 template <bool INCLUSIVE>
 __global__ void __launch_bounds__(256) sgr_scan_final_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                             size_t n, const uint32_t* __restrict__ block_sums) {
+                                                             size_t n, const uint32_t* __restrict__ block_sums,
+                                                             const uint32_t* __restrict__ gather) {
     __shared__ uint32_t lds4[4];
     const size_t base = (size_t)blockIdx.x * SGR_SCAN_ITEMS + (size_t)threadIdx.x * 8;
     uint32_t v[8];
     uint32_t s = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        v[i] = (base + i < n) ? in[base + i] : 0;
+        v[i] = (base + i < n) ? (gather ? in[gather[base + i]] : in[base + i]) : 0;
         s += v[i];
     }
     uint32_t total;
@@ -98,14 +100,14 @@ __global__ void __launch_bounds__(256) sgr_scan_final_kernel(const uint32_t* __r
 // out may alias in.  tmp needs sgr_scan_tmp_count(n) words; tmp[nblocks] receives the grand total, and so does
 // *total_out when given.
 void sgr_launch_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, bool inclusive, hipStream_t s,
-                     uint32_t* total_out) {
+                     uint32_t* total_out, const uint32_t* gather) {
     if (n == 0) return;
     const size_t nb = (n + SGR_SCAN_ITEMS - 1) / SGR_SCAN_ITEMS;
 
-    sgr_scan_reduce_kernel<<<(unsigned)nb, 256, 0, s>>>(in, n, tmp);
+    sgr_scan_reduce_kernel<<<(unsigned)nb, 256, 0, s>>>(in, n, tmp, gather);
     sgr_scan_spine_kernel<<<1, 256, 0, s>>>(tmp, nb, total_out);
-    if (inclusive) sgr_scan_final_kernel<true><<<(unsigned)nb, 256, 0, s>>>(in, out, n, tmp);
-    else sgr_scan_final_kernel<false><<<(unsigned)nb, 256, 0, s>>>(in, out, n, tmp);
+    if (inclusive) sgr_scan_final_kernel<true><<<(unsigned)nb, 256, 0, s>>>(in, out, n, tmp, gather);
+    else sgr_scan_final_kernel<false><<<(unsigned)nb, 256, 0, s>>>(in, out, n, tmp, gather);
 }
 
 // ------------------------------------------------------------------------------------------------
