@@ -17,12 +17,17 @@ all-reduced and the SH gradient, which is rank-1 per view, is rebuilt on every r
 dRGB; `--reduce bucket` all-reduces everything as one flat bucket).  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline     -- the dominant kernel (blend backward): algorithmic bytes per launch (SURVEY.md 8d B_blend_b)
-                  divided by its mean duration measured with HIP events on the launch stream (sgr_profile_*),
-                  against the 8 TB/s HBM peak; "stages_ms" lists every stage, "pairs_per_s" the honest unit for
-                  this ALU/LDS-bound kernel.
-  cpu_baseline -- the C oracle (a line-by-line port of the reference algorithm; the reference has no CPU path)
-                  on the host's cores, on a bounded sample of the same workload.
+  roofline      -- the dominant kernel (blend backward): algorithmic bytes per launch (SURVEY.md 8d B_blend_b)
+                   divided by its mean duration measured with HIP events on the launch stream INSIDE the timed region
+                   (sgr_profile_*; only that kernel is bracketed there, two events per step), against the 8 TB/s HBM
+                   peak.  "stages_ms" (every stage) comes from a short extra pass after the timed region.
+                   "traffic" is the rocprofv3 PMC figure of profiles/pmc_blend_bwd.json and is printed only when that
+                   file was measured on the kernel sources this build was compiled from.
+  sustained     -- (N = 1) an extra region of >= 1 s of back-to-back steps when the K timed steps were shorter.
+  other_configs -- (N = 1) BASELINE.json's other single-GPU configurations on the same build: 500 k, 2 M + 19
+                   semantic channels, 5 M Gaussians (ms/step, R, V, blend kernel times).
+  cpu_baseline  -- the C oracle (a line-by-line port of the reference algorithm; the reference has no CPU path)
+                   on the host's cores (all of them, and one), on a bounded sample of the same workload.
 """
 import argparse
 import ctypes as C
@@ -47,8 +52,8 @@ STAGES = ["preprocess", "scan", "duplicate", "sort", "tile_ranges", "blend_fwd",
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1280)
@@ -61,6 +66,9 @@ def parse():
                          "of everything (236 B/Gaussian)")
     ap.add_argument("--step-times", action="store_true", help="debug: also print 10 individually synchronised steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the 500k / 2M+S19 / 5M runs (N = 1 only)")
+    ap.add_argument("--scene", default=None, help="a scene PLY in the reference's layout (street_gaussian_model.py:94-117, "
+                    "read with street_gaussians_amd.plyio) to render instead of the synthetic Gaussians")
     ap.add_argument("--cpu-sample-gaussians", type=int, default=0, help="override the CPU sample size")
     return ap.parse_args()
 
@@ -91,29 +99,59 @@ def cpu_baseline(args, cam, sc):
         return best, R
 
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     Ws, Hs = max(16, args.width // 4), max(16, args.height // 4)
     small = syn.make_camera(Ws, Hs, fx=args.width / (2.0 * cam.tanfovx))
     t_small, R_small = run(Ws, Hs, small, 2)
+    # one thread (SURVEY 8d asks for both): the central 1/64 window, so that it stays within ~10 s
+    one = None
+    try:
+        gomp = C.CDLL("libgomp.so.1")
+        W1, H1 = max(16, args.width // 8), max(16, args.height // 8)
+        c1 = syn.make_camera(W1, H1, fx=args.width / (2.0 * cam.tanfovx))
+        gomp.omp_set_num_threads(1)
+        try:
+            t1, R1 = run(W1, H1, c1, 1)
+        finally:
+            gomp.omp_set_num_threads(cores)
+        one = {"seconds": round(t1, 3), "sample": f"central {W1}x{H1} window = 1/64 of the pixels (R={R1}), all {sc.P} "
+                                                   "Gaussians preprocessed", "cores": 1,
+               "full_frame_iters_per_s_estimate": round(1.0 / (64.0 * t1), 5)}
+    except Exception as ex:
+        one = {"error": str(ex)[:120]}
     if 16.0 * t_small <= 30.0:  # the whole frame fits the budget: report the real thing
         t_full, R_full = run(args.width, args.height, cam, 2)
-        return {"value": round(1.0 / t_full, 4), "unit": "iters/s", "cores": cores, "kind": "port",
+        return {"value": round(1.0 / t_full, 4), "unit": "iters/s", "cores": cores, "cpu_model": model, "kind": "port",
                 "sample": f"oracle fwd+bwd (OpenMP), the full workload: all {sc.P} Gaussians, {args.width}x{args.height} "
                           f"(R={R_full}), best of 2", "seconds": round(t_full, 3),
-                "window_1_16_seconds": round(t_small, 3)}
-    return {"value": round(1.0 / t_small, 4), "unit": "iters/s on the sample", "cores": cores, "kind": "port",
+                "window_1_16_seconds": round(t_small, 3), "one_thread": one}
+    return {"value": round(1.0 / t_small, 4), "unit": "iters/s on the sample", "cores": cores, "cpu_model": model,
+            "kind": "port",
             "sample": f"oracle fwd+bwd (OpenMP), all {sc.P} Gaussians, central {Ws}x{Hs} window = 1/16 of the "
                       f"{args.width}x{args.height} pixels (R={R_small}); full-frame rate ~ value/16",
-            "seconds": round(t_small, 3)}
+            "seconds": round(t_small, 3), "one_thread": one}
 
 
 def reference_kernels_on_gpu(args, cam, sc):
     """Times the reference's OWN kernels (untouched CUDA sources compiled for gfx950, oracle/_ref) on this GPU at
     the same workload: the most meaningful speed-up denominator.  Test infrastructure used as a
-    reported baseline only; skipped when the .so did not travel.  Its scratch buffers are hipMalloc'ed per call
-    (the reference's torch glue would use the caching allocator), so the best of several runs is reported."""
+    reported baseline only; skipped when the .so did not travel.  Its three scratch buffers come from a pool that is
+    warmed by the first call (ref_set_pooled: what torch's caching allocator does for the reference's own glue), so
+    the timed calls contain no hipMalloc / hipFree; best of 4."""
     from oracle import ref
     if not ref.available():
         return None
+    pooled = hasattr(ref.lib(), "ref_set_pooled")
+    if pooled:
+        ref.lib().ref_set_pooled(1)
     d = lambda t: t.detach().to("cuda").contiguous()  # inputs resident in HBM, like the timed HIP path
     w = {k: d(v) for k, v in syn.loss_weights(cam, S=0).items()}
     kw = dict(means3D=d(sc.means3D), opacities=d(sc.opacities), viewmatrix=d(cam.viewmatrix),
@@ -121,7 +159,7 @@ def reference_kernels_on_gpu(args, cam, sc):
               tanfovy=cam.tanfovy, image_height=cam.image_height, image_width=cam.image_width, sh_degree=3,
               shs=d(sc.shs), scales=d(sc.scales), rotations=d(sc.rotations))
     best = None
-    for _ in range(4):
+    for it in range(5):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         rf = ref.forward(**kw)
@@ -129,10 +167,145 @@ def reference_kernels_on_gpu(args, cam, sc):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         rf.free()
-        best = dt if best is None else min(best, dt)
+        if it > 0:  # the first call sizes the pool
+            best = dt if best is None else min(best, dt)
+    if pooled:
+        ref.lib().ref_set_pooled(0)
     return {"ms_per_step": round(1e3 * best, 3), "iters_per_s": round(1.0 / best, 3),
             "what": "reference CUDA kernels (forward.cu/backward.cu/rasterizer_impl.cu + hipCUB) compiled unmodified "
-                    "for gfx950, same inputs resident in HBM; includes the hipMalloc of its scratch and gradient zero-fills"}
+                    "for gfx950, same inputs resident in HBM, scratch " + ("pre-allocated (pooled)" if pooled else
+                    "hipMalloc'ed per call") + "; includes its gradient zero-fills and its blocking D2H of num_rendered"}
+
+
+class Workload:
+    """One rasterizer workload resident in HBM: `step()` = forward + backward (+ the exchange step when N > 1)."""
+
+    def __init__(self, args, P, S, rank, dev, dist=None, force_dist=False, scene_file=None):
+        from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+        from street_gaussians_amd import multiview
+        self.args, self.P, self.S, self.dev = args, P, S, dev
+        W, H = args.width, args.height
+        # identical Gaussians on every rank (seed 0); rank r renders view r (yawed r*5 degrees)
+        self.cam0 = syn.make_camera(W, H, fx=2050.0 * W / 1920.0)
+        if scene_file:
+            self.scene = load_scene_file(scene_file, S)
+            self.P = P = self.scene.P
+        else:
+            self.scene = syn.make_scene(P, self.cam0, sh_degree_max=3, S=S, seed=0)
+        scene = self.scene
+        self.cam = cam = syn.make_camera(W, H, fx=2050.0 * W / 1920.0, yaw_deg=5.0 * rank)
+        self.params = {k: getattr(scene, k).to(dev).requires_grad_(True)
+                       for k in ["means3D", "scales", "rotations", "opacities", "shs"]}
+        if S:
+            self.params["semantics"] = scene.semantics.to(dev).requires_grad_(True)
+        self.means2D = torch.zeros(scene.P, 3, device=dev, requires_grad=True)
+        self.w = {k: v.to(dev) for k, v in syn.loss_weights(cam, S=S, seed=1 + rank).items()}
+        self.st = GaussianRasterizationSettings(
+            image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+            bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=cam.viewmatrix.to(dev),
+            projmatrix=cam.projmatrix.to(dev), sh_degree=3, campos=cam.campos.to(dev), prefiltered=False, debug=False)
+        self.rast = GaussianRasterizer(self.st)
+        self.radii = None
+        # exchange step (N > 1): the optimiser's gradients.  dL/dmeans2D is not one of them -- it feeds per-view
+        # densification statistics (multiview.reduce_densification_stats) -- so it stays local.
+        self.reducer = None
+        params = self.params
+        if dist is not None:
+            def bucket():
+                return multiview.GradReducer(list(params.values()), force=force_dist)
+            if args.reduce == "factored":
+                try:
+                    dense = [v for k, v in params.items() if k != "shs"]
+                    self.reducer = multiview.FactoredGradReducer(dense, params["shs"], params["means3D"], force=force_dist)
+                    self.reducer.warm_up()  # RCCL's lazy communicator / channel set-up is not part of a training step
+                except Exception as ex:  # measurement harness only: fall back to the plain bucket and say so
+                    print(f"[bench] factored exchange unavailable ({type(ex).__name__}: {ex}); using --reduce bucket",
+                          file=sys.stderr)
+                    if self.reducer is not None:
+                        self.reducer.close()
+                    args.reduce = "bucket"
+                    self.reducer = None
+            if self.reducer is None:
+                self.reducer = bucket()
+                self.reducer.warm_up()
+
+    def step(self):
+        p, w, S = self.params, self.w, self.S
+        for t in list(p.values()) + [self.means2D]:
+            t.grad = None
+        color, radii, depth, alpha, sem = self.rast(p["means3D"], self.means2D, p["opacities"], shs=p["shs"],
+                                                    scales=p["scales"], rotations=p["rotations"],
+                                                    semantics=p.get("semantics"))
+        if self.args.loss == "scalar":
+            loss = (color * w["color"]).sum() + (depth * w["depth"]).sum() + (alpha * w["alpha"]).sum()
+            if S:
+                loss = loss + (sem * w["semantic"]).sum()
+            loss.backward()
+        else:
+            outs, grads = [color, depth, alpha], [w["color"], w["depth"], w["alpha"]]
+            if S:
+                outs.append(sem)
+                grads.append(w["semantic"])
+            torch.autograd.backward(outs, grads)
+        if self.reducer is not None:
+            self.reducer.all_reduce()
+        self.radii = radii
+
+    def counts(self):
+        """R (tile instances), V (visible Gaussians) and the sum of n_contrib of this view (R/P and V/P are
+        reported with every number)."""
+        from street_gaussians_amd import _C as native
+        st, p = self.st, self.params
+        V = int((self.radii > 0).sum().item())
+        out = native.rasterize_gaussians(st.bg, p["means3D"].detach(), torch.Tensor([]),
+                                         torch.zeros(self.P, 0, device=self.dev), p["opacities"].detach(),
+                                         p["scales"].detach(), p["rotations"].detach(), 1.0, torch.Tensor([]),
+                                         st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy, st.image_height,
+                                         st.image_width, p["shs"].detach(), 3, st.campos, False, False)
+        R = int(out[0])
+        n_contrib = native.export_internal("n_contrib", self.P, R, self.args.height, self.args.width, out[6], out[7], out[8])
+        return R, V, int(n_contrib.to(torch.int64).sum().item())
+
+
+def load_scene_file(path, S):
+    """A scene in the reference's on-disk layout (one `vertex_<model>` element per sub-model,
+    street_gaussian_model.py:94-117), flattened to rasterizer inputs: activations applied as the model's getters do
+    (gaussian_model.py:224-251), all sub-models concatenated, actors left in their stored frame."""
+    from street_gaussians_amd import plyio
+    models = plyio.read_scene_ply(path)
+    cat = lambda k: torch.cat([torch.as_tensor(m[k]) for m in models.values()], 0).float()
+    xyz = cat("xyz")
+    shs = torch.cat([cat("f_dc"), cat("f_rest")], 1)
+    sem = cat("semantic") if all("semantic" in m for m in models.values()) else torch.zeros(xyz.shape[0], 0)
+    if S and sem.shape[1] != S:
+        sem = torch.zeros(xyz.shape[0], S)
+    rot = cat("rotation")
+    return syn.Scene(xyz.contiguous(), torch.exp(cat("scaling")).contiguous(),
+                     (rot / rot.norm(dim=1, keepdim=True)).contiguous(), torch.sigmoid(cat("opacity")).contiguous(),
+                     shs.contiguous(), (sem[:, :S] if S else sem[:, :0]).contiguous())
+
+
+def profiled_steps(L, wl, fence, steps, stage_mask):
+    """Runs `steps` steps with the chosen stages bracketed by HIP events; returns (seconds, {stage: mean ms})."""
+    L.sgr_profile_select(stage_mask)
+    L.sgr_profile_enable(1)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    fence()
+    dt = time.perf_counter() - t0
+    sums = (C.c_double * 9)()
+    counts = (C.c_int * 9)()
+    L.sgr_profile_read(sums, counts)
+    L.sgr_profile_enable(0)
+    L.sgr_profile_select(0x1FF)
+    return dt, {STAGES[i]: (sums[i] / counts[i] if counts[i] else None) for i in range(9)}
+
+
+def blend_bytes(S, R, N, V):
+    """SURVEY 8d algorithmic bytes per launch: B_blend_b, B_blend_f."""
+    return (44 + 4 * S) * R + (28 + 4 * S) * N + (48 + 4 * S) * V, (44 + 4 * S) * R + (24 + 4 * S) * N
 
 
 def main():
@@ -154,68 +327,13 @@ def main():
             os.environ.setdefault("RANK", "0"), os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
-    from street_gaussians_amd import _native, multiview
+    from street_gaussians_amd import _native
+    from street_gaussians_amd import build as sgr_build
 
-    # identical Gaussians on every rank (seed 0); rank r renders view r (yawed r*5 degrees)
-    cam0 = syn.make_camera(args.width, args.height, fx=2050.0 * args.width / 1920.0)
-    scene = syn.make_scene(args.gaussians, cam0, sh_degree_max=3, S=args.semantics, seed=0)
-    cam = syn.make_camera(args.width, args.height, fx=2050.0 * args.width / 1920.0, yaw_deg=5.0 * rank)
     S = args.semantics
-    params = {k: getattr(scene, k).to(dev).requires_grad_(True)
-              for k in ["means3D", "scales", "rotations", "opacities", "shs"]}
-    if S:
-        params["semantics"] = scene.semantics.to(dev).requires_grad_(True)
-    means2D = torch.zeros(scene.P, 3, device=dev, requires_grad=True)
-    w = {k: v.to(dev) for k, v in syn.loss_weights(cam, S=S, seed=1 + rank).items()}
-    st = GaussianRasterizationSettings(
-        image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
-        bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=cam.viewmatrix.to(dev),
-        projmatrix=cam.projmatrix.to(dev), sh_degree=3, campos=cam.campos.to(dev), prefiltered=False, debug=False)
-    rast = GaussianRasterizer(st)
-    # exchange step (N > 1): the optimiser's gradients.  dL/dmeans2D is not one of them -- it feeds per-view
-    # densification statistics (multiview.reduce_densification_stats) -- so it stays local.
-    reducer = None
-    if dist is not None:
-        def bucket():
-            return multiview.GradReducer(list(params.values()), force=force_dist)
-        if args.reduce == "factored":
-            try:
-                dense = [v for k, v in params.items() if k != "shs"]
-                reducer = multiview.FactoredGradReducer(dense, params["shs"], params["means3D"], force=force_dist)
-                reducer.warm_up()  # RCCL's lazy communicator / channel set-up is not part of a training step
-            except Exception as ex:  # measurement harness only: fall back to the plain bucket and say so
-                print(f"[bench] factored exchange unavailable ({type(ex).__name__}: {ex}); using --reduce bucket",
-                      file=sys.stderr)
-                if reducer is not None:
-                    reducer.close()
-                args.reduce = "bucket"
-                reducer = None
-        if reducer is None:
-            reducer = bucket()
-            reducer.warm_up()
-    stats = {}
-
-    def step():
-        for p in list(params.values()) + [means2D]:
-            p.grad = None
-        color, radii, depth, alpha, sem = rast(params["means3D"], means2D, params["opacities"], shs=params["shs"],
-                                               scales=params["scales"], rotations=params["rotations"],
-                                               semantics=params.get("semantics"))
-        if args.loss == "scalar":
-            loss = (color * w["color"]).sum() + (depth * w["depth"]).sum() + (alpha * w["alpha"]).sum()
-            if S:
-                loss = loss + (sem * w["semantic"]).sum()
-            loss.backward()
-        else:
-            outs, grads = [color, depth, alpha], [w["color"], w["depth"], w["alpha"]]
-            if S:
-                outs.append(sem)
-                grads.append(w["semantic"])
-            torch.autograd.backward(outs, grads)
-        if reducer is not None:
-            reducer.all_reduce()
-        stats["radii"] = radii
+    wl = Workload(args, args.gaussians, S, rank, dev, dist=dist, force_dist=force_dist, scene_file=args.scene)
+    args.gaussians = wl.P
+    reducer = wl.reducer
 
     def fence():
         if dist is not None:
@@ -223,70 +341,71 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        wl.step()
     L = _native.lib()
-    L.sgr_profile_enable(1)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    sums = (C.c_double * 9)()
-    counts = (C.c_int * 9)()
-    L.sgr_profile_read(sums, counts)
-    L.sgr_profile_enable(0)
+    # ---- the timed region: EXACTLY args.steps steps between two fences; only the dominant kernel carries events
+    dt, timed = profiled_steps(L, wl, fence, args.steps, 1 << 7)
     if args.step_times:
-        for tag in ("profiled-off",):
-            ts = []
-            for _ in range(10):
-                fence()
-                t1 = time.perf_counter()
-                step()
-                fence()
-                ts.append(round(1e3 * (time.perf_counter() - t1), 3))
-            print(f"[step-times {tag}] {ts}", file=sys.stderr)
+        ts = []
+        for _ in range(10):
+            fence()
+            t1 = time.perf_counter()
+            wl.step()
+            fence()
+            ts.append(round(1e3 * (time.perf_counter() - t1), 3))
+        print(f"[step-times] {ts}", file=sys.stderr)
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
-    # workload statistics (R/P and V/P must be reported with every number)
-    V = int((stats["radii"] > 0).sum().item())
-    from street_gaussians_amd import _C as native
-    out = native.rasterize_gaussians(st.bg, params["means3D"].detach(), torch.Tensor([]),
-                                     torch.zeros(scene.P, 0, device=dev), params["opacities"].detach(),
-                                     params["scales"].detach(), params["rotations"].detach(), 1.0, torch.Tensor([]),
-                                     st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy, st.image_height,
-                                     st.image_width, params["shs"].detach(), 3, st.campos, False, False)
-    R = int(out[0])
-    n_contrib = native.export_internal("n_contrib", scene.P, R, args.height, args.width, out[6], out[7], out[8])
-    pairs_blended = int(n_contrib.to(torch.int64).sum().item())  # upper bound of pairs walked per pixel
+    # ---- untimed extras: every stage bracketed (a short pass), a >= 1 s sustained region
+    _, stage_ms = profiled_steps(L, wl, fence, min(50, max(5, args.steps)), 0x1FF)
+    sustained = None
+    if world == 1 and dist is None and dt < 1.0:
+        n = int(1.2 / max(dt / args.steps, 1e-5)) + 1
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(n):
+            wl.step()
+        fence()
+        sdt = time.perf_counter() - t1
+        sustained = {"steps": n, "seconds": round(sdt, 3), "ms_per_step": round(1e3 * sdt / n, 4),
+                     "iters_per_s": round(n / sdt, 3)}
+    R, V, pairs_blended = wl.counts()
     N = args.width * args.height
 
     if rank == 0:
-        stage_ms = {STAGES[i]: (sums[i] / counts[i] if counts[i] else None) for i in range(9)}
-        bwd_ms = stage_ms["blend_bwd"]
-        # B_blend_b = (44+4S)*R + (28+4S)*N + (48+4S)*V   algorithmic bytes per launch
-        algo_bytes = (44 + 4 * S) * R + (28 + 4 * S) * N + (48 + 4 * S) * V
+        bwd_ms = timed["blend_bwd"]
+        algo_bytes, fwd_bytes = blend_bytes(S, R, N, V)
         achieved = algo_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms else None
         fwd_ms = stage_ms["blend_fwd"]
-        fwd_bytes = (44 + 4 * S) * R + (24 + 4 * S) * N
-        traffic, valu = None, None
+        traffic, valu, traffic_note = None, None, None
         tfile = os.path.join(ROOT, "profiles", "pmc_blend_bwd.json")
+        kernel_name = "sgr_blend_bwd_kernel_s0" if S == 0 else "sgr_blend_bwd_kernel"
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                if tj.get("gaussians") == args.gaussians and tj.get("width") == args.width:
+                sha = sgr_build.source_sha16()
+                same_cfg = (tj.get("gaussians") == args.gaussians and tj.get("width") == args.width and
+                            tj.get("height") == args.height and kernel_name in str(tj.get("kernel", "")) and
+                            (S == 0) == ("_s0" in str(tj.get("kernel", ""))) and not args.scene)
+                if not same_cfg:
+                    traffic_note = "profiles/pmc_blend_bwd.json was measured on another kernel / configuration"
+                elif tj.get("source_sha16") != sha:
+                    traffic_note = (f"profiles/pmc_blend_bwd.json was measured on kernel sources {tj.get('source_sha16')}, "
+                                    f"this build is {sha}: re-run tools/gpu_evidence.sh + tools/pmc_summary.py")
+                else:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_note = "rocprofv3 PMC, 2*FETCH_SIZE + WRITE_SIZE per launch, " + str(tj.get("source", ""))[:120]
                     if tj.get("sq_insts_valu") and bwd_ms:
                         # what actually bounds the kernel: VALU wave-instructions (rocprofv3 SQ_INSTS_VALU) against
                         # the issue slots of 256 CUs x 4 SIMDs (one wave64 VALU instruction = 2 cycles) at 2.4 GHz
                         slots = 1024 * (bwd_ms * 1e-3) * 2.4e9 / 2.0
                         valu = {"insts_per_launch": int(tj["sq_insts_valu"]), "issue_slot_frac": round(tj["sq_insts_valu"] / slots, 3),
                                 "source": "profiles/pmc_blend_bwd.json (SQ_INSTS_VALU) / live kernel_ms"}
-            except Exception:
-                traffic = None
+            except Exception as ex:
+                traffic, traffic_note = None, f"profiles/pmc_blend_bwd.json unreadable: {ex}"
         line = {
             "metric": "train iters/s (fwd+bwd) @1M Gaussians 1920x1280 SH3",
             "value": round(world * args.steps / dt, 3),
@@ -299,9 +418,10 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"{args.gaussians} synthetic Gaussians (SURVEY 8d recipe, seed 0), "
-                                   f"{args.width}x{args.height}, SH degree 3, S={S} semantic channels, "
+            "data": "synthetic" if not args.scene else f"scene file {os.path.basename(args.scene)}",
+            "config": {"workload": f"{args.gaussians} " + ("synthetic Gaussians (SURVEY 8d recipe, seed 0)" if not args.scene
+                                   else f"Gaussians of {os.path.basename(args.scene)}") +
+                                   f", {args.width}x{args.height}, SH degree 3, S={S} semantic channels, "
                                    f"rasterizer forward+backward, one camera view per GPU",
                        "gaussians": args.gaussians, "width": args.width, "height": args.height, "sh_degree": 3,
                        "semantic_channels": S, "loss": args.loss, "views_per_step": world, "num_rendered_R": R, "visible_V": V,
@@ -309,30 +429,39 @@ def main():
                        "parallelism": f"view-dp{world}" + ((" + RCCL all-reduce of Gaussian grads" + (
                            " (dense 44 B/Gaussian; SH gradient rebuilt from an all-gather of per-view dRGB, 12 B/Gaussian/view)"
                            if args.reduce == "factored" else " (one 236 B/Gaussian bucket)")) if world > 1 else ""),
-                       "exchange_bytes_per_rank": reducer.nbytes if reducer is not None else 0},
-            "roofline": {"bound": "hbm", "kernel": "sgr_blend_bwd_kernel_s0" if S == 0 else "sgr_blend_bwd_kernel",
+                       "exchange_bytes_per_rank": reducer.nbytes if reducer is not None else 0,
+                       "kernel_sources_sha16": sgr_build.source_sha16()},
+            "roofline": {"bound": "hbm", "kernel": kernel_name,
                          "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": traffic, "valu": valu,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": traffic,
+                         "traffic_note": traffic_note, "valu": valu,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "kernel_ms": round(bwd_ms, 4) if bwd_ms else None,
+                         "kernel_ms_source": f"HIP events around the kernel on its launch stream, mean over the "
+                                             f"{min(args.steps, 1024)} timed steps",
                          "blend_fwd": {"kernel_ms": round(fwd_ms, 4) if fwd_ms else None,
                                        "achieved": round(fwd_bytes / (fwd_ms * 1e-3) / 1e9, 2) if fwd_ms else None,
                                        "algorithmic_bytes_per_launch": fwd_bytes},
                          "stages_ms": {k: (round(v, 4) if v is not None else None) for k, v in stage_ms.items()},
+                         "stages_ms_source": "extra pass after the timed region, every stage bracketed by HIP events",
                          "sum_n_contrib_pairs": pairs_blended,
                          "note": "blend kernels are VALU/exp/LDS bound (SURVEY 8d); HBM fraction is reported as the "
-                                 "metric demands, stage times are HIP-event means over the timed region"},
+                                 "metric demands"},
         }
+        if sustained is not None:
+            line["sustained"] = sustained
+        if world == 1 and dist is None and not args.no_other_configs and not args.scene:
+            line["other_configs"] = other_configs(args, L, dev, fence)
         if not args.no_cpu_baseline and world == 1:
             try:
-                rk = reference_kernels_on_gpu(args, cam, scene)
+                rk = reference_kernels_on_gpu(args, wl.cam, wl.scene)
                 if rk is not None:
                     rk["speedup_vs_reference_kernels"] = round(line["value"] / rk["iters_per_s"], 2)
                     line["reference_kernels_mi355x"] = rk
             except Exception as ex:
                 line["reference_kernels_mi355x"] = {"error": str(ex)[:200]}
             try:
-                line["cpu_baseline"] = cpu_baseline(args, cam0, scene)
+                line["cpu_baseline"] = cpu_baseline(args, wl.cam0, wl.scene)
             except Exception as ex:  # the baseline is a reported extra; never lose the GPU number over it
                 line["cpu_baseline"] = {"value": None, "unit": "iters/s", "cores": os.cpu_count(), "kind": "port",
                                         "sample": f"failed: {ex}"}
@@ -344,6 +473,36 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def other_configs(args, L, dev, fence):
+    """BASELINE.json's other single-GPU configurations on the same build (untimed extras of the N = 1 run): configs[1]
+    500 k Gaussians, configs[2] 2 M Gaussians + 19 semantic channels, configs[4]'s per-GPU load 5 M Gaussians (its
+    densify step is timed by tools/bench_densify.py)."""
+    out = []
+    for name, P, S in (("configs[1] 500k", 500_000, 0), ("configs[2] 2M + 19 semantic channels", 2_000_000, 19),
+                       ("configs[4] 5M (rasterizer only)", 5_000_000, 0)):
+        try:
+            torch.cuda.empty_cache()
+            wl = Workload(args, P, S, 0, dev)
+            for _ in range(3):
+                wl.step()
+            steps = 20
+            dt, _ = profiled_steps(L, wl, fence, steps, 0)
+            _, st = profiled_steps(L, wl, fence, 10, 0x1FF)
+            R, V, _ = wl.counts()
+            bb, fb = blend_bytes(S, R, args.width * args.height, V)
+            out.append({"config": name, "gaussians": P, "semantic_channels": S, "steps": steps,
+                        "ms_per_step": round(1e3 * dt / steps, 4), "iters_per_s": round(steps / dt, 3),
+                        "num_rendered_R": R, "visible_V": V,
+                        "blend_bwd_ms": round(st["blend_bwd"], 4) if st["blend_bwd"] else None,
+                        "blend_fwd_ms": round(st["blend_fwd"], 4) if st["blend_fwd"] else None,
+                        "blend_bwd_hbm_frac": round(bb / (st["blend_bwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if st["blend_bwd"] else None,
+                        "stages_ms": {k: (round(v, 4) if v is not None else None) for k, v in st.items()}})
+            del wl
+        except Exception as ex:  # an extra: never lose the headline over it
+            out.append({"config": name, "error": f"{type(ex).__name__}: {ex}"[:200]})
+    return out
 
 
 if __name__ == "__main__":

@@ -104,10 +104,13 @@ int sgr_partial_row_floats(int S);
 
 /* ---- per-stage timing with HIP events recorded on the caller's stream (bench.py's roofline leg) ---------------
  * stages: 0 preprocess 1 scan 2 duplicate 3 sort 4 tile_ranges 5 blend_fwd 6 partials memset 7 blend_bwd
- * 8 gauss_bwd.  sgr_profile_read sums the durations (ms) of the up-to-4096 stage executions recorded (by any host thread) since
+ * 8 gauss_bwd.  sgr_profile_read sums the durations (ms) of the up-to-1024 stage executions recorded (by any host thread) since
  * sgr_profile_enable(1), writes 9 sums + 9 counts, resets the recorder and returns the number of records. */
 int sgr_profile_enable(int on);
 int sgr_profile_read(double* sum_ms, int* counts);
+/* which stages are recorded (bit i = stage i; default all): a timed region that only needs the dominant kernel records
+ * two events per step instead of eighteen.  stage_mask < 0 only queries; returns the previous mask. */
+int sgr_profile_select(int stage_mask);
 
 /* ---- introspection for parity tests: copies one internal array, densely packed, to dst (device). -------------
  * which: 0 depths f32[P] | 1 clamped u8[3P] | 2 means2D f32[2P] | 3 cov3D f32[6P] | 4 conic_opacity f32[4P]

@@ -20,8 +20,23 @@ struct RefHandle {
     char* img = nullptr;
     int P = 0, W = 0, H = 0, R = 0;
 };
-std::function<char*(size_t)> grow(char** slot) {
-    return [slot](size_t n) {
+// Pooled mode (ref_set_pooled(1), bench.py's "reference kernels on MI355X" timing): the three scratch buffers are kept
+// and re-used across calls like torch's caching allocator would for the reference's own glue
+// (rasterize_points.cu:27-33), so the timing does not include hipMalloc / hipFree.  One live handle at a time.
+bool g_pooled = false;
+char* g_pool[3] = {nullptr, nullptr, nullptr};
+size_t g_pool_bytes[3] = {0, 0, 0};
+std::function<char*(size_t)> grow(char** slot, int which) {
+    return [slot, which](size_t n) {
+        if (g_pooled) {
+            if (g_pool_bytes[which] < n) {
+                if (g_pool[which]) hipFree(g_pool[which]);
+                hipMalloc((void**)&g_pool[which], n + n / 4 + 256);
+                g_pool_bytes[which] = n + n / 4 + 256;
+            }
+            *slot = g_pool[which];
+            return *slot;
+        }
         if (*slot) hipFree(*slot);
         hipMalloc((void**)slot, n ? n : 1);
         return *slot;
@@ -44,7 +59,7 @@ void* ref_forward(int P, int D, int M, int S, const float* bg, int W, int H, con
                   int* num_rendered) {
     RefHandle* h = new RefHandle();
     h->P = P; h->W = W; h->H = H;
-    int R = CudaRasterizer::Rasterizer::forward(grow(&h->geom), grow(&h->binning), grow(&h->img), P, D, M, S, bg, W, H,
+    int R = CudaRasterizer::Rasterizer::forward(grow(&h->geom, 0), grow(&h->binning, 1), grow(&h->img, 2), P, D, M, S, bg, W, H,
                                                 means3D, shs, colors_precomp, semantics, opacities, scales,
                                                 scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix,
                                                 campos, tan_fovx, tan_fovy, prefiltered != 0, out_color, out_depth,
@@ -107,10 +122,21 @@ void* ref_internal(void* handle, int which) {
 void ref_free(void* handle) {
     RefHandle* h = (RefHandle*)handle;
     if (!h) return;
-    if (h->geom) hipFree(h->geom);
-    if (h->binning) hipFree(h->binning);
-    if (h->img) hipFree(h->img);
+    if (!g_pooled || h->geom != g_pool[0]) { if (h->geom) hipFree(h->geom); }
+    if (!g_pooled || h->binning != g_pool[1]) { if (h->binning) hipFree(h->binning); }
+    if (!g_pooled || h->img != g_pool[2]) { if (h->img) hipFree(h->img); }
     delete h;
+}
+
+void ref_set_pooled(int on) {
+    g_pooled = on != 0;
+    if (!g_pooled) {
+        for (int i = 0; i < 3; i++) {
+            if (g_pool[i]) hipFree(g_pool[i]);
+            g_pool[i] = nullptr;
+            g_pool_bytes[i] = 0;
+        }
+    }
 }
 
 void ref_mark_visible(int P, float* means3D, float* viewmatrix, float* projmatrix, bool* present) {
@@ -123,10 +149,13 @@ void ref_visible_filter(int P, int M, int W, int H, const float* means3D, const 
                         const float* projmatrix, float tan_fovx, float tan_fovy, int prefiltered, int* radii,
                         float* means2D, int debug) {
     char *g = nullptr, *b = nullptr, *i = nullptr;
-    CudaRasterizer::Rasterizer::visible_filter(grow(&g), grow(&b), grow(&i), P, M, W, H, means3D, scales,
+    const bool was_pooled = g_pooled;
+    g_pooled = false;
+    CudaRasterizer::Rasterizer::visible_filter(grow(&g, 0), grow(&b, 1), grow(&i, 2), P, M, W, H, means3D, scales,
                                                scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix,
                                                tan_fovx, tan_fovy, prefiltered != 0, radii, means2D, debug != 0);
     hipDeviceSynchronize();
+    g_pooled = was_pooled;
     if (g) hipFree(g);
     if (b) hipFree(b);
     if (i) hipFree(i);

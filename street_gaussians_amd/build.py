@@ -25,6 +25,17 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", 
          "-Wno-unused-function"]
 
 
+def source_sha16() -> str:
+    """First 16 hex digits of the SHA-256 over the kernel sources and headers: identifies the build a profile was
+    taken on (profiles/pmc_blend_bwd.json, bench.py's roofline.traffic)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES + [x for x in HEADERS if not x.startswith("..")]):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 

@@ -75,12 +75,13 @@ static int switches() {
 // stages: 0 preprocess(+camera pack, memsets) 1 depth sort + scan 2 duplicate 3 tile sort 4 tile_ranges 5 blend_fwd
 //         6 partials memset 7 blend_bwd 8 gauss_bwd
 #define SGR_PROF_STAGES 9
-#define SGR_PROF_SLOTS 4096
+#define SGR_PROF_SLOTS 1024
 // One process-wide recorder: the forward runs on the caller's thread and the backward on autograd's, and both must land
 // in the same recording.  Slots are claimed with an atomic counter (each thread records only into slots it claimed);
 // enable / read are called by the measuring thread while no step is in flight.
 struct SgrProf {
     std::atomic<bool> on{false};
+    std::atomic<int> mask{(1 << SGR_PROF_STAGES) - 1};  // stages that are recorded (sgr_profile_select)
     std::atomic<int> n{0};  // claimed (begin, end) slots
     hipEvent_t ev[SGR_PROF_SLOTS][2];
     int stage[SGR_PROF_SLOTS];
@@ -91,6 +92,7 @@ static thread_local int t_prof_slot = -1;  // slot opened by prof_begin on this 
 static void prof_begin(int stage, hipStream_t s) {
     t_prof_slot = -1;
     if (!g_prof.on.load(std::memory_order_relaxed)) return;
+    if (!((g_prof.mask.load(std::memory_order_relaxed) >> stage) & 1)) return;
     const int i = g_prof.n.fetch_add(1, std::memory_order_relaxed);
     if (i >= SGR_PROF_SLOTS) return;
     g_prof.stage[i] = stage;
@@ -439,6 +441,12 @@ int sgr_profile_enable(int on) {
     g_prof.n.store(0);
     g_prof.on.store(on != 0);
     return 0;
+}
+
+int sgr_profile_select(int stage_mask) {
+    const int prev = g_prof.mask.load();
+    if (stage_mask >= 0) g_prof.mask.store(stage_mask & ((1 << SGR_PROF_STAGES) - 1));
+    return prev;
 }
 
 // Sums the recorded stage durations (ms) since sgr_profile_enable(1) and resets the recorder.

@@ -9,7 +9,15 @@ flips) is written to gpurun_out/fullsize_parity.json so that the gates below can
 
 The oracle's backward runs in its order-free mode (oracle.backward(parallel="exact"): the reference's float terms
 summed in double, rounded once), so the differences reported here are the HIP path's own rounding + the handful of
-exp-ulp threshold flips, not the oracle's accumulation order."""
+exp-ulp threshold flips, not the oracle's accumulation order.
+
+Two backward comparisons are made.  "grads": the oracle's backward is given the SAME forward state the HIP backward
+got (the HIP path's alpha image) -- identical inputs, the north-star gate.  "grads_end_to_end": each side uses its own
+forward.  The reference recovers the final transmittance as T_final = 1 - alpha_out (backward.cu:468); in these dense
+scenes most pixels end near T = 1e-4, where ONE ulp of alpha_out (v_exp_f32 vs expf in the forward) is a 6e-4 relative
+change of T_final and therefore of every gradient term of the pixel.  That sensitivity belongs to the reference
+algorithm (its own kernels and its C restatement differ by as much, tests/test_gpu_parity.py: SATURATING_TOL), so
+the end-to-end figures are reported and held to a correspondingly wider gate."""
 import json
 import os
 
@@ -35,11 +43,15 @@ GRADS = ["means2D", "colors", "opacity", "means3D", "cov3D", "sh", "scales", "ro
 #              and each bounded by IMG_FLIP_CAP of the image's scale;
 #   gradients: |a-b| <= 1e-4*max(|a|,|b|) + GRAD_ABS_FRAC*max|b|; at most GRAD_OUT_FRAC of the elements outside
 #              (Gaussians that saw a threshold flip), none further than GRAD_CAP of the tensor's scale.
-IMG_FLIP_FRAC = 3e-5
-IMG_FLIP_CAP = 0.05
+# Measured (profiles/r2/fullsize_parity.json, all three sizes): images -- at most 8.5e-6 of the elements outside, worst
+# 2.1e-3 of the scale; gradients on identical inputs -- at most 2.2e-4 outside, worst 6.2e-3 of the scale (a Gaussian
+# whose pixel flipped in the oracle's own n_contrib); end to end at rel 2e-3 -- at most 2.2e-5 outside, worst 7.7e-4.
+IMG_FLIP_FRAC = 2e-5
+IMG_FLIP_CAP = 5e-3
 GRAD_ABS_FRAC = 2e-6
-GRAD_OUT_FRAC = 2e-3
-GRAD_CAP = 2e-2
+GRAD_OUT_FRAC = 5e-4
+GRAD_CAP = 1e-2
+E2E_REL, E2E_ABS_FRAC, E2E_OUT_FRAC = 2e-3, 2e-4, 1e-4  # end to end: see the module docstring
 
 
 def _image_stats(a, b):
@@ -56,13 +68,13 @@ def _image_stats(a, b):
                 max_rel_inside=float(rel[~bad].max()) if (~bad).any() else 0.0)
 
 
-def _grad_stats(a, b, abs_frac):
+def _grad_stats(a, b, abs_frac, rel=1e-4):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     if a.size == 0:
         return dict(n=0, outside=0, outside_frac=0.0, worst_abs_over_scale=0.0, p9999_err_over_tol=0.0)
     scale = max(float(np.abs(b).max()), 1e-30)
-    tol = 1e-4 * np.maximum(np.abs(a), np.abs(b)) + abs_frac * scale
+    tol = rel * np.maximum(np.abs(a), np.abs(b)) + abs_frac * scale
     err = np.abs(a - b)
     bad = err > tol
     ratio = (err / tol).ravel()
@@ -96,12 +108,17 @@ def test_baseline_size_matches_oracle(name, P, S):
     H, W = cam.image_height, cam.image_width
 
     fw = oracle.forward(**kw)
-    ref = oracle.backward(fw, wts["color"], wts["depth"], wts["alpha"], wts["semantic"] if S else None, parallel="exact")
+    gsem = wts["semantic"] if S else None
+    ref_e2e = oracle.backward(fw, wts["color"], wts["depth"], wts["alpha"], gsem, parallel="exact")
     res, internal = raw_forward(kw)
     g = raw_backward(kw, res, wts)
     torch.cuda.synchronize()
+    own_alpha = fw.alpha
+    fw.alpha = npy(res["alpha"]).reshape(own_alpha.shape).copy()  # the forward state the HIP backward was given
+    ref = oracle.backward(fw, wts["color"], wts["depth"], wts["alpha"], gsem, parallel="exact")
+    fw.alpha = own_alpha
 
-    rec = dict(P=P, S=S, R=int(fw.num_rendered), V=int((fw.radii > 0).sum()), images={}, grads={})
+    rec = dict(P=P, S=S, R=int(fw.num_rendered), V=int((fw.radii > 0).sum()), images={}, grads={}, grads_end_to_end={})
     # ---- integer / index outputs: bit exact
     assert res["R"] == fw.num_rendered
     assert (npy(res["radii"]) == fw.radii).all()
@@ -122,6 +139,7 @@ def test_baseline_size_matches_oracle(name, P, S):
     # ---- gradients
     for k in GRADS:
         rec["grads"][k] = _grad_stats(npy(g[k]).reshape(ref[k].shape), ref[k], GRAD_ABS_FRAC)
+        rec["grads_end_to_end"][k] = _grad_stats(npy(g[k]).reshape(ref[k].shape), ref_e2e[k], E2E_ABS_FRAC, rel=E2E_REL)
     _save(name, rec)
     print(json.dumps({name: rec}))
 
@@ -133,4 +151,7 @@ def test_baseline_size_matches_oracle(name, P, S):
         assert st.get("finite", True), k
         assert st["outside_frac"] <= GRAD_OUT_FRAC, (k, st)
         assert st["worst_abs_over_scale"] <= GRAD_CAP, (k, st)
+    for k, st in rec["grads_end_to_end"].items():
+        assert st["outside_frac"] <= E2E_OUT_FRAC, ("end to end", k, st)
+        assert st["worst_abs_over_scale"] <= GRAD_CAP, ("end to end", k, st)
     fw.free()
