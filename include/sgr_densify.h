@@ -31,6 +31,9 @@ typedef struct sgr_densify_params {
     int32_t prune_big;    /* the reference's max_screen_size / prune_big_points being truthy */
     int32_t grad_column;  /* column of xyz_gradient_accum: 0 (:523), 1 = the "abs" variants (gaussian_model_bkgd.py:76-79) */
     int32_t n_split;      /* N of densify_and_split (2) */
+    int32_t defer_prune;  /* 1: sgr_densify_plan / _map lay out ALL candidates (kept originals, clones, split children);
+                             pruning is then decided per candidate row by sgr_densify_prune_mask -- needed by the
+                             background and actor models, whose prune rules look at the NEW points' positions */
 } sgr_densify_params;
 
 #define SGR_KIND_KEEP 0
@@ -62,6 +65,35 @@ int sgr_densify_gather(int n_out, int width, const float* in, const int32_t* src
 int sgr_densify_split_children(int n_out, int n_split, const int32_t* src, const uint8_t* kind, const int32_t* sample_row,
                                const float* xyz_in, const float* scaling_in, const float* rotation_in,
                                const float* normals, float* xyz_out, float* scaling_out, void* stream);
+
+/* ---- the prune rules of the models street_gaussians instantiates, evaluated on the candidate set -----------------
+ * (candidates = rows laid out with defer_prune = 1; xyz / scaling / rotation / opacity are the candidates' RAW
+ * parameters, i.e. gathered rows with the split children's position and log-scale already written.)
+ *   variant SGR_PRUNE_BASE   GaussianModel.densify_and_prune (gaussian_model.py:532-543):
+ *                            sigmoid(opacity) < min_opacity, or (prune_big and max scale > extent * percent_big_ws)
+ *   variant SGR_PRUNE_BKGD   GaussianModelBkgd (gaussian_model_bkgd.py:91-104): the same, but a big point farther than
+ *                            2 * sphere_radius from sphere_center is exempt; sphere = {cx, cy, cz, radius} (host)
+ *   variant SGR_PRUNE_ACTOR  GaussianModelActor (gaussian_model_actor.py:226-252): additionally prunes a point when
+ *                            either of two samples xyz + R(q) (z * scale) leaves the tracking box [box_min, box_max]
+ *                            (box = {min xyz, max xyz}, host; box_normals [n, 2, 3] = the standard normals z of
+ *                            torch.normal(mean=0, std=scale), device).  Only when prune_big, like the reference.
+ * prune[i] = 1 for rows to drop.  counts (host; the call synchronises the stream): [0] below min opacity,
+ * [1] big in world space (after the exemption), [2] outside the tracking box, [3] pruned. */
+#define SGR_PRUNE_BASE 0
+#define SGR_PRUNE_BKGD 1
+#define SGR_PRUNE_ACTOR 2
+int sgr_densify_prune_mask(int n, const sgr_densify_params* p, int variant, const float* xyz, const float* scaling,
+                           const float* rotation, const float* opacity, const float* sphere, const float* box,
+                           const float* box_normals, uint8_t* prune, int64_t counts[4], void* stream);
+
+/* sel[0 .. *n_out) = ascending indices of the rows with prune[i] == 0.  work: sgr_densify_work_bytes(n) bytes.
+ * *n_out is written before the call returns (the call synchronises the stream). */
+int sgr_densify_compact(int n, const uint8_t* prune, char* work, int32_t* sel, int64_t* n_out, void* stream);
+
+/* GaussianModel.reset_opacity (gaussian_model.py:410-414 with reset_optimizer :344-361):
+ * opacity = inverse_sigmoid(min(sigmoid(opacity), 0.01)) in place; the two Adam moments of the group (may be NULL)
+ * are zero-filled. */
+int sgr_reset_opacity(int N, float* opacity, float* exp_avg, float* exp_avg_sq, void* stream);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,8 @@ SYMBOLS = [
     "sgr_scene_densification_stats", "sgr_ssim_workspace_floats", "sgr_ssim_forward", "sgr_ssim_backward",
     "sgr_l1_workspace_floats", "sgr_l1_forward", "sgr_l1_backward", "sgr_bce_forward", "sgr_bce_backward",
     "sgr_lidar_work_bytes", "sgr_lidar_depth_forward", "sgr_lidar_depth_backward", "sgr_densify_work_bytes", "sgr_densify_plan",
-    "sgr_densify_map", "sgr_densify_gather", "sgr_densify_split_children",
+    "sgr_densify_map", "sgr_densify_gather", "sgr_densify_split_children", "sgr_densify_prune_mask",
+    "sgr_densify_compact", "sgr_reset_opacity",
 ]
 
 
@@ -103,6 +104,12 @@ def lib():
         L.sgr_densify_gather.argtypes = [i, i, vp, vp, vp, i, vp, vp]
         L.sgr_densify_split_children.restype = i
         L.sgr_densify_split_children.argtypes = [i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.sgr_densify_prune_mask.restype = i
+        L.sgr_densify_prune_mask.argtypes = [i, vp, i, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_int64), vp]
+        L.sgr_densify_compact.restype = i
+        L.sgr_densify_compact.argtypes = [i, vp, vp, vp, C.POINTER(C.c_int64), vp]
+        L.sgr_reset_opacity.restype = i
+        L.sgr_reset_opacity.argtypes = [i, vp, vp, vp, vp]
         L.sgr_knn.restype = i
         L.sgr_knn.argtypes = [i, vp, vp, ALLOC_FN, vp, vp]
         L.sgr_export_internal.restype = i

@@ -60,10 +60,10 @@ sgr_densify_flags_kernel(int N, sgr_densify_params p, const float* __restrict__ 
     const float op = 1.0f / (1.0f + expf(-opacity[i]));
     const bool low = op < p.min_opacity;                              // :533
     const float big = p.extent * p.percent_big_ws;
-    const bool prune_self = low || (p.prune_big && smax > big);       // :536-540
+    const bool prune_self = !p.defer_prune && (low || (p.prune_big && smax > big));  // :536-540
     // children: log(scale / (0.8 N)) -> exp gives scale / (0.8 N) again (up to rounding, like the reference's log/exp)
     const float child = expf(logf(smax / (0.8f * (float)p.n_split)));
-    const bool prune_child = low || (p.prune_big && child > big);
+    const bool prune_child = !p.defer_prune && (low || (p.prune_big && child > big));
     const uint32_t f = (clone ? DN_CLONE : 0u) | (split ? DN_SPLIT : 0u) | (prune_self ? DN_PRUNE_SELF : 0u) |
                        (prune_child ? DN_PRUNE_CHILD : 0u);
     w.flags[i] = f;
@@ -153,7 +153,148 @@ sgr_densify_children_kernel(int n_out, int n_split, const int32_t* __restrict__ 
     }
 }
 
+// ---- prune rules on the candidate set (include/sgr_densify.h) ----------------------------------------------------
+struct DnSphere { float cx, cy, cz, r; };
+struct DnBox { float lo[3], hi[3]; };
+__global__ void __launch_bounds__(256)
+sgr_densify_prune_kernel(int n, sgr_densify_params p, int variant, const float* __restrict__ xyz,
+                         const float* __restrict__ scaling, const float* __restrict__ rotation,
+                         const float* __restrict__ opacity, DnSphere sph, DnBox box,
+                         const float* __restrict__ box_normals, uint8_t* __restrict__ prune, uint32_t* __restrict__ cnt) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool low = false, big = false, outside = false;
+    if (i < n) {
+        const float op = 1.0f / (1.0f + expf(-opacity[i]));
+        low = op < p.min_opacity;
+        const float s[3] = {expf(scaling[3 * i]), expf(scaling[3 * i + 1]), expf(scaling[3 * i + 2])};
+        const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        if (p.prune_big) {
+            big = fmaxf(s[0], fmaxf(s[1], s[2])) > p.extent * p.percent_big_ws;
+            if (variant == SGR_PRUNE_BKGD) {  // gaussian_model_bkgd.py:95-97
+                const float dx = x - sph.cx, dy = y - sph.cy, dz = z - sph.cz;
+                const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+                if (dist > 2.0f * sph.r) big = false;
+            }
+            if (variant == SGR_PRUNE_ACTOR) {  // gaussian_model_actor.py:231-249
+                float qw = rotation[4 * i], qx = rotation[4 * i + 1], qy = rotation[4 * i + 2], qz = rotation[4 * i + 3];
+                const float nrm = sqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
+                qw /= nrm; qx /= nrm; qy /= nrm; qz /= nrm;
+                const float R[9] = {1.f - 2.f * (qy * qy + qz * qz), 2.f * (qx * qy - qw * qz), 2.f * (qx * qz + qw * qy),
+                                    2.f * (qx * qy + qw * qz), 1.f - 2.f * (qx * qx + qz * qz), 2.f * (qy * qz - qw * qx),
+                                    2.f * (qx * qz - qw * qy), 2.f * (qy * qz + qw * qx), 1.f - 2.f * (qx * qx + qy * qy)};
+                const float c[3] = {x, y, z};
+                bool inside = true;
+                for (int m = 0; m < 2; m++) {
+                    const float* zn = box_normals + (size_t)(2 * i + m) * 3;
+                    const float v[3] = {zn[0] * s[0], zn[1] * s[1], zn[2] * s[2]};
+#pragma unroll
+                    for (int a = 0; a < 3; a++) {
+                        const float w = R[3 * a] * v[0] + R[3 * a + 1] * v[1] + R[3 * a + 2] * v[2] + c[a];
+                        inside = inside && (w >= box.lo[a]) && (w <= box.hi[a]);
+                    }
+                }
+                outside = !inside;
+            }
+        }
+        prune[i] = (low || big || outside) ? 1 : 0;
+    }
+    // four counters, one atomic each per wave (integers: order-independent)
+    const uint64_t b0 = __ballot(low), b1 = __ballot(big), b2 = __ballot(outside), b3 = __ballot(low || big || outside);
+    if ((threadIdx.x & 63) == 0) {
+        if (b0) atomicAdd(&cnt[0], (uint32_t)__popcll(b0));
+        if (b1) atomicAdd(&cnt[1], (uint32_t)__popcll(b1));
+        if (b2) atomicAdd(&cnt[2], (uint32_t)__popcll(b2));
+        if (b3) atomicAdd(&cnt[3], (uint32_t)__popcll(b3));
+    }
+}
+
+__global__ void __launch_bounds__(256)
+sgr_densify_keep_flags_kernel(int n, const uint8_t* __restrict__ prune, uint32_t* __restrict__ keep) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) keep[i] = prune[i] ? 0u : 1u;
+}
+__global__ void __launch_bounds__(256)
+sgr_densify_compact_kernel(int n, const uint8_t* __restrict__ prune, const uint32_t* __restrict__ off,
+                           int32_t* __restrict__ sel) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && !prune[i]) sel[off[i]] = i;
+}
+
+__global__ void __launch_bounds__(256)
+sgr_reset_opacity_kernel(int N, float* __restrict__ opacity, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float op = 1.0f / (1.0f + expf(-opacity[i]));   // get_opacity
+    const float x = fminf(op, 0.01f);                      // torch.min(opacity, 0.01)
+    opacity[i] = logf(x / (1.0f - x));                     // inverse_sigmoid (general_utils.py:28-29)
+    if (exp_avg) exp_avg[i] = 0.0f;
+    if (exp_avg_sq) exp_avg_sq[i] = 0.0f;
+}
+
 extern "C" {
+
+int sgr_densify_prune_mask(int n, const sgr_densify_params* p, int variant, const float* xyz, const float* scaling,
+                           const float* rotation, const float* opacity, const float* sphere, const float* box,
+                           const float* box_normals, uint8_t* prune, int64_t counts[4], void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!p || !counts) return sgr_set_error(SGR_E_INVALID, "p and counts are required");
+    for (int k = 0; k < 4; k++) counts[k] = 0;
+    if (n <= 0) return 0;
+    if (!xyz || !scaling || !opacity || !prune) return sgr_set_error(SGR_E_INVALID, "xyz, scaling, opacity and prune are required");
+    if (variant < SGR_PRUNE_BASE || variant > SGR_PRUNE_ACTOR) return sgr_set_error(SGR_E_INVALID, "unknown prune variant");
+    DnSphere sph = {0.f, 0.f, 0.f, 0.f};
+    DnBox bx = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    if (variant == SGR_PRUNE_BKGD) {
+        if (!sphere) return sgr_set_error(SGR_E_INVALID, "the background rule needs sphere = {cx, cy, cz, radius}");
+        sph = {sphere[0], sphere[1], sphere[2], sphere[3]};
+    }
+    if (variant == SGR_PRUNE_ACTOR && p->prune_big) {
+        if (!box || !box_normals || !rotation)
+            return sgr_set_error(SGR_E_INVALID, "the actor rule needs box, box_normals and rotation");
+        for (int a = 0; a < 3; a++) { bx.lo[a] = box[a]; bx.hi[a] = box[3 + a]; }
+    }
+    static thread_local uint32_t* cnt[64] = {};  // 16-byte counter block per (host thread, device), kept
+    int dev = 0;
+    DN_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return sgr_set_error(SGR_E_INVALID, "device index out of range");
+    if (!cnt[dev]) DN_HIP(hipMalloc((void**)&cnt[dev], 256));
+    DN_HIP(hipMemsetAsync(cnt[dev], 0, 16, stream));
+    sgr_densify_prune_kernel<<<(n + 255) / 256, 256, 0, stream>>>(n, *p, variant, xyz, scaling, rotation, opacity, sph, bx,
+                                                                 box_normals, prune, cnt[dev]);
+    uint32_t h[4];
+    DN_HIP(hipMemcpyAsync(h, cnt[dev], 16, hipMemcpyDeviceToHost, stream));
+    DN_HIP(hipStreamSynchronize(stream));
+    for (int k = 0; k < 4; k++) counts[k] = h[k];
+    return 0;
+}
+
+int sgr_densify_compact(int n, const uint8_t* prune, char* work, int32_t* sel, int64_t* n_out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!n_out) return sgr_set_error(SGR_E_INVALID, "n_out is required");
+    *n_out = 0;
+    if (n <= 0) return 0;
+    if (!prune || !work || !sel) return sgr_set_error(SGR_E_INVALID, "prune, work and sel are required");
+    const DnWork w = dn_carve((char*)sgr_align_up((size_t)work, 256), (size_t)n);
+    sgr_densify_keep_flags_kernel<<<(n + 255) / 256, 256, 0, stream>>>(n, prune, w.offA);
+    sgr_launch_scan(w.offA, w.offA, (size_t)n, w.tmp, false, stream, w.totals + 0);
+    sgr_densify_compact_kernel<<<(n + 255) / 256, 256, 0, stream>>>(n, prune, w.offA, sel);
+    uint32_t t = 0;
+    DN_HIP(hipMemcpyAsync(&t, w.totals, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    DN_HIP(hipStreamSynchronize(stream));
+    *n_out = t;
+    return 0;
+}
+
+int sgr_reset_opacity(int N, float* opacity, float* exp_avg, float* exp_avg_sq, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N <= 0) return 0;
+    if (!opacity) return sgr_set_error(SGR_E_INVALID, "opacity is required");
+    sgr_reset_opacity_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, opacity, exp_avg, exp_avg_sq);
+    DN_HIP(hipGetLastError());
+    return 0;
+}
 
 size_t sgr_densify_work_bytes(int N) {
     char* base = (char*)4096;

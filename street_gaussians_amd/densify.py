@@ -7,7 +7,15 @@ it returns the new parameter tensors, the new Adam moments and the reference's `
 results back into ``nn.Parameter`` / ``optimizer.state`` stays with the caller.
 
 The split draws ``samples = normal(0, std)``; here the caller may pass the standard normals (``normals``), otherwise
-they are drawn with ``torch.randn`` -- same distribution, not the same random stream.  GPU only."""
+they are drawn with ``torch.randn`` -- same distribution, not the same random stream.  GPU only.
+
+``variant`` selects the prune rule of the model classes street_gaussians instantiates (both override the base method):
+``"bkgd"`` = GaussianModelBkgd.densify_and_prune (gaussian_model_bkgd.py:74-114: big points farther than
+2 * sphere_radius from sphere_center are exempt; scalars also carry points_below_min_opacity / points_big_ws) and
+``"actor"`` = GaussianModelActor.densify_and_prune (gaussian_model_actor.py:204-261: points whose sampled extent
+leaves the tracking box are pruned).  Those rules look at the NEW points' positions, so the candidates (kept originals,
+clones, split children) are laid out first and pruned in a second step (sgr_densify_prune_mask / _compact).
+``reset_opacity`` is GaussianModel.reset_opacity (gaussian_model.py:410-414)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -23,7 +31,11 @@ PARAMS = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "semantic")
 
 class _CParams(C.Structure):
     _fields_ = [("max_grad", C.c_float), ("min_opacity", C.c_float), ("extent", C.c_float), ("percent_dense", C.c_float),
-                ("percent_big_ws", C.c_float), ("prune_big", C.c_int32), ("grad_column", C.c_int32), ("n_split", C.c_int32)]
+                ("percent_big_ws", C.c_float), ("prune_big", C.c_int32), ("grad_column", C.c_int32), ("n_split", C.c_int32),
+                ("defer_prune", C.c_int32)]
+
+
+_VARIANTS = {None: 0, "base": 0, "bkgd": 1, "actor": 2}
 
 
 def _p(t):
@@ -33,11 +45,23 @@ def _p(t):
 def densify_and_prune(params: Dict[str, torch.Tensor], xyz_gradient_accum: torch.Tensor, denom: torch.Tensor, *,
                       max_grad: float, min_opacity: float, extent: float, percent_dense: float, percent_big_ws: float,
                       prune_big: bool, states: Optional[Dict[str, Tuple[torch.Tensor, torch.Tensor]]] = None,
-                      grad_column: int = 0, n_split: int = 2, normals: Optional[torch.Tensor] = None):
+                      grad_column: int = 0, n_split: int = 2, normals: Optional[torch.Tensor] = None,
+                      variant: Optional[str] = None, sphere_center=None, sphere_radius: Optional[float] = None,
+                      box_min=None, box_max=None, box_normals: Optional[torch.Tensor] = None):
     """params: {'xyz' [N,3], 'f_dc' [N,C,3], 'f_rest' [N,M-1,3], 'opacity' [N,1], 'scaling' [N,3], 'rotation' [N,4],
     'semantic' [N,S]} raw parameters; states: optional {name: (exp_avg, exp_avg_sq)} shaped like the parameters.
     Returns (new_params, new_states, scalars, index) with scalars = {'points_total', 'points_clone', 'points_split',
-    'points_pruned'} and index = {'src', 'kind'} (source row and 0 keep / 1 clone / 2 split child per result row)."""
+    'points_pruned'} and index = {'src', 'kind'} (source row and 0 keep / 1 clone / 2 split child per result row).
+    variant "bkgd" needs sphere_center [3] and sphere_radius; variant "actor" needs box_min / box_max [3] and takes
+    box_normals [n_candidates, 2, 3] (standard normals; drawn when omitted)."""
+    if variant not in _VARIANTS:
+        raise ValueError(f"unknown variant {variant!r}")
+    if _VARIANTS[variant] != 0:
+        return _densify_two_step(params, xyz_gradient_accum, denom, max_grad=max_grad, min_opacity=min_opacity,
+                                 extent=extent, percent_dense=percent_dense, percent_big_ws=percent_big_ws,
+                                 prune_big=prune_big, states=states, grad_column=grad_column, n_split=n_split,
+                                 normals=normals, variant=variant, sphere_center=sphere_center,
+                                 sphere_radius=sphere_radius, box_min=box_min, box_max=box_max, box_normals=box_normals)
     xyz = params["xyz"]
     if not xyz.is_cuda:
         raise SgrError("densify_and_prune needs HIP (cuda) tensors: there is no CPU path")
@@ -45,7 +69,7 @@ def densify_and_prune(params: Dict[str, torch.Tensor], xyz_gradient_accum: torch
     L = _native.lib()
     f32 = lambda t: t.detach().to(torch.float32).contiguous()
     cp = _CParams(float(max_grad), float(min_opacity), float(extent), float(percent_dense), float(percent_big_ws),
-                  int(bool(prune_big)), int(grad_column), int(n_split))
+                  int(bool(prune_big)), int(grad_column), int(n_split), 0)
     counts = (C.c_int64 * 6)()
     work = torch.empty(L.sgr_densify_work_bytes(N), dtype=torch.uint8, device=dev)
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -80,3 +104,116 @@ def densify_and_prune(params: Dict[str, torch.Tensor], xyz_gradient_accum: torch
     scalars = {"points_total": int(counts[0]), "points_clone": int(counts[1]), "points_split": int(counts[2]),
                "points_pruned": int(counts[3])}
     return new_params, new_states, scalars, {"src": src, "kind": kind}
+
+
+def _gather(L, t, src, kind, n_out, zero_new, stream, N):
+    t = t.detach().to(torch.float32).contiguous()
+    width = t[0].numel() if N else 0
+    out = torch.empty((n_out,) + tuple(t.shape[1:]), dtype=torch.float32, device=t.device)
+    check(L.sgr_densify_gather(n_out, width, _p(t), _p(src), _p(kind), int(zero_new), _p(out), stream))
+    return out
+
+
+def _densify_two_step(params, xyz_gradient_accum, denom, *, max_grad, min_opacity, extent, percent_dense, percent_big_ws,
+                      prune_big, states, grad_column, n_split, normals, variant, sphere_center, sphere_radius, box_min,
+                      box_max, box_normals):
+    xyz = params["xyz"]
+    if not xyz.is_cuda:
+        raise SgrError("densify_and_prune needs HIP (cuda) tensors: there is no CPU path")
+    dev, N = xyz.device, xyz.shape[0]
+    L = _native.lib()
+    f32 = lambda t: t.detach().to(torch.float32).contiguous()
+    cp = _CParams(float(max_grad), float(min_opacity), float(extent), float(percent_dense), float(percent_big_ws),
+                  int(bool(prune_big)), int(grad_column), int(n_split), 1)
+    counts = (C.c_int64 * 6)()
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    acc, den, sc, op = f32(xyz_gradient_accum), f32(denom), f32(params["scaling"]), f32(params["opacity"])
+    with torch.cuda.device(dev):
+        work = torch.empty(L.sgr_densify_work_bytes(N), dtype=torch.uint8, device=dev)
+        check(L.sgr_densify_plan(N, C.byref(cp), _p(acc), _p(den), _p(sc), _p(op), _p(work), counts, stream))
+        n_cand, n_norm = int(counts[4]), int(counts[5])
+        src = torch.empty(n_cand, dtype=torch.int32, device=dev)
+        kind = torch.empty(n_cand, dtype=torch.uint8, device=dev)
+        srow = torch.empty(n_cand, dtype=torch.int32, device=dev)
+        check(L.sgr_densify_map(N, C.byref(cp), _p(work), _p(src), _p(kind), _p(srow), stream))
+        # the candidates' geometry: gathered rows, split children computed
+        cand = {k: _gather(L, params[k], src, kind, n_cand, False, stream, N) for k in ("xyz", "scaling", "rotation", "opacity")}
+        if n_norm:
+            if normals is None:
+                normals = torch.randn(n_norm, 3, device=dev)
+            if tuple(normals.shape) != (n_norm, 3):
+                raise RuntimeError(f"normals must have dimensions ({n_norm}, 3)")
+            check(L.sgr_densify_split_children(n_cand, int(n_split), _p(src), _p(kind), _p(srow), _p(f32(params["xyz"])),
+                                               _p(sc), _p(f32(params["rotation"])), _p(f32(normals)), _p(cand["xyz"]),
+                                               _p(cand["scaling"]), stream))
+        sphere = box = None
+        if variant == "bkgd":
+            if sphere_center is None or sphere_radius is None:
+                raise ValueError('variant "bkgd" needs sphere_center and sphere_radius')
+            c = [float(v) for v in torch.as_tensor(sphere_center).flatten().tolist()]
+            sphere = (C.c_float * 4)(c[0], c[1], c[2], float(torch.as_tensor(sphere_radius).flatten()[0]))
+        if variant == "actor" and prune_big:
+            if box_min is None or box_max is None:
+                raise ValueError('variant "actor" needs box_min and box_max')
+            lo = [float(v) for v in torch.as_tensor(box_min).flatten().tolist()]
+            hi = [float(v) for v in torch.as_tensor(box_max).flatten().tolist()]
+            box = (C.c_float * 6)(*lo, *hi)
+            if box_normals is None:
+                box_normals = torch.randn(n_cand, 2, 3, device=dev)
+            if tuple(box_normals.shape) != (n_cand, 2, 3):
+                raise RuntimeError(f"box_normals must have dimensions ({n_cand}, 2, 3)")
+            box_normals = f32(box_normals)
+        prune = torch.empty(n_cand, dtype=torch.uint8, device=dev)
+        pc = (C.c_int64 * 4)()
+        check(L.sgr_densify_prune_mask(n_cand, C.byref(cp), _VARIANTS[variant], _p(cand["xyz"]), _p(cand["scaling"]),
+                                       _p(cand["rotation"]), _p(cand["opacity"]), sphere, box,
+                                       _p(box_normals) if box is not None else None, _p(prune), pc, stream))
+        sel = torch.empty(n_cand, dtype=torch.int32, device=dev)
+        n_out = C.c_int64(0)
+        work2 = torch.empty(L.sgr_densify_work_bytes(n_cand), dtype=torch.uint8, device=dev)
+        check(L.sgr_densify_compact(n_cand, _p(prune), _p(work2), _p(sel), C.byref(n_out), stream))
+        n_out = int(n_out.value)
+        sel = sel[:n_out]
+        sel64 = sel.long()
+        src_f, kind_f = src[sel64].contiguous(), kind[sel64].contiguous()
+        keep0 = torch.zeros(n_out, dtype=torch.uint8, device=dev)  # rows copied from the candidate arrays as they are
+        new_params = {}
+        for k in PARAMS:
+            if k not in params:
+                continue
+            if k in cand:
+                new_params[k] = _gather(L, cand[k], sel, keep0, n_out, False, stream, n_cand)
+                if params[k].dim() != new_params[k].dim():
+                    new_params[k] = new_params[k].reshape((n_out,) + tuple(params[k].shape[1:]))
+            else:
+                new_params[k] = _gather(L, params[k], src_f, kind_f, n_out, False, stream, N)
+        new_states = None
+        if states is not None:
+            new_states = {k: (_gather(L, a, src_f, kind_f, n_out, True, stream, N), _gather(L, b, src_f, kind_f, n_out, True, stream, N))
+                          for k, (a, b) in states.items()}
+    scalars = {"points_total": int(counts[0]), "points_clone": int(counts[1]), "points_split": int(counts[2]),
+               "points_pruned": int(pc[3])}
+    if variant == "bkgd":
+        scalars["points_below_min_opacity"] = int(pc[0])
+        if prune_big:
+            scalars["points_big_ws"] = int(pc[1])
+    return new_params, new_states, scalars, {"src": src_f, "kind": kind_f}
+
+
+def reset_opacity(opacity: torch.Tensor, state: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+    """GaussianModel.reset_opacity (gaussian_model.py:410-414): returns inverse_sigmoid(min(sigmoid(opacity), 0.01)) as a
+    new tensor; ``state`` = the group's (exp_avg, exp_avg_sq), zero-filled IN PLACE like reset_optimizer (:344-361)."""
+    if not opacity.is_cuda:
+        raise SgrError("reset_opacity needs a HIP (cuda) tensor: there is no CPU path")
+    dev = opacity.device
+    out = opacity.detach().to(torch.float32).contiguous().clone()
+    a = b = None
+    if state is not None:
+        a, b = state
+        for t in (a, b):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != out.numel():
+                raise SgrError("the Adam moments must be contiguous float32 tensors shaped like opacity")
+    with torch.cuda.device(dev):
+        check(_native.lib().sgr_reset_opacity(out.numel(), _p(out), _p(a), _p(b),
+                                              C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return out

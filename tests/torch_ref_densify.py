@@ -36,8 +36,18 @@ class Model:
             self.p[k] = self.p[k][keep]
             self.s[k] = (self.s[k][0][keep], self.s[k][1][keep])
 
+    def reset_opacity(self):  # gaussian_model.py:410-414 with reset_optimizer :344-361
+        op = torch.sigmoid(self.p["opacity"])
+        x = torch.min(op, torch.ones_like(op) * 0.01)
+        self.p["opacity"] = torch.log(x / (1 - x))
+        self.s["opacity"] = (torch.zeros_like(self.p["opacity"]), torch.zeros_like(self.p["opacity"]))
+
     def densify_and_prune(self, max_grad, min_opacity, extent, percent_dense, percent_big_ws, prune_big, normals,
-                          grad_column=0, N=2):
+                          grad_column=0, N=2, variant=None, sphere_center=None, sphere_radius=None, box_min=None,
+                          box_max=None, box_normals=None):
+        """variant None: GaussianModel (gaussian_model.py:522-553); "bkgd": GaussianModelBkgd
+        (gaussian_model_bkgd.py:74-114); "actor": GaussianModelActor (gaussian_model_actor.py:204-261), whose
+        torch.normal(mean=0, std=scale) samples are box_normals * scale."""
         scalars = {"points_total": self.p["xyz"].shape[0]}
         grads = self.accum[:, grad_column:grad_column + 1] / self.denom      # :523
         grads[grads.isnan()] = 0.0                                           # :524
@@ -62,8 +72,24 @@ class Model:
         self._prune(torch.cat((sel, torch.zeros(N * int(sel.sum()), dtype=torch.bool, device=sel.device))))
         # prune (:532-543)
         mask = (torch.sigmoid(self.p["opacity"]) < min_opacity).squeeze(-1)
+        if variant == "bkgd":
+            scalars["points_below_min_opacity"] = int(mask.sum())
         if prune_big:
-            mask = mask | (scale().max(dim=1).values > extent * percent_big_ws)
+            big = scale().max(dim=1).values > extent * percent_big_ws
+            if variant == "bkgd":  # gaussian_model_bkgd.py:95-101
+                dists = torch.linalg.norm(self.p["xyz"] - sphere_center, dim=1)
+                big[dists > 2 * sphere_radius] = False
+                scalars["points_big_ws"] = int(big.sum())
+            mask = mask | big
+            if variant == "actor":  # gaussian_model_actor.py:231-249
+                stds = scale()[:, None, :].expand(-1, 2, -1)
+                samples = box_normals.to(stds.dtype) * stds
+                rots = _rotmat(self.p["rotation"])[:, None, :, :].expand(-1, 2, -1, -1)
+                origins = self.p["xyz"][:, None, :].expand(-1, 2, -1)
+                sx = torch.matmul(rots, samples.unsqueeze(-1)).squeeze(-1) + origins
+                n = sx.shape[0]
+                inside = torch.all((sx >= box_min).view(n, -1), dim=-1) & torch.all((sx <= box_max).view(n, -1), dim=-1)
+                mask = mask | ~inside
         self._prune(mask)
         scalars["points_pruned"] = int(mask.sum())
         return scalars
