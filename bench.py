@@ -269,20 +269,21 @@ class Workload:
 
 def load_scene_file(path, S):
     """A scene in the reference's on-disk layout (one `vertex_<model>` element per sub-model,
-    street_gaussian_model.py:94-117), flattened to rasterizer inputs: activations applied as the model's getters do
-    (gaussian_model.py:224-251), all sub-models concatenated, actors left in their stored frame."""
-    from street_gaussians_amd import plyio
-    models = plyio.read_scene_ply(path)
-    cat = lambda k: torch.cat([torch.as_tensor(m[k]) for m in models.values()], 0).float()
+    street_gaussian_model.py:94-117; or a .pth checkpoint, train.py:218-223), flattened to rasterizer inputs: activations
+    applied as the model's getters do (gaussian_model.py:224-251), all sub-models concatenated, actors left in their
+    stored (object) frame, the first Fourier coefficient as their DC colour."""
+    from street_gaussians_amd import checkpoint, plyio
+    models = checkpoint.load(path) if path.endswith(".pth") else plyio.read_scene_ply(path)
+    ten = lambda v: torch.as_tensor(v).float()
+    cat = lambda k: torch.cat([ten(m[k]) for m in models.values()], 0)
     xyz = cat("xyz")
-    shs = torch.cat([cat("f_dc"), cat("f_rest")], 1)
-    sem = cat("semantic") if all("semantic" in m for m in models.values()) else torch.zeros(xyz.shape[0], 0)
-    if S and sem.shape[1] != S:
-        sem = torch.zeros(xyz.shape[0], S)
+    dc = torch.cat([ten(m["features_dc"])[:, :1, :] for m in models.values()], 0)
+    shs = torch.cat([dc, cat("features_rest")], 1)
+    sem = torch.zeros(xyz.shape[0], S)
     rot = cat("rotation")
     return syn.Scene(xyz.contiguous(), torch.exp(cat("scaling")).contiguous(),
                      (rot / rot.norm(dim=1, keepdim=True)).contiguous(), torch.sigmoid(cat("opacity")).contiguous(),
-                     shs.contiguous(), (sem[:, :S] if S else sem[:, :0]).contiguous())
+                     shs.contiguous(), sem.contiguous())
 
 
 def profiled_steps(L, wl, fence, steps, stage_mask):

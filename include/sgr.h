@@ -68,6 +68,30 @@ int sgr_backward(int P, int D, int M, int R, int S, const float* background, int
                  float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                  float* dL_dsemantic, sgr_alloc_fn scratch, void* scratch_user, int debug, void* stream);
 
+/* sgr_backward with optional extras (NULL = plain sgr_backward).
+ * Densification statistics sink: the per-Gaussian epilogue of the backward holds dL/dmean2D and the radius in
+ * registers, so it can apply this view's set_max_radii2D + add_densification_stats
+ * (lib/models/street_gaussian_model.py:551-571) in place -- for every Gaussian with radii > 0:
+ *   xyz_gradient_accum[g,0] += |dL/dmean2D[g,:2]|,  xyz_gradient_accum[g,1] += |dL/dmean2D[g,2]|,  denom[g] += 1,
+ *   max_radii2D[g] = max(max_radii2D[g], radii[g])
+ * -- instead of six masked torch ops per sub-model afterwards.  The three arrays cover all P Gaussians of the call in
+ * its order (street_gaussians_amd.scene.FlatStats keeps the sub-models' statistics as views of such arrays). */
+typedef struct sgr_backward_extras {
+    float* xyz_gradient_accum; /* [P,2] or NULL */
+    float* denom;              /* [P,1] */
+    float* max_radii2D;        /* [P]   */
+} sgr_backward_extras;
+int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, int width, int height,
+                    const float* means3D, const float* shs, const float* colors_precomp, const float* semantics,
+                    const float* alphas, const float* scales, float scale_modifier, const float* rotations,
+                    const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+                    float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer,
+                    char* image_buffer, const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dalphas,
+                    const float* dL_dpix_semantic, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
+                    float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                    float* dL_dsemantic, sgr_alloc_fn scratch, void* scratch_user, int debug, void* stream,
+                    const sgr_backward_extras* extras);
+
 /* ---- view-sharded multi-GPU training (BASELINE.json north_star; no counterpart in the single-GPU reference) -------
  * The SH gradient of one view is rank-1: dL/dSH[k][c] = Y_k(dir) * dRGB[c] (cuda_rasterizer/backward.cu:46-105), so
  * ranks exchange the 3 floats of dRGB per Gaussian instead of the 3*M floats of dL/dSH and rebuild the sum locally.

@@ -15,6 +15,10 @@ from ._native import ALLOC_FN, SgrError, check
 NUM_CHANNELS = 3  # config.h:15
 
 
+class _BackwardExtras(C.Structure):  # sgr_backward_extras (include/sgr.h)
+    _fields_ = [("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p), ("max_radii2D", C.c_void_p)]
+
+
 def _dev_check(t: torch.Tensor, name: str):
     if not t.is_cuda:
         raise SgrError(f"{name} must be a HIP (cuda) tensor: street_gaussians_amd has no CPU path")
@@ -89,9 +93,11 @@ def rasterize_gaussians(background, means3D, colors, semantics, opacity, scales,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                  dL_dout_alpha, dL_dout_semantic, sh, degree, campos, geomBuffer, R, binningBuffer,
-                                 imageBuffer, alphas, semantics, debug):
+                                 imageBuffer, alphas, semantics, debug, stats=None):
     """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:126-220).  Returns
-    (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dsemantic)."""
+    (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dsemantic).
+    stats (extension): (xyz_gradient_accum [P,2], denom [P,1], max_radii2D [P]) contiguous float32 tensors updated in
+    place with this view's densification statistics (sgr_backward_ex)."""
     _dev_check(means3D, "means3D")
     dev = means3D.device
     P = means3D.size(0)
@@ -121,7 +127,14 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             keep.append(t)
             return ptr
         vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
-        check(_native.lib().sgr_backward(
+        extras = None
+        if stats is not None:
+            acc, den, mr = stats
+            for t, n in ((acc, 2 * P), (den, P), (mr, P)):
+                if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n):
+                    raise SgrError("densification statistics must be contiguous float32 HIP tensors covering all P Gaussians")
+            extras = _BackwardExtras(acc.data_ptr(), den.data_ptr(), mr.data_ptr())
+        check(_native.lib().sgr_backward_ex(
             P, int(degree), M, int(R), S, p(background, "bg"), W, H, p(means3D, "means3D"), p(sh, "sh"),
             p(colors, "colors_precomp"), p(semantics, "semantics"), p(alphas, "alpha"), p(scales, "scales"),
             float(scale_modifier), p(rotations, "rotations"), p(cov3D_precomp, "cov3D_precomp"),
@@ -130,7 +143,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             p(dL_dout_color, "dL_dout_color"), p(dL_dout_depth, "dL_dout_depth"), p(dL_dout_alpha, "dL_dout_alpha"),
             p(dL_dout_semantic, "dL_dout_semantic"), vp(dL_dmeans2D), vp(dL_dopacity), vp(dL_dcolors), vp(dL_dmeans3D),
             vp(dL_dcov3D), vp(dL_dsh), vp(dL_dscales), vp(dL_drotations), vp(dL_dsemantic), scratch.cb, None,
-            int(bool(debug)), _stream(dev)))
+            int(bool(debug)), _stream(dev), C.byref(extras) if extras is not None else None))
     return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations,
             dL_dsemantic)
 

@@ -18,7 +18,7 @@ _lib = None
 
 # every symbol include/sgr.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "sgr_last_error", "sgr_version", "sgr_forward", "sgr_backward", "sgr_mark_visible", "sgr_visible_filter",
+    "sgr_last_error", "sgr_version", "sgr_forward", "sgr_backward", "sgr_backward_ex", "sgr_mark_visible", "sgr_visible_filter",
     "sgr_knn", "sgr_geometry_bytes", "sgr_binning_bytes", "sgr_image_bytes", "sgr_partial_row_floats",
     "sgr_export_internal", "sgr_test_scan", "sgr_test_sort", "sgr_test_sort32", "sgr_test_sort_hist_words", "sgr_test_scan_tmp_words",
     "sgr_test_wave_sum", "sgr_test_switches", "sgr_profile_enable", "sgr_profile_select", "sgr_profile_read", "sgr_masked_color_grad",
@@ -59,6 +59,8 @@ def lib():
         L.sgr_backward.restype = i
         L.sgr_backward.argtypes = [i, i, i, i, i, vp, i, i, vp, vp, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, f, f, vp, vp,
                                    vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ALLOC_FN, vp, i, vp]
+        L.sgr_backward_ex.restype = i
+        L.sgr_backward_ex.argtypes = L.sgr_backward.argtypes + [vp]
         L.sgr_mark_visible.restype = i
         L.sgr_mark_visible.argtypes = [i, vp, vp, vp, vp, vp]
         L.sgr_visible_filter.restype = i

@@ -41,7 +41,7 @@ void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, cons
                           const SgrGeomView& gv, const float* partials, int row_stride, const uint8_t* touched,
                           float4* cd, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dsemantic,
-                          hipStream_t s);
+                          const SgrStatSink& sink, hipStream_t s);
 void sgr_launch_masked_color_grad(int P, const uint32_t* clamped, const float* dL_dcolor, float* out, hipStream_t s);
 void sgr_launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* campos,
                                    const float* drgb, float* dL_dsh, hipStream_t s);
@@ -344,7 +344,32 @@ int sgr_backward(int P, int D, int M, int R, int S, const float* background, int
                  const float* dL_dpix_semantic, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
                  float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                  float* dL_dsemantic, sgr_alloc_fn scratch, void* scratch_user, int debug, void* stream_) {
+    return sgr_backward_ex(P, D, M, R, S, background, width, height, means3D, shs, colors_precomp, semantics, alphas, scales,
+                           scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy,
+                           radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_dpix_depth, dL_dalphas,
+                           dL_dpix_semantic, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
+                           dL_drot, dL_dsemantic, scratch, scratch_user, debug, stream_, nullptr);
+}
+
+int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, int width, int height,
+                    const float* means3D, const float* shs, const float* colors_precomp, const float* semantics,
+                    const float* alphas, const float* scales, float scale_modifier, const float* rotations,
+                    const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+                    float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer,
+                    char* image_buffer, const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dalphas,
+                    const float* dL_dpix_semantic, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
+                    float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                    float* dL_dsemantic, sgr_alloc_fn scratch, void* scratch_user, int debug, void* stream_,
+                    const sgr_backward_extras* extras) {
     hipStream_t stream = (hipStream_t)stream_;
+    SgrStatSink sink;
+    if (extras && (extras->xyz_gradient_accum || extras->denom || extras->max_radii2D)) {
+        if (!extras->xyz_gradient_accum || !extras->denom || !extras->max_radii2D)
+            return fail(SGR_E_INVALID, "the statistics sink needs xyz_gradient_accum, denom and max_radii2D together");
+        sink.accum = extras->xyz_gradient_accum;
+        sink.denom = extras->denom;
+        sink.max_radii = extras->max_radii2D;
+    }
     (void)colors_precomp; (void)scale_modifier; (void)viewmatrix; (void)projmatrix; (void)campos;
     (void)tan_fovx; (void)tan_fovy;  // already resident in the geometry buffer's camera block
     if (P <= 0) return 0;
@@ -395,7 +420,7 @@ int sgr_backward(int P, int D, int M, int R, int S, const float* background, int
     prof_begin(8, stream);
     sgr_launch_gauss_bwd(P, D, M, S, means3D, radii_ptr, shs, scales, rotations, cov3D_precomp, cam_slot(gv), gv, partials,
                          stride, touched, cd, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
-                         dL_drot, dL_dsemantic, stream);
+                         dL_drot, dL_dsemantic, sink, stream);
     SGR_STAGE("gauss_bwd");
     prof_end(stream);
     return 0;

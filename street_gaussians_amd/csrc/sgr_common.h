@@ -56,6 +56,13 @@ struct SgrBinView {
     uint8_t* hit4;       // per sorted instance: bit q = the forward blended it into >= 1 pixel of quadrant q of its tile
 };
 
+// optional sink of the backward for this view's densification statistics (sgr_backward_ex); all three or none
+struct SgrStatSink {
+    float* accum = nullptr;      // xyz_gradient_accum [P,2]
+    float* denom = nullptr;      // [P,1]
+    float* max_radii = nullptr;  // max_radii2D [P]
+};
+
 struct SgrImgView {
     uint32_t* n_contrib;
     uint2* ranges;

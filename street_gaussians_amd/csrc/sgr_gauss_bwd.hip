@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(SGR_GB_THREADS)
 sgr_row_sum_kernel(int P, int S, const int* __restrict__ radii, SgrGeomView gv, const float* __restrict__ partials,
                    int row_stride, const uint8_t* __restrict__ touched, float* __restrict__ dL_dmean2D,
                    float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dsemantic,
-                   float4* __restrict__ cd) {
+                   float4* __restrict__ cd, SgrStatSink sink) {
     constexpr int NV = (SGR_ROW_BASE_N + SMAX + 3) / 4;
     const int gtid = blockIdx.x * SGR_GB_THREADS + threadIdx.x;
     const int idx = gtid / SGR_RS_LANES, q = gtid % SGR_RS_LANES;
@@ -83,6 +83,16 @@ sgr_row_sum_kernel(int P, int S, const int* __restrict__ radii, SgrGeomView gv, 
         dL_dmean2D[3 * idx + 0] = acc[0];
         dL_dmean2D[3 * idx + 1] = acc[1];
         dL_dmean2D[3 * idx + 2] = acc[2];
+        // densification statistics of this view (set_max_radii2D + add_densification_stats,
+        // street_gaussian_model.py:551-571) while dL/dmean2D and the radius are in registers: visibility = radii > 0
+        const int r = radii[idx];
+        if (sink.accum != nullptr && r > 0) {
+#pragma clang fp contract(off)
+            sink.accum[2 * (size_t)idx] += sqrtf(acc[0] * acc[0] + acc[1] * acc[1]);  // norm of grad[:, :2]
+            sink.accum[2 * (size_t)idx + 1] += fabsf(acc[2]);                          // norm of grad[:, 2:]
+            sink.denom[idx] += 1.0f;
+            sink.max_radii[idx] = fmaxf(sink.max_radii[idx], (float)r);
+        }
     } else if (q == 1) {
         dL_dopacity[idx] = acc[6];
         dL_dcolor[3 * idx + 0] = acc[7];
@@ -272,13 +282,13 @@ void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, cons
                           const SgrGeomView& gv, const float* partials, int row_stride, const uint8_t* touched,
                           float4* cd, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dsemantic,
-                          hipStream_t s) {
+                          const SgrStatSink& sink, hipStream_t s) {
     if (P <= 0) return;
     const unsigned nb = (P + SGR_GB_THREADS - 1) / SGR_GB_THREADS;
     const unsigned nb4 = (unsigned)(((size_t)P * SGR_RS_LANES + SGR_GB_THREADS - 1) / SGR_GB_THREADS);
 #define SGR_RS(N)                                                                                                    \
     sgr_row_sum_kernel<N><<<nb4, SGR_GB_THREADS, 0, s>>>(P, S, radii, gv, partials, row_stride, touched, dL_dmean2D,   \
-                                                        dL_dopacity, dL_dcolor, dL_dsemantic, cd)
+                                                        dL_dopacity, dL_dcolor, dL_dsemantic, cd, sink)
     if (S == 0) SGR_RS(0);
     else if (S <= 4) SGR_RS(4);
     else if (S <= 8) SGR_RS(8);

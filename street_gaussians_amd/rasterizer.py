@@ -20,9 +20,9 @@ def cpu_deep_copy_tuple(input_tuple):
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, semantics, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings):
+                        raster_settings, stats=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, semantics, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+                                     cov3Ds_precomp, raster_settings, stats)
 
 
 # callables invoked at the end of every rasterizer backward with that view's dL/dcolour, geometry buffer and camera
@@ -33,7 +33,7 @@ BACKWARD_OBSERVERS = []
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, semantics, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings):
+                raster_settings, stats=None):
         # argument order of the native entry point (reference __init__.py:62-83)
         args = (raster_settings.bg, means3D, colors_precomp, semantics, opacities, scales, rotations,
                 raster_settings.scale_modifier, cov3Ds_precomp, raster_settings.viewmatrix, raster_settings.projmatrix,
@@ -54,6 +54,7 @@ class _RasterizeGaussians(torch.autograd.Function):
              imgBuffer) = _C.rasterize_gaussians(*args)
 
         ctx.raster_settings = raster_settings
+        ctx.stats = stats  # extension: densification statistics updated by the backward (GaussianRasterizer.stats_sink)
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer, alpha, semantics)
@@ -71,18 +72,19 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raster_settings.tanfovy, grad_color, grad_depth, grad_alpha, grad_semantic, sh,
                 raster_settings.sh_degree, raster_settings.campos, geomBuffer, num_rendered, binningBuffer, imgBuffer,
                 alpha, semantics, raster_settings.debug)
+        stats = ctx.stats
         if raster_settings.debug:
             cpu_args = cpu_deep_copy_tuple(args)
             try:
                 (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
-                 grad_scales, grad_rotations, grad_semantics) = _C.rasterize_gaussians_backward(*args)
+                 grad_scales, grad_rotations, grad_semantics) = _C.rasterize_gaussians_backward(*args, stats=stats)
             except Exception as ex:
                 torch.save(cpu_args, "snapshot_bw.dump")
                 print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise ex
         else:
             (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
-             grad_scales, grad_rotations, grad_semantics) = _C.rasterize_gaussians_backward(*args)
+             grad_scales, grad_rotations, grad_semantics) = _C.rasterize_gaussians_backward(*args, stats=stats)
 
         for observer in list(BACKWARD_OBSERVERS):  # view-sharded training (multiview.FactoredGradReducer)
             observer(grad_colors=grad_colors_precomp, geomBuffer=geomBuffer, campos=raster_settings.campos,
@@ -92,7 +94,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         # autograd (None / empty placeholders) are dropped instead of returned and ignored
         need = ctx.needs_input_grad
         grads = (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_semantics, grad_opacities,
-                 grad_scales, grad_rotations, grad_cov3Ds_precomp, None)
+                 grad_scales, grad_rotations, grad_cov3Ds_precomp, None, None)
         grads = tuple(g if (g is not None and need[i]) else None for i, g in enumerate(grads))
         return grads
 
@@ -116,6 +118,10 @@ class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings):
         super().__init__()
         self.raster_settings = raster_settings
+        # extension (not in the reference): (xyz_gradient_accum [P,2], denom [P,1], max_radii2D [P]) float32 tensors that
+        # the backward of the next forward updates in place with the view's densification statistics
+        # (street_gaussian_model.py:551-571) -- see street_gaussians_amd.scene.FlatStats
+        self.stats_sink = None
 
     def markVisible(self, positions):
         # Mark visible points (based on frustum culling for camera) with a boolean
@@ -150,7 +156,7 @@ class GaussianRasterizer(nn.Module):
             semantics = torch.zeros(means3D.shape[0], 0, dtype=torch.float32, device=means3D.device)
 
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, semantics, opacities, scales, rotations,
-                                   cov3D_precomp, raster_settings)
+                                   cov3D_precomp, raster_settings, self.stats_sink)
 
     def visible_filter(self, means3D, scales=None, rotations=None, cov3D_precomp=None):
         raster_settings = self.raster_settings

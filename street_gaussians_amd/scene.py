@@ -211,3 +211,31 @@ def densification_stats(models: Sequence[dict], dL_dmeans2D: torch.Tensor, radii
     with torch.cuda.device(dev):
         check(_native.lib().sgr_scene_densification_stats(len(models), arr, _ptr(g), _ptr(r), grow.cb, None,
                                                           C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+
+
+class FlatStats:
+    """The sub-models' densification statistics (``xyz_gradient_accum`` [n,2], ``denom`` [n,1], ``max_radii2D`` [n] of
+    the reference's GaussianModel) kept as VIEWS of three flat tensors in concatenation order -- the layout the
+    rasterizer's backward updates in place when ``GaussianRasterizer.stats_sink = stats.sink()`` is set
+    (include/sgr.h: sgr_backward_ex), so that ``set_max_radii2D`` + ``add_densification_stats``
+    (street_gaussian_model.py:551-571) cost nothing extra.  After a densification step the point counts change:
+    build a new FlatStats (the reference re-creates the three tensors as zeros there as well, gaussian_model.py:545-547).
+    """
+
+    def __init__(self, counts: Sequence[int], device):
+        self.counts = [int(c) for c in counts]
+        n = sum(self.counts)
+        self.xyz_gradient_accum = torch.zeros(n, 2, dtype=torch.float32, device=device)
+        self.denom = torch.zeros(n, 1, dtype=torch.float32, device=device)
+        self.max_radii2D = torch.zeros(n, dtype=torch.float32, device=device)
+
+    def sink(self):
+        return self.xyz_gradient_accum, self.denom, self.max_radii2D
+
+    def views(self) -> List[dict]:
+        out, start = [], 0
+        for c in self.counts:
+            out.append({"xyz_gradient_accum": self.xyz_gradient_accum[start:start + c], "denom": self.denom[start:start + c],
+                        "max_radii2D": self.max_radii2D[start:start + c]})
+            start += c
+        return out

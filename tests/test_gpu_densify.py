@@ -63,8 +63,8 @@ def _check(new_p, new_s, got, index, m, want, keys):
         assert got[k] == want[k], (k, got[k], want[k])
     for k in ref.NAMES:
         assert new_p[k].shape == m.p[k].shape, k
-        if k in ("xyz", "scaling"):  # split children are computed, not copied
-            assert torch.allclose(new_p[k].cpu(), m.p[k], rtol=2e-6, atol=2e-6), k
+        if k in ("xyz", "scaling"):  # split children are computed, not copied (R (z * s) + mu with s up to ~50 here)
+            assert torch.allclose(new_p[k].cpu(), m.p[k], rtol=2e-5, atol=2e-5), k
             keep = (index["kind"] != 2).cpu()
             assert torch.equal(new_p[k].cpu()[keep], m.p[k][keep]), k
         else:

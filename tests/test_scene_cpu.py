@@ -93,3 +93,95 @@ def test_scene_abi_symbols_are_exported():
     assert len(names) == 3
     for n in names:
         assert hasattr(L, n), n
+
+
+# ---- pin of the flattening itself: the reference's OWN property getters, cut out of its source and executed on stub
+# objects (street_gaussian_model.py:287-449, gaussian_model.py:224-251, gaussian_model_actor.py:55-80) ----------------
+SGM = "/root/reference/lib/models/street_gaussian_model.py"
+GMP = "/root/reference/lib/models/gaussian_model.py"
+GMA = "/root/reference/lib/models/gaussian_model_actor.py"
+
+
+def _getters(path, names, ns, prop=True):
+    src = open(path).read()
+    out = {}
+    for name in names:
+        pat = rf"^    @property\n    def {name}\(self.*?(?=^    def |^    @|\Z)" if prop else rf"^    def {name}\(self.*?(?=^    def |^    @|\Z)"
+        m = re.search(pat, src, re.S | re.M)
+        assert m, (path, name)
+        body = "\n".join(ln[4:] if ln.startswith("    ") else ln for ln in m.group(0).split("\n"))
+        body = body.replace("@property\n", "").replace(".cuda()", "")
+        exec(body, ns)
+        out[name] = property(ns[name]) if prop else ns[name]
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(SGM), reason="reference checkout not present on this machine")
+@pytest.mark.parametrize("train,sem_mode", [(True, "logits"), (False, "probabilities")])
+def test_restated_flattening_matches_the_reference_getters(train, sem_mode):
+    import types
+    S, M = 4, 16
+    g = torch.Generator().manual_seed(11)
+    r = lambda *s: torch.randn(*s, generator=g)
+    cfg = types.SimpleNamespace(mode="train" if train else "eval")
+    idft_rows = {}
+
+    def IDFT(time, dim):  # lib/utils/general_utils.py: only its result is used here; the row is an input of the test
+        return idft_rows[dim][None]
+    ns = {"torch": torch, "cfg": cfg, "quaternion_raw_multiply": _reference_fn("quaternion_raw_multiply"),
+          "quaternion_to_matrix": _reference_fn("quaternion_to_matrix"), "IDFT": IDFT,
+          "GaussianModel": object, "GaussianModelActor": object}
+
+    Base = type("Base", (), _getters(GMP, ["get_scaling", "get_rotation", "get_xyz", "get_features", "get_semantic", "get_opacity"], ns))
+    actor_ns = dict(ns)
+    Actor = type("Actor", (Base,), {**_getters(GMA, ["get_semantic"], actor_ns),
+                                    **_getters(GMA, ["get_features_fourier"], actor_ns, prop=False)})
+    Street = type("Street", (), _getters(SGM, ["get_scaling", "get_rotation", "get_xyz", "get_features", "get_semantic", "get_opacity"], dict(ns)))
+
+    def model(cls, n, C, sem_cols):
+        m = cls()
+        m._xyz, m._rotation, m._scaling, m._opacity = r(n, 3), r(n, 4), r(n, 3) * 0.4, r(n, 1)
+        m._features_dc, m._features_rest, m._semantic = r(n, C, 3), r(n, M - 1, 3), r(n, sem_cols)
+        m.scaling_activation, m.opacity_activation = torch.exp, torch.sigmoid
+        m.rotation_activation = torch.nn.functional.normalize
+        m.semantic_mode = sem_mode
+        return m
+
+    bk = model(Base, 40, 1, S)
+    actors = []
+    for i, (n, C, label) in enumerate([(17, 3, 2), (9, 1, 0)]):
+        a = model(Actor, n, C, 1)
+        a.num_classes_global, a.obj_class_label = S, label
+        a.start_frame, a.end_frame, a.fourier_scale, a.fourier_dim = 0, 10, 1.0, C
+        idft_rows[C] = r(C)
+        actors.append(a)
+    st = Street()
+    st.background = bk
+    st.get_visibility = lambda name: True
+    st.graph_obj_list = ["obj_0", "obj_1"]
+    st.obj_0, st.obj_1 = actors
+    st.use_pose_correction = False
+    st.frame = 3
+    poses = [r(7), r(7)]
+    st.obj_rots = torch.cat([p[:4].unsqueeze(0).expand(a._xyz.shape[0], -1) for p, a in zip(poses, actors)], 0)
+    st.obj_trans = torch.cat([p[4:].unsqueeze(0).expand(a._xyz.shape[0], -1) for p, a in zip(poses, actors)], 0)
+    masks = [torch.rand(a._xyz.shape[0], generator=g) < 0.4 for a in actors]
+    st.flip_mask = torch.cat(masks, 0)
+    st.flip_axis = 1
+    st.flip_matrix = torch.tensor([[0.0, 0.0, 1.0, 0.0]])  # matrix_to_quaternion of diag(-1, 1, -1), checked above
+
+    seg = lambda m: dict(xyz=m._xyz, rotation=m._rotation, scaling=m._scaling, opacity=m._opacity,
+                         features_dc=m._features_dc, features_rest=m._features_rest, semantic=m._semantic,
+                         semantic_mode=sem_mode)
+    segs = [seg(bk)]
+    for a, p, fm in zip(actors, poses, masks):
+        d = seg(a)
+        d.update(pose=p, idft=idft_rows[a.fourier_dim], class_label=a.obj_class_label, flip_mask=fm if train else None)
+        segs.append(d)
+    xyz, rot, scale, opac, feats, sem = ref.compose(segs, M, S)
+    assert torch.equal(xyz, st.get_xyz)
+    assert torch.equal(rot, st.get_rotation)
+    assert torch.equal(scale, st.get_scaling)
+    assert torch.equal(opac, st.get_opacity)
+    assert torch.equal(feats, st.get_features)
+    assert torch.equal(sem, st.get_semantic)

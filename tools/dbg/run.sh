@@ -1,3 +1,3 @@
 #!/bin/bash
-timeout 900 python bench.py 2>&1 | grep -v amdgpu.ids | tail -3 > gpurun_out/bench_r2_try.json; tail -c 6000 gpurun_out/bench_r2_try.json
-timeout 300 python -m pytest tests/test_gpu_parity.py -q --tb=short -m gpu -x -k "backward_matches or edge or random" 2>&1 | grep -v amdgpu.ids | tail -8
+timeout 900 python -m pytest tests/test_gpu_scene.py tests/test_gpu_densify.py tests/test_gpu_loss.py -q --tb=short -m gpu 2>&1 | grep -v amdgpu.ids | tail -30
+timeout 300 python bench.py --scene tests/golden/scene_ref_layout.ply --steps 20 --no-cpu-baseline --no-other-configs 2>&1 | tail -1 | cut -c1-600
