@@ -246,7 +246,7 @@ def sh_grad_from_views(means3D, campos, drgb, degree, M):
     return out
 
 
-NO_CULL, NO_DPP, NO_DET, NO_HITS = 1, 2, 4, 8
+NO_CULL, NO_DPP, NO_DET, NO_HITS, USE_V2 = 1, 2, 4, 8, 16
 
 
 def test_switches(mask: int = -1) -> int:

@@ -32,7 +32,7 @@ void sgr_launch_blend_fwd(bool cull, int gx, int gy, const uint2* ranges, const 
                           float* out_depth, float* out_alpha, float* out_semantic, uint32_t* n_contrib, uint8_t* hit4,
                           hipStream_t s);
 int sgr_partial_row_stride(int S);
-void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
+void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, bool v2, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
                           int H, int S, const float* bg, const float4* rec, const float* semantics, const float* alphas,
                           const uint32_t* n_contrib, const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth,
                           const float* dL_dalpha, const float* dL_dsem, float* partials, uint8_t* touched, hipStream_t s);
@@ -57,15 +57,16 @@ static bool env_flag(const char* name) {
 }
 
 // A/B switches of the blend kernels (tests and tools/gpu_ab.sh): bit 0 no quadrant cull, 1 no DPP reduction,
-// 2 no deterministic LDS combine, 3 backward ignores the forward's hit record.  Process-wide, set through
-// sgr_test_switches(); the environment (SGR_NO_CULL / SGR_NO_DPP / SGR_NO_DET / SGR_NO_HITS) only provides the
+// 2 no deterministic LDS combine, 3 backward ignores the forward's hit record, 4 the S = 0 backward runs the
+// transposed-accumulation kernel (an A/B design that measured 10 % slower than the cross-lane reduction).  Process-wide, set through
+// sgr_test_switches(); the environment (SGR_NO_CULL / SGR_NO_DPP / SGR_NO_DET / SGR_NO_HITS / SGR_V2) only provides the
 // initial value, read ONCE -- the per-step path is one relaxed atomic load, no getenv.
 static std::atomic<int> g_switches{-1};
 static int switches() {
     int v = g_switches.load(std::memory_order_relaxed);
     if (v < 0) {
         v = (env_flag("SGR_NO_CULL") ? 1 : 0) | (env_flag("SGR_NO_DPP") ? 2 : 0) | (env_flag("SGR_NO_DET") ? 4 : 0) |
-            (env_flag("SGR_NO_HITS") ? 8 : 0);
+            (env_flag("SGR_NO_HITS") ? 8 : 0) | (env_flag("SGR_V2") ? 16 : 0);
         g_switches.store(v, std::memory_order_relaxed);
     }
     return v;
@@ -411,7 +412,7 @@ int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, 
         // the forward's record of which (quadrant, instance) pairs blended at all; switch 8: the kernel redoes the
         // geometric cull instead (A/B and tests: the two walks must give bit-identical gradients)
         const uint8_t* hits = (sw & 8) ? nullptr : bv.hit4;
-        sgr_launch_blend_bwd(cull, dpp, det, gx, gy, iv.ranges, bv.vals[cur], W, H, S, background, gv.rec, semantics,
+        sgr_launch_blend_bwd(cull, dpp, det, (sw & 16) != 0, gx, gy, iv.ranges, bv.vals[cur], W, H, S, background, gv.rec, semantics,
                              alphas, iv.n_contrib, hits, dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, partials,
                              touched, stream);
         SGR_STAGE("blend_bwd");
@@ -452,7 +453,7 @@ int sgr_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, con
 
 int sgr_test_switches(int mask) {
     const int prev = switches();
-    if (mask >= 0) g_switches.store(mask & 15, std::memory_order_relaxed);
+    if (mask >= 0) g_switches.store(mask & 31, std::memory_order_relaxed);
     return prev;
 }
 

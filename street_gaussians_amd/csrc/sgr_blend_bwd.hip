@@ -605,13 +605,293 @@ sgr_blend_bwd_kernel_s0(SGR_BWD_ARGS) {
     sgr_blend_bwd_body<0, CULL, DPP, DET, SgrBwdBatch<0>::value>(SGR_BWD_PASS);
 }
 
+// =====================================================================================================================
+// S = 0, second design ("transposed accumulation").  The kernel above spends ~60 of its ~100 VALU instructions per
+// (quadrant, instance) visit on turning 64 per-pixel terms into 11 sums: the gradient products are formed on every
+// lane (44 % of them hit) and then reduced ACROSS lanes.  Here the reduction is turned into per-lane serial work:
+//   pass A (lane = pixel, as before): walk the visit, update the per-pixel recurrences, and store only TWO scalars per
+//          pixel in LDS -- Gd = G * dL/dalpha-term and wm = alpha * T (zero where the pixel is not hit);
+//   pass B (after 8 visits): lane = (visit v, pixel column g).  Each lane reads the 8 pixels of its column of its
+//          visit back from LDS (an XOR swizzle keeps both directions bank-conflict free), and accumulates the moments
+//          sum Gd*{1, dx, dy, dx^2, dx*dy, dy^2}, sum |..| and sum wm*dL/d{r,g,b,depth} in registers -- every lane busy,
+//          no cross-lane traffic; then three DPP levels inside each 8-lane group, and one lane per visit turns the
+//          moments into the row (mean2D, conic, opacity, abs, colour, depth) and adds it to the slot's row in LDS.
+// ~48 + ~25 instructions per visit instead of ~100, still free of global atomics and bit-reproducible.
+// dL/dmean2D and dL/dconic are assembled from moments (sum first, multiply by the conic once per visit), so they
+// differ from the per-pixel products of backward.cu:616-635 by rounding only.
+#define SGR_V2_BATCH 64
+#define SGR_V2_CH 8
+#ifndef SGR_V2_WAVES
+#define SGR_V2_WAVES 5  // waves per SIMD the register allocation aims at (30 KB of LDS allow 5 workgroups per CU)
+#endif
+template <bool CULL, bool DET>
+__global__ void __launch_bounds__(SGR_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(SGR_V2_WAVES, SGR_V2_WAVES)))
+sgr_blend_bwd_kernel_v2(SGR_BWD_ARGS) {
+#pragma clang fp contract(off)
+    constexpr int BATCH = SGR_V2_BATCH, CH = SGR_V2_CH, ACCW = 12, NROW = DET ? 2 : 1;
+    __shared__ float4 sA[BATCH];  // {x, y, -, -}
+    __shared__ float4 sB[BATCH];  // {qa, qb, qc, opacity}
+    __shared__ float4 sC[BATCH];  // {r, g, b, depth}
+    __shared__ uint32_t sU[BATCH];
+    __shared__ uint32_t sFlag[BATCH];
+    __shared__ uint64_t sBits[4];
+    __shared__ int sMax[4];
+    __shared__ __attribute__((aligned(16))) float sAcc[NROW * BATCH * ACCW];
+    __shared__ __attribute__((aligned(16))) float2 sW[4][CH][64];  // [wave][visit][pixel ^ swizzle] = {Gd, wm}
+    __shared__ float4 sDL[4][64];                                    // [wave][pixel] = dL/d{r, g, b, depth}
+    __shared__ int sVis[4][CH];                                      // slot of each visit of the chunk
+    (void)S; (void)semantics; (void)dL_dpixel_semantics; (void)row_stride;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t tx, ty;
+    if (!sgr_xcd_tile(blockIdx.x, (uint32_t)gx, (uint32_t)gy, tx, ty)) return;  // whole workgroup: padding block
+    const uint32_t tile = ty * (uint32_t)gx + tx;
+    const uint32_t qx0 = tx * SGR_BLOCK_X + (wave & 1) * 8, qy0 = ty * SGR_BLOCK_Y + (wave >> 1) * 8;
+    const uint32_t px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const bool inside = px < (uint32_t)W && py < (uint32_t)H;
+    const float pxf = (float)px, pyf = (float)py;
+    const size_t pix_id = (size_t)W * py + px;
+    const size_t plane = (size_t)H * W;
+    const uint2 range = ranges[tile];
+
+    const float T_final = inside ? (1.0f - alphas[pix_id]) : 0.0f;  // backward.cu:466-500
+    float T = T_final;
+    const int lastc = inside ? (int)n_contrib[pix_id] : 0;
+    float dLdC0 = 0.f, dLdC1 = 0.f, dLdC2 = 0.f, dLdD = 0.f, dLdA = 0.f;
+    if (inside) {
+        dLdC0 = dL_dpixels[pix_id];
+        dLdC1 = dL_dpixels[plane + pix_id];
+        dLdC2 = dL_dpixels[2 * plane + pix_id];
+        dLdD = dL_dpixel_depths[pix_id];
+        dLdA = dL_dalphas[pix_id];
+    }
+    sDL[wave][lane] = make_float4(dLdC0, dLdC1, dLdC2, dLdD);
+    const float bgdot = bg_color[0] * dLdC0 + bg_color[1] * dLdC1 + bg_color[2] * dLdC2;
+    const float kx = (0.5f * (float)W) / SGR_LOG2E, ky = (0.5f * (float)H) / SGR_LOG2E;
+
+    sgr_f2 acc01 = {0.f, 0.f}, acc2D = {0.f, 0.f}, last01 = {0.f, 0.f}, last2D = {0.f, 0.f};
+    const sgr_f2 dL01 = {dLdC0, dLdC1}, dL2D = {dLdC2, dLdD};
+    float accA = 0.f, last_alpha = 0.f;
+
+    int mx = lastc;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) sMax[wave] = mx;
+    sgr_lds_barrier();
+    const int maxc = max(max(sMax[0], sMax[1]), max(sMax[2], sMax[3]));
+    const float tx0 = (float)(tx * SGR_BLOCK_X), ty0 = (float)(ty * SGR_BLOCK_Y);
+    // pass B coordinates: this lane handles column g of visit v
+    const int pv = lane >> 3, pg = lane & 7;
+    const float bpx = (float)(qx0 + (uint32_t)pg), bpy0 = (float)qy0;
+    const int rowset = (DET ? (wave >> 1) : 0) * BATCH * ACCW;
+
+    for (int hi = maxc - 1; hi >= 0; hi -= BATCH) {
+        sgr_lds_barrier();  // previous batch fully consumed (rows written) before LDS is overwritten
+        const bool stager = tid < BATCH;
+        const int pos = stager ? hi - tid : -1;
+        uint32_t mask4 = 0;
+        if (stager) sFlag[tid] = 0;
+        if (tid < NROW * BATCH) {
+            float4* z = reinterpret_cast<float4*>(&sAcc[tid * ACCW]);
+            z[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+            z[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            z[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (pos >= 0) {
+            const uint32_t g = point_list[range.x + (uint32_t)pos];
+            const float4* r = rec + 4 * (size_t)g;  // one 64-byte line
+            const float4 a = r[0];
+            const float4 b = r[1];
+            const float4 d4 = r[3];
+            sA[tid] = a;
+            sB[tid] = make_float4(-0.5f * SGR_LOG2E * b.x, -SGR_LOG2E * b.y, -0.5f * SGR_LOG2E * b.z, b.w);
+            sC[tid] = r[2];
+            const uint32_t dy_ = __float_as_uint(d4.y);
+            const uint32_t rx0 = dy_ & 1023u, ry0 = (dy_ >> 10) & 1023u, rw = dy_ >> 20;
+            sU[tid] = __float_as_uint(d4.x) + (ty - ry0) * rw + (tx - rx0);
+            mask4 = CULL ? (hit4 != nullptr ? (uint32_t)hit4[range.x + (uint32_t)pos] : sgr_quadrant_mask(a, b, tx0, ty0))
+                         : 0xFu;
+        }
+        if (stager) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint64_t m = __ballot((mask4 >> q) & 1u);
+                if (lane == 0) sBits[q] = m;
+            }
+        }
+        sgr_lds_barrier();
+
+        // ---- pass A for one visit: slot j, chunk position c (both wave-uniform) ----
+        auto pass_a = [&](const int j, const int c, const float4 q, const float dx, const float dy, const float power2,
+                          const float G, const float alpha) __attribute__((always_inline)) {
+            (void)dx; (void)dy;
+            const int posj = hi - j;
+            const bool hit = (posj < lastc) && !(power2 > 0.0f) && !(alpha < SGR_ALPHA_MIN);  // backward.cu:527-545
+            float Gd = 0.0f, wm = 0.0f;
+            if (hit) {
+                const float4 cc = sC[j];
+                const float oma = 1.0f - alpha;
+                float inv1ma = __builtin_amdgcn_rcpf(oma);
+                inv1ma = fmaf(fmaf(-oma, inv1ma, 1.0f), inv1ma, inv1ma);  // Newton step: T recovery compounds per layer
+                T = T * inv1ma;  // T = T / (1 - alpha)
+                wm = alpha * T;
+                const float one_m_la = 1.0f - last_alpha;
+                const sgr_f2 c01 = {cc.x, cc.y}, c2D = {cc.z, cc.w};
+                const sgr_f2 la2 = {last_alpha, last_alpha};
+                acc01 = __builtin_elementwise_fma(la2, last01, one_m_la * acc01);
+                acc2D = __builtin_elementwise_fma(la2, last2D, one_m_la * acc2D);
+                const sgr_f2 t = __builtin_elementwise_fma(c2D - acc2D, dL2D, (c01 - acc01) * dL01);
+                float d = t.x + t.y;
+                accA = fmaf(one_m_la, accA, last_alpha);
+                d = fmaf(1.0f - accA, dLdA, d);
+                last01 = c01;
+                last2D = c2D;
+                last_alpha = alpha;
+                d *= T;
+                const float dopa = fmaf(-T_final * inv1ma, bgdot, d);  // backward.cu:611-614
+                Gd = G * dopa;
+            }
+            (void)q;
+            sW[wave][c][lane ^ ((c & 3) << 3)] = make_float2(Gd, wm);
+            if (lane == 0) sVis[wave][c] = j;
+        };
+
+        // ---- pass B for the nv (<= 8) visits of a chunk ----
+        auto pass_b = [&](const int nv) __attribute__((always_inline)) {
+            float m0 = 0.f, m1x = 0.f, m1y = 0.f, m2xx = 0.f, m2xy = 0.f, m2yy = 0.f, wabs = 0.f;
+            float c0 = 0.f, c1 = 0.f, c2 = 0.f, cD = 0.f;
+            const bool act = pv < nv;
+            int j = 0;
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (act) {
+                j = sVis[wave][pv];
+                const float4 a = sA[j];
+                q = sB[j];
+                const float dx = a.x - bpx;
+                const float qa2 = q.x + q.x, qc2 = q.z + q.z;
+                const float qbdx = q.y * dx;
+                const int swz = (pv & 3) << 3;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int p = 8 * i + pg;
+                    const float2 wv = sW[wave][pv][p ^ swz];
+                    const float4 dl = sDL[wave][p];
+                    const float dy = a.y - (bpy0 + (float)i);
+                    const float Gd = wv.x, wmv = wv.y;
+                    const float gxx = Gd * dx, gyy = Gd * dy;
+                    m0 += Gd;
+                    m1x += gxx;
+                    m1y += gyy;
+                    m2xx = fmaf(gxx, dx, m2xx);
+                    m2xy = fmaf(gxx, dy, m2xy);
+                    m2yy = fmaf(gyy, dy, m2yy);
+                    const float A = fmaf(qa2, dx, q.y * dy), B = fmaf(qc2, dy, qbdx);
+                    wabs = fmaf(fabsf(Gd), fmaf(fabsf(A), kx, fabsf(B) * ky), wabs);
+                    c0 = fmaf(wmv, dl.x, c0);
+                    c1 = fmaf(wmv, dl.y, c1);
+                    c2 = fmaf(wmv, dl.z, c2);
+                    cD = fmaf(wmv, dl.w, cD);
+                }
+            }
+            // 8 lanes -> 1: the first level pairs a moment with a colour-side value (even bank <- first, odd bank <-
+            // second), the other two levels run inside the quads
+            sgr_fold4(m0, wabs);
+            sgr_fold4(m1x, c0);
+            sgr_fold4(m1y, c1);
+            sgr_fold4(m2xx, c2);
+            sgr_fold4(m2xy, cD);
+            sgr_half4(m2yy);
+            sgr_quad_sum2(m0, m1x);
+            sgr_quad_sum2(m1y, m2xx);
+            sgr_quad_sum2(m2xy, m2yy);
+            if (act && (lane & 3) == 0) {
+                const bool odd = (lane >> 2) & 1;
+                // even bank: moments -> mean2D.x, mean2D.y, conic x / y / w, opacity (row 0, 1, 3, 4, 5, 6);
+                // odd bank: abs term, colour, depth (row 2, 7, 8, 9, 10)
+                const float qw = q.w;
+                const float e0 = qw * kx * fmaf(q.x + q.x, m1x, q.y * m1y);
+                const float e1 = qw * ky * fmaf(q.z + q.z, m1y, q.y * m1x);
+                const float h = -0.5f * qw;
+                float* dst = sAcc + (rowset + j * ACCW);
+                atomicAdd(&dst[odd ? 2 : 0], odd ? qw * m0 : e0);
+                atomicAdd(&dst[odd ? 7 : 1], odd ? m1x : e1);
+                atomicAdd(&dst[odd ? 8 : 3], odd ? m1y : h * m2xx);
+                atomicAdd(&dst[odd ? 9 : 4], odd ? m2xx : h * m2xy);
+                atomicAdd(&dst[odd ? 10 : 5], odd ? m2xy : h * m2yy);
+                if (!odd) {
+                    atomicAdd(&dst[6], m0);
+                    sFlag[j] = 1u;
+                }
+            }
+        };
+
+        uint64_t m = sgr_uniform_u64(sBits[wave]);
+        while (m) {
+            int nv = 0;
+            for (int trip = 0; trip < CH / 2 && m; trip++) {
+                const int j0 = __ffsll((unsigned long long)m) - 1;
+                m &= m - 1;
+                const bool two = m != 0;
+                const int j1 = two ? (__ffsll((unsigned long long)m) - 1) : j0;
+                m &= m - 1;
+                const float4 a0 = sA[j0], q0 = sB[j0];
+                const float4 a1 = sA[j1], q1 = sB[j1];
+                const float dx0 = a0.x - pxf, dy0 = a0.y - pyf, dx1 = a1.x - pxf, dy1 = a1.y - pyf;
+                const float pw0 = sgr_power2(q0.x, q0.y, q0.z, dx0, dy0);
+                const float pw1 = sgr_power2(q1.x, q1.y, q1.z, dx1, dy1);
+                const float G0 = __builtin_amdgcn_exp2f(pw0), G1 = __builtin_amdgcn_exp2f(pw1);
+                const float al0 = fminf(0.99f, q0.w * G0), al1 = fminf(0.99f, q1.w * G1);
+                pass_a(j0, nv, q0, dx0, dy0, pw0, G0, al0);
+                nv++;
+                if (two) {
+                    pass_a(j1, nv, q1, dx1, dy1, pw1, G1, al1);
+                    nv++;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();  // this wave's own LDS writes above precede its reads below (program order)
+            pass_b(nv);
+            __builtin_amdgcn_wave_barrier();
+        }
+        sgr_lds_barrier();
+        const uint32_t flags = stager ? sFlag[tid] : 0u;
+        if (flags) {
+            const uint32_t u = sU[tid];
+            touched[u] = 1;
+            float4* row = reinterpret_cast<float4*>(partials + (size_t)u * 16);
+            const float4* src = reinterpret_cast<const float4*>(&sAcc[tid * ACCW]);
+            float4 r0 = src[0], r1 = src[1], r2 = src[2];
+            if (DET) {
+                const float4* s1 = reinterpret_cast<const float4*>(&sAcc[(BATCH + tid) * ACCW]);
+                const float4 t0 = s1[0], t1 = s1[1], t2 = s1[2];
+                r0.x += t0.x; r0.y += t0.y; r0.z += t0.z; r0.w += t0.w;
+                r1.x += t1.x; r1.y += t1.y; r1.z += t1.z; r1.w += t1.w;
+                r2.x += t2.x; r2.y += t2.y; r2.z += t2.z; r2.w += t2.w;
+            }
+            row[0] = r0;
+            row[1] = r1;
+            row[2] = r2;
+        }
+    }
+}
+
 template <int SMAX>
-static void launch_bwd(bool cull, bool dpp, bool det, unsigned tiles, hipStream_t s, const uint2* ranges, const uint32_t* point_list,
+static void launch_bwd(bool cull, bool dpp, bool det, bool v2, unsigned tiles, hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                        int W, int H, int S, int gx, int gy, const float* bg, const float4* rec, const float* semantics,
                        const float* alphas,
                        const uint32_t* n_contrib, const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth,
                        const float* dL_dalpha, const float* dL_dsem, float* partials, int row_stride, uint8_t* touched) {
     constexpr bool kDet = true;  // every instantiation has the two-row deterministic combine (see SgrBwdBatch)
+    if constexpr (SMAX == 0) {
+        if (v2 && dpp) {  // transposed accumulation (S = 0)
+#define SGR_V2(C, D) sgr_blend_bwd_kernel_v2<C, D><<<tiles, SGR_TILE_THREADS, 0, s>>>(                                    \
+            ranges, point_list, W, H, S, gx, gy, bg, rec, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,         \
+            dL_dalpha, dL_dsem, partials, row_stride, touched)
+            if (cull) { if (det) SGR_V2(true, true); else SGR_V2(true, false); }
+            else { if (det) SGR_V2(false, true); else SGR_V2(false, false); }
+#undef SGR_V2
+            return;
+        }
+    }
     if (SMAX > 4) { cull = true; dpp = true; }  // the A/B switches (tests) exist for the small instantiations only
 #define SGR_GO(C, D)                                                                                                 \
     do {                                                                                                             \
@@ -645,14 +925,14 @@ static void launch_bwd(bool cull, bool dpp, bool det, unsigned tiles, hipStream_
 // floats per partial row for S semantic channels: the kernel's SMAX bucket writes ceil((11+SMAX)/4) float4
 int sgr_partial_row_stride(int S) { return S <= 4 ? 16 : (S <= 20 ? 32 : 48); }
 
-void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
+void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, bool v2, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
                           int H, int S, const float* bg, const float4* rec, const float* semantics, const float* alphas, const uint32_t* n_contrib,
                           const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha,
                           const float* dL_dsem, float* partials, uint8_t* touched, hipStream_t s) {
     if (gx <= 0 || gy <= 0) return;
     const unsigned tiles = sgr_xcd_grid_blocks(gx, gy);  // supertile-ordered grid incl. padding blocks
     const int stride = sgr_partial_row_stride(S);
-#define SGR_BWD(N) launch_bwd<N>(cull, dpp, det, tiles, s, ranges, point_list, W, H, S, gx, gy, bg, rec, semantics, alphas, \
+#define SGR_BWD(N) launch_bwd<N>(cull, dpp, det, v2, tiles, s, ranges, point_list, W, H, S, gx, gy, bg, rec, semantics, alphas, \
                                  n_contrib, hit4, dL_dpix, dL_ddepth, dL_dalpha, dL_dsem, partials, stride, touched)
     if (S == 0) SGR_BWD(0);
     else if (S <= 4) SGR_BWD(4);

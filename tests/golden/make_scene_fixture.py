@@ -77,10 +77,10 @@ def main():
         for k, v in p.items():
             raw[f"{name}/{k}"] = v.numpy()
     state["iter"] = 30000                                                # train.py:221
-    write_ply(os.path.join(HERE, "scene_ref_layout.ply"), elements)
-    torch.save(state, os.path.join(HERE, "scene_ref_state.pth"))
-    np.savez_compressed(os.path.join(HERE, "scene_ref_params.npz"), **raw)
-    print("wrote", [os.path.getsize(os.path.join(HERE, f)) for f in ("scene_ref_layout.ply", "scene_ref_state.pth", "scene_ref_params.npz")])
+    write_ply(os.path.join(HERE, "scene", "scene_ref_layout.ply"), elements)
+    torch.save(state, os.path.join(HERE, "scene", "scene_ref_state.pth"))
+    np.savez_compressed(os.path.join(HERE, "scene", "scene_ref_params.npz"), **raw)
+    print("wrote", [os.path.getsize(os.path.join(HERE, "scene", f)) for f in ("scene_ref_layout.ply", "scene_ref_state.pth", "scene_ref_params.npz")])
 
 
 if __name__ == "__main__":

@@ -163,6 +163,12 @@ def test_culling_is_invisible_and_backward_is_deterministic(name):
         g_c = raw_backward(kw, res_a, wts)
     for k in g_a:  # different summation order inside a wave: equal up to fp32 rounding
         grad_close(npy(g_a[k]), npy(g_c[k]), rel=1e-4, abs_frac=2e-5, name=f"dpp:{k}", max_outlier_frac=0.0)
+    with switches(_C.USE_V2):  # S = 0: the transposed-accumulation A/B kernel (moments): equal up to rounding
+        g_d = raw_backward(kw, res_a, wts)
+        g_d2 = raw_backward(kw, res_a, wts)
+    for k in g_a:
+        assert torch.equal(g_d[k], g_d2[k]), f"{k} not deterministic (transposed accumulation)"
+        grad_close(npy(g_a[k]), npy(g_d[k]), rel=1e-4, abs_frac=2e-5, name=f"v2:{k}", max_outlier_frac=0.0)
 
 
 @pytest.mark.parametrize("P,S,scale_px", [(1, 0, 0.8), (2, 20, 0.3), (65, 1, 0.05), (129, 7, 0.02)])

@@ -188,7 +188,7 @@ def test_scene_file_in_the_reference_layout_renders_like_the_oracle(source):
     from gpu_utils import image_close, npy, settings
     from oracle import oracle
     from street_gaussians_amd import checkpoint, plyio, synthetic as syn
-    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scene")
     if source == "ply":
         models = plyio.read_scene_ply(os.path.join(gold, "scene_ref_layout.ply"))
     else:

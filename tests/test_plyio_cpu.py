@@ -64,7 +64,7 @@ def test_reads_single_model_files_and_other_scalar_types(tmp_path):
 
 # ---- fixtures written in the reference's layout by the reference's own make_ply / state_dict
 # (tests/golden/make_scene_fixture.py) --------------------------------------------------------------------------
-GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scene")
 
 
 def _raw():
