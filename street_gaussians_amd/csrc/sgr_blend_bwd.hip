@@ -438,7 +438,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                 for (int k = 0; k < NVAL; k++) v[k] = 0.0f;
                 // Everything per-pixel runs under the hit mask and updates the recurrences in place; the other lanes
                 // keep dopa = wm = 0, and every output below is a product with one of those two.
-                float dopa = 0.0f, wm = 0.0f;
+                float Gd = 0.0f, wm = 0.0f;  // Gd = G * dL/dalpha-term: zero off the hit lanes even if G overflowed there
                 if (hit) {
                     const float oma = 1.0f - alpha;
                     float inv1ma = __builtin_amdgcn_rcpf(oma);
@@ -473,25 +473,26 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                     last2D = c2D;
                     last_alpha = alpha;
                     d *= T;
-                    dopa = fmaf(-T_final * inv1ma, bgdot, d);  // backward.cu:611-614
+                    Gd = G * fmaf(-T_final * inv1ma, bgdot, d);  // backward.cu:611-614
                 }
                 if (SMAX > 0) {
 #pragma unroll
                     for (int ch = 0; ch < SMAX; ch++) v[SGR_ROW_BASE + ch] = wm * dLdS[ch];
                 }
-                const float dL_dG = q.w * dopa;
-                const float gdx = G * dx, gdy = G * dy;
-                // dG/ddelx = -gdx*A - gdy*B = (2*qa*gdx + qb*gdy)/log2e  (qa = -0.5*log2e*A, qb = -log2e*B)
-                const float gmx = dL_dG * fmaf(2.0f * q.x, gdx, q.y * gdy) * kx;
-                const float gmy = dL_dG * fmaf(2.0f * q.z, gdy, q.y * gdx) * ky;
-                v[0] = gmx;
-                v[1] = gmy;
-                v[2] = fabsf(gmx) + fabsf(gmy);
-                const float h = -0.5f * dL_dG;
-                v[3] = h * gdx * dx;
-                v[4] = h * gdx * dy;
-                v[5] = h * gdy * dy;
-                v[6] = G * dopa;
+                // Per pixel only the MOMENTS of Gd = G * dopa are formed (Gd*dx, Gd*dy, Gd*dx^2, Gd*dx*dy, Gd*dy^2) plus the
+                // "abs" term, which is not linear; the flush turns the tile's sums into dL/dmean2D and dL/dconic with the
+                // instance's conic and opacity (dL_dG = opacity * dopa is constant per instance, backward.cu:616-635):
+                // 17 instead of 26 instructions per visit, same sums up to rounding.
+                const float gx = Gd * dx, gy = Gd * dy;
+                // dG/ddelx / G = (2*qa*dx + qb*dy)/log2e  (qa = -0.5*log2e*A, qb = -log2e*B; 1/log2e is in kx, ky)
+                const float ax = fmaf(q.x + q.x, dx, q.y * dy), ay = fmaf(q.z + q.z, dy, q.y * dx);
+                v[0] = gx;
+                v[1] = gy;
+                v[2] = fabsf(Gd) * fmaf(fabsf(ax), kx, fabsf(ay) * ky);
+                v[3] = gx * dx;
+                v[4] = gx * dy;
+                v[5] = gy * dy;
+                v[6] = Gd;
                 const sgr_f2 o01 = wm * dL01, o2D = wm * dL2D;
                 v[7] = o01.x;
                 v[8] = o01.y;
@@ -574,6 +575,17 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                         r[k4].x += t.x; r[k4].y += t.y; r[k4].z += t.z; r[k4].w += t.w;
                     }
                 }
+            }
+            // moments -> gradients (see `process`): r[0] = {S gx, S abs, S gy, S gxx}, r[1] = {S gxy, S Gd, S gyy, colour r}
+            {
+                const float4 qq = sB[tid];
+                const float sgx = r[0].x, sgy = r[0].z, qw = qq.w, hq = -0.5f * qq.w;
+                r[0].x = qw * kx * fmaf(qq.x + qq.x, sgx, qq.y * sgy);  // dL/dmean2D.x
+                r[0].z = qw * ky * fmaf(qq.z + qq.z, sgy, qq.y * sgx);  // dL/dmean2D.y
+                r[0].y = qw * r[0].y;                                    // sum |gx| + |gy|
+                r[0].w = hq * r[0].w;                                    // dL/dconic.x
+                r[1].x = hq * r[1].x;                                    // dL/dconic.y
+                r[1].z = hq * r[1].z;                                    // dL/dconic.w
             }
 #pragma unroll
             for (int k4 = 0; k4 < NVAL / 4; k4++) row[k4] = make_float4(r[k4].x, r[k4].z, r[k4].y, r[k4].w);
