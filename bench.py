@@ -64,6 +64,9 @@ def parse():
                     help="N > 1 exchange: factored = all-reduce of the dense parameter gradients + all-gather of per-view "
                          "dRGB with a local rebuild of dL/dSH (60 B/Gaussian on the wire); bucket = one flat all-reduce "
                          "of everything (236 B/Gaussian)")
+    ap.add_argument("--exchange", choices=["overlap", "blocking"], default="overlap",
+                    help="N > 1: overlap = the exchange runs on a side stream under the NEXT step's forward (training: the "
+                         "optimiser sees gradients one step late; no staleness with > 1 view per rank); blocking = inside the step")
     ap.add_argument("--step-times", action="store_true", help="debug: also print 10 individually synchronised steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the 500k / 2M+S19 / 5M runs (N = 1 only)")
@@ -236,6 +239,12 @@ class Workload:
         color, radii, depth, alpha, sem = self.rast(p["means3D"], self.means2D, p["opacities"], shs=p["shs"],
                                                     scales=p["scales"], rotations=p["rotations"],
                                                     semantics=p.get("semantics"))
+        if self.reducer is not None and self.args.exchange == "overlap":
+            # the previous step's exchange ran under the forward that was just queued; its result is due now (the
+            # optimiser step would sit here), then the gradient slots are cleared for this step's backward
+            self.reducer.wait()
+            for t in list(p.values()):
+                t.grad = None
         if self.args.loss == "scalar":
             loss = (color * w["color"]).sum() + (depth * w["depth"]).sum() + (alpha * w["alpha"]).sum()
             if S:
@@ -248,8 +257,16 @@ class Workload:
                 grads.append(w["semantic"])
             torch.autograd.backward(outs, grads)
         if self.reducer is not None:
-            self.reducer.all_reduce()
+            if self.args.exchange == "overlap":
+                self.reducer.begin()
+            else:
+                self.reducer.all_reduce()
         self.radii = radii
+
+    def drain(self):
+        """Joins an exchange that is still in flight (end of a timed region)."""
+        if self.reducer is not None:
+            self.reducer.wait()
 
     def counts(self):
         """R (tile instances), V (visible Gaussians) and the sum of n_contrib of this view (R/P and V/P are
@@ -294,6 +311,7 @@ def profiled_steps(L, wl, fence, steps, stage_mask):
     t0 = time.perf_counter()
     for _ in range(steps):
         wl.step()
+    wl.drain()  # the last step's exchange belongs to the timed region
     fence()
     dt = time.perf_counter() - t0
     sums = (C.c_double * 9)()
@@ -431,6 +449,9 @@ def main():
                            " (dense 44 B/Gaussian; SH gradient rebuilt from an all-gather of per-view dRGB, 12 B/Gaussian/view)"
                            if args.reduce == "factored" else " (one 236 B/Gaussian bucket)")) if world > 1 else ""),
                        "exchange_bytes_per_rank": reducer.nbytes if reducer is not None else 0,
+                       "exchange_schedule": (None if reducer is None else (
+                           "side stream, overlapped with the next step's forward (one-step-delayed gradients in training)"
+                           if args.exchange == "overlap" else "blocking, inside the step")),
                        "kernel_sources_sha16": sgr_build.source_sha16()},
             "roofline": {"bound": "hbm", "kernel": kernel_name,
                          "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",

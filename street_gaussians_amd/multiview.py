@@ -13,6 +13,14 @@ view is rank-1, ``dL/dSH[k][c] = Y_k(dir) * dRGB[c]`` (cuda_rasterizer/backward.
 3 floats of dRGB per Gaussian (+ their camera centre) and rebuild ``sum_v Y(dir_v) (x) dRGB_v`` locally with one HIP
 kernel (csrc/sgr_multiview.hip): 44 B all-reduced + 12 B all-gathered per Gaussian instead of 236 B all-reduced.
 
+Overlap.  ``begin()`` issues the exchange on a side stream behind an event of the compute stream and returns at once;
+``wait()`` makes the compute stream wait for it and installs the reduced gradients.  ``all_reduce()`` = both, back to
+back (the blocking form).  What the exchange can overlap with depends on the schedule: with several views per rank
+(``views_per_rank > 1``) the all-gather of view j's dRGB runs under view j+1's forward + backward; with one view per
+rank it can only run under the NEXT step's forward (0.76 ms of the 1.95 ms step at 1 M Gaussians), which in training
+means the optimiser consumes gradients one step late (``bench.py --exchange overlap`` measures exactly that schedule
+and says so; ``--exchange blocking`` keeps everything inside the step).
+
 Also combines the densification statistics the training loop derives from the rasterizer outputs
 (/root/reference/lib/models/street_gaussian_model.py:551-571): sums for the view-space gradient accumulators,
 max for the screen radii.  Works with the gloo backend on CPU tensors (tests/test_multiview_gloo.py).
@@ -41,6 +49,9 @@ class GradReducer:
         pad = (-total) % max(self.world, 1)  # reduce_scatter needs equal shards
         ref = self.params[0]
         self.flat = torch.zeros(total + pad, dtype=torch.float32, device=ref.device)
+        self._side = torch.cuda.Stream(ref.device) if ref.is_cuda else None  # the exchange's own stream
+        self._works = []
+        self._inflight = False
         self._views = []
         off = 0
         for p, n in zip(self.params, self._numel):
@@ -62,27 +73,72 @@ class GradReducer:
         if self.flat.is_cuda:
             torch.cuda.synchronize(self.flat.device)
 
-    def _collective(self) -> None:
+    def _collective(self, async_op: bool = False):
+        """Issues the collective(s) on the current stream; returns the work handles when async_op."""
+        works = []
         if self.mode == "rs_ag":
             shard = self.flat.numel() // self.world
             rank = dist.get_rank(self.group)
             mine = self.flat[rank * shard:(rank + 1) * shard]
-            dist.reduce_scatter_tensor(mine, self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            dist.all_gather_into_tensor(self.flat, mine.clone(), group=self.group)
+            w = dist.reduce_scatter_tensor(mine, self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            if async_op:
+                w.wait()  # orders the all-gather behind the reduce-scatter on this stream (no host block on RCCL)
+            works.append(dist.all_gather_into_tensor(self.flat, mine.clone(), group=self.group, async_op=async_op))
         else:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            works.append(dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op))
+        return works if async_op else []
 
-    def all_reduce(self) -> None:
-        """Sum gradients over all ranks; ``p.grad`` is replaced by a view of the reduced bucket."""
+    def begin(self) -> None:
+        """Non-blocking start of the exchange: gradients are packed and the collective is issued on the side stream,
+        ordered behind everything the compute stream has queued so far.  Pair with ``wait()``."""
+        if self._inflight:
+            raise RuntimeError("begin() called twice without wait()")
         if self.world == 1 and not self.force:
             return
         grads = [p.grad if p.grad is not None else torch.zeros_like(v) for p, v in zip(self.params, self._views)]
-        torch._foreach_copy_(self._views, grads)
-        self._collective()
-        if self.average:
-            self.flat.div_(self.world)
+        if self._side is not None:
+            cur = torch.cuda.current_stream(self.flat.device)
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                torch._foreach_copy_(self._views, grads)
+                for g in grads:
+                    g.record_stream(self._side)  # the caching allocator must not hand these out before the copy ran
+                self._works = self._collective(async_op=True)
+                if self.average:
+                    for w in self._works:
+                        w.wait()
+                    self.flat.div_(self.world)
+        else:
+            torch._foreach_copy_(self._views, grads)
+            self._works = self._collective(async_op=True)
+        self._inflight = True
+
+    def wait(self) -> None:
+        """The compute stream waits for the exchange begun by ``begin()``; ``p.grad`` becomes a view of the reduced
+        bucket.  No host synchronisation on RCCL (work.wait() orders streams)."""
+        if not self._inflight:
+            return
+        if self._side is not None:
+            with torch.cuda.stream(self._side):
+                for w in self._works:
+                    w.wait()
+            torch.cuda.current_stream(self.flat.device).wait_stream(self._side)
+        else:
+            for w in self._works:
+                w.wait()
+            if self.average:
+                self.flat.div_(self.world)
+        self._works = []
+        self._inflight = False
         for p, v in zip(self.params, self._views):
             p.grad = v
+
+    def all_reduce(self) -> None:
+        """Sum gradients over all ranks (blocking form); ``p.grad`` is replaced by a view of the reduced bucket."""
+        if self.world == 1 and not self.force:
+            return
+        self.begin()
+        self.wait()
 
 
 class FactoredGradReducer:
@@ -90,7 +146,10 @@ class FactoredGradReducer:
     SH gradient through an all-gather of per-view dRGB + a local rebuild (module docstring).
 
     dense_params  parameters whose ``.grad`` is all-reduced as is (means3D, scales, rotations, opacities, semantics ...)
-    shs           the SH coefficient parameter [P, M, 3]; its ``.grad`` is REPLACED by the rebuilt sum over all views
+    shs           the SH coefficient parameter [P, M, 3], or the reference's pair (features_dc [P, 1, 3],
+                  features_rest [P, M-1, 3]) (gaussian_model.py:120-123); ``.grad`` of it / of both is REPLACED by the
+                  rebuilt sum over all views.  Leaf tensors only: a non-leaf SH tensor (e.g. the output of
+                  scene.compose) has already sent this view's dL/dSH down the graph.
     means3D       positions [P, 3] (view directions are recomputed from them on every rank)
     views_per_rank  rasterizer backward calls every rank makes per step (equal on all ranks)
 
@@ -105,7 +164,13 @@ class FactoredGradReducer:
                  force: bool = False, mask_fn=None, rebuild_fn=None):
         from . import rasterizer as _rast
         self.dense = GradReducer(dense_params, group=group, mode=mode, force=force)
-        self.shs, self.means3D, self.group, self.force = shs, means3D, group, force
+        self.shs_parts = list(shs) if isinstance(shs, (tuple, list)) else [shs]
+        for t in self.shs_parts:
+            if not t.is_leaf:
+                raise ValueError("FactoredGradReducer needs LEAF SH parameters (their .grad is replaced)")
+        self.M = sum(int(t.shape[1]) for t in self.shs_parts)
+        self.shs = self.shs_parts[0] if len(self.shs_parts) == 1 else None
+        self.means3D, self.group, self.force = means3D, group, force
         self.k = int(views_per_rank)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._mask_fn, self._rebuild_fn = mask_fn, rebuild_fn
@@ -120,6 +185,10 @@ class FactoredGradReducer:
 
     # -- rasterizer backward hook --
     def _observe(self, grad_colors, geomBuffer, campos, sh_degree, num_points):
+        # the hook list is process-wide: passes over another Gaussian set (the reference's training step also renders
+        # single objects, street_gaussian_renderer.render_object) are not this reducer's business
+        if int(num_points) != int(self.means3D.shape[0]):
+            return
         if len(self._pending) >= self.k:
             raise RuntimeError(f"more than views_per_rank={self.k} rasterizer backward passes since the last exchange")
         if self._mask_fn is not None:
@@ -148,28 +217,64 @@ class FactoredGradReducer:
         if self._all.is_cuda:
             torch.cuda.synchronize(self._all.device)
 
-    def all_reduce(self) -> None:
+    def begin(self) -> None:
+        """Non-blocking start: the dense bucket's all-reduce and the all-gather of the per-view dRGB go to the side stream."""
         if len(self._pending) != self.k:
             raise RuntimeError(f"expected {self.k} rasterizer backward passes before the exchange, saw {len(self._pending)}")
-        degree = self._pending[0]
+        self._degree = self._pending[0]
         self._pending = []
+        self._gather_works = []
+        self._begun = True
         if self.world == 1 and not self.force:
             return  # shs.grad of the single view is already the sum
-        self.dense.all_reduce()
+        self.dense.begin()
         if self.world > 1 or dist.is_initialized():
-            dist.all_gather_into_tensor(self._all, self._mine, group=self.group)
+            side = self.dense._side
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream(self._mine.device))
+                with torch.cuda.stream(side):
+                    self._gather_works = [dist.all_gather_into_tensor(self._all, self._mine, group=self.group, async_op=True)]
+            else:
+                self._gather_works = [dist.all_gather_into_tensor(self._all, self._mine, group=self.group, async_op=True)]
         else:
             self._all.copy_(self._mine)
+
+    def wait(self) -> None:
+        """Joins the exchange and rebuilds dL/dSH = sum over all views of Y(dir_v) (x) dRGB_v on the compute stream."""
+        if not getattr(self, "_begun", False):
+            return
+        self._begun = False
+        if self.world == 1 and not self.force:
+            return
+        side = self.dense._side
+        if side is not None:
+            with torch.cuda.stream(side):
+                for w in self._gather_works:
+                    w.wait()
+        else:
+            for w in self._gather_works:
+                w.wait()
+        self._gather_works = []
+        self.dense.wait()  # also makes the compute stream wait for the side stream
         V = self._all.shape[0]
-        P, M = self.means3D.shape[0], self.shs.shape[1]
+        P, M = self.means3D.shape[0], self.M
         campos = self._all[:, :3].contiguous()
         drgb = self._all[:, 3:].reshape(V, P, 3)
         if self._rebuild_fn is not None:
-            grad = self._rebuild_fn(self.means3D.detach(), campos, drgb, degree, M)
+            grad = self._rebuild_fn(self.means3D.detach(), campos, drgb, self._degree, M)
         else:
             from . import _C
-            grad = _C.sh_grad_from_views(self.means3D.detach(), campos, drgb, degree, M)
-        self.shs.grad = grad.view_as(self.shs)
+            grad = _C.sh_grad_from_views(self.means3D.detach(), campos, drgb, self._degree, M)
+        grad = grad.view(P, M, 3)
+        off = 0
+        for t in self.shs_parts:  # one parameter, or the reference's (features_dc, features_rest) pair
+            m = int(t.shape[1])
+            t.grad = grad[:, off:off + m, :] if len(self.shs_parts) > 1 else grad.view_as(t)
+            off += m
+
+    def all_reduce(self) -> None:
+        self.begin()
+        self.wait()
 
     def close(self) -> None:
         if self._observe in self._rast.BACKWARD_OBSERVERS:

@@ -86,3 +86,54 @@ def test_masked_color_grad_and_rebuild_match_oracle():
     assert np.abs(npy(dsh) - want).max() <= 1e-5 * np.abs(want).max()
     assert torch.allclose(dsh, g["sh"].reshape(sc.P, 16, 3), rtol=0, atol=2e-6 * float(g["sh"].abs().max()))
     fw.free()
+
+
+def test_bench_runs_the_rccl_exchange_on_one_rank():
+    """bench.py with a forced one-rank RCCL group (SGR_BENCH_FORCE_DIST=1): the factored exchange, overlapped and
+    blocking, runs end to end on the GPU and prints the contract's JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode in ("overlap", "blocking"):
+        env = dict(os.environ, SGR_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+                              "--gaussians", "100000", "--no-cpu-baseline", "--no-other-configs", "--exchange", mode],
+                             env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = json.loads(out.stdout.strip().split("\n")[-1])
+        assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["exchange_bytes_per_rank"] > 0
+        assert (mode == "overlap") == ("overlapped" in line["config"]["exchange_schedule"])
+
+
+def test_async_exchange_matches_blocking_exchange():
+    """GradReducer / FactoredGradReducer: begin() + wait() give the same gradients as all_reduce(), also when the next
+    step's work is queued in between (one-rank RCCL group)."""
+    port = socket.socket()
+    port.bind(("127.0.0.1", 0))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port.getsockname()[1])
+    port.close()
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        _async_body()
+    finally:
+        dist.destroy_process_group()
+
+
+def _async_body():
+    g = torch.Generator().manual_seed(1)
+    params = [torch.zeros(50000, 3, device="cuda", requires_grad=True), torch.zeros(50000, 1, device="cuda", requires_grad=True)]
+    grads = [torch.randn(p.shape, generator=g).cuda() for p in params]
+    red = multiview.GradReducer(params, force=True)
+    for p, gr in zip(params, grads):
+        p.grad = gr.clone()
+    red.begin()
+    junk = torch.randn(4096, 4096, device="cuda") @ torch.randn(4096, 4096, device="cuda")  # "the next forward"
+    for p in params:
+        p.grad = torch.zeros_like(p)
+    red.wait()
+    torch.cuda.synchronize()
+    for p, gr in zip(params, grads):
+        assert torch.equal(p.grad, gr)
+    assert torch.isfinite(junk).all()

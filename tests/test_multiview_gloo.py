@@ -36,6 +36,22 @@ def _worker(rank, world, port, mode, q):
         if i == 4:
             exp = all_grads[0][4]
         ok &= torch.allclose(p.grad, exp, atol=1e-6)
+    # begin() / wait(): the exchange carries the gradients as they were at begin(); what the next step does to .grad
+    # in between does not leak into it, and wait() installs the reduced values
+    for p, gr in zip(params, all_grads[rank]):
+        p.grad = gr.clone()
+    red.begin()
+    try:
+        red.begin()
+        ok = False  # a second begin() without wait() is a usage error
+    except RuntimeError:
+        pass
+    for p in params:
+        p.grad = None if p.grad is None else torch.full_like(p.grad, 123.0)
+    red.wait()
+    for i, p in enumerate(params):
+        ok &= torch.allclose(p.grad, sum(all_grads[r][i] for r in range(world)), atol=1e-6)
+    red.wait()  # idempotent
     acc = torch.full((50, 2), float(rank + 1))
     den = torch.full((50, 1), 1.0)
     rad = torch.arange(50, dtype=torch.float32) * (1 if rank == 0 else -1)
@@ -84,13 +100,14 @@ def _factored_worker(rank, world, port, q):
     P, M, deg, k = 257, 16, 3, 2
     g = torch.Generator().manual_seed(7)
     means3D = torch.randn(P, 3, generator=g) * 3 + torch.tensor([0.0, 0.0, 10.0])
-    shs = torch.zeros(P, M, 3, requires_grad=True)
+    # the reference keeps the SH coefficients as two parameters (gaussian_model.py:120-123)
+    f_dc, f_rest = torch.zeros(P, 1, 3, requires_grad=True), torch.zeros(P, M - 1, 3, requires_grad=True)
     dense = [torch.zeros(P, 3, requires_grad=True), torch.zeros(P, 1, requires_grad=True)]
     campos = torch.randn(world * k, 3, generator=g)
     colors = torch.randn(world * k, P, 3, generator=g)
     clamp = torch.rand(world * k, P, 3, generator=g) < 0.2
     dense_g = [[torch.randn(p.shape, generator=g) for p in dense] for _ in range(world)]
-    with multiview.FactoredGradReducer(dense, shs, means3D, views_per_rank=k,
+    with multiview.FactoredGradReducer(dense, (f_dc, f_rest), means3D, views_per_rank=k,
                                        mask_fn=lambda geom, gc, n: gc * (~geom).float(),
                                        rebuild_fn=_rebuild_ref) as red:
         ok = len(rasterizer.BACKWARD_OBSERVERS) == 1
@@ -98,12 +115,15 @@ def _factored_worker(rank, world, port, q):
             v = rank * k + j
             for obs in list(rasterizer.BACKWARD_OBSERVERS):
                 obs(grad_colors=colors[v], geomBuffer=clamp[v], campos=campos[v], sh_degree=deg, num_points=P)
+                # a pass over another Gaussian set (render_object) is ignored, not an error
+                obs(grad_colors=colors[v][:5], geomBuffer=clamp[v][:5], campos=campos[v], sh_degree=deg, num_points=5)
         for p, gr in zip(dense, dense_g[rank]):
             p.grad = gr.clone()
-        shs.grad = torch.full_like(shs, float("nan"))  # must be replaced, not accumulated into
-        red.all_reduce()
+        f_dc.grad = torch.full_like(f_dc, float("nan"))  # must be replaced, not accumulated into
+        red.begin()
+        red.wait()
         exp = _rebuild_ref(means3D, campos, colors * (~clamp).float(), deg, M)
-        ok &= torch.allclose(shs.grad, exp, atol=1e-6)
+        ok &= torch.allclose(f_dc.grad, exp[:, :1], atol=1e-6) and torch.allclose(f_rest.grad, exp[:, 1:], atol=1e-6)
         for i, p in enumerate(dense):
             ok &= torch.allclose(p.grad, sum(dense_g[r][i] for r in range(world)), atol=1e-6)
         try:  # a second exchange without new backward passes is a usage error
