@@ -14,6 +14,55 @@ from ._native import ALLOC_FN, SgrError, check
 
 NUM_CHANNELS = 3  # config.h:15
 
+# Two bindings of the same C ABI: the pybind module built from csrc/ext.cpp with torch.utils.cpp_extension (what the
+# reference ships, ext.cpp:15-20) and the ctypes one below (no compiler needed).  The pybind module is used for the
+# five reference entry points when it has been built (street_gaussians_amd.build.build_pybind) unless
+# SGR_BINDING=ctypes; everything beyond the reference's API (statistics sink, introspection, ...) is ctypes.
+_ext = None
+_ext_tried = False
+
+
+def _pybind():
+    global _ext, _ext_tried
+    if not _ext_tried:
+        _ext_tried = True
+        import os
+        if os.environ.get("SGR_BINDING", "") != "ctypes":
+            _native.lib()  # libsgr_hip.so first: a missing library must raise its own, clear error
+            try:
+                from . import _C_pybind as m
+                _ext = m
+            except ImportError:
+                if os.environ.get("SGR_BINDING", "") == "pybind":
+                    raise
+    return _ext
+
+
+def binding() -> str:
+    """'pybind' or 'ctypes': which binding serves the reference's entry points in this process."""
+    return "pybind" if _pybind() is not None else "ctypes"
+
+
+def set_binding(name: str) -> None:
+    """Switch at run time (A/B of the host-side cost): 'pybind' or 'ctypes'."""
+    global _ext, _ext_tried
+    if name == "ctypes":
+        _ext, _ext_tried = None, True
+    elif name == "pybind":
+        from . import _C_pybind as m
+        _ext, _ext_tried = m, True
+    else:
+        raise ValueError(name)
+
+
+def _call_ext(fn, *args):
+    try:
+        return fn(*args)
+    except RuntimeError as ex:  # std::runtime_error of the C++ side -> the error type of the ctypes binding
+        if isinstance(ex, SgrError):
+            raise
+        raise SgrError(str(ex).split("\n")[0]) from None
+
 
 class _BackwardExtras(C.Structure):  # sgr_backward_extras (include/sgr.h)
     _fields_ = [("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p), ("max_radii2D", C.c_void_p)]
@@ -61,6 +110,14 @@ def rasterize_gaussians(background, means3D, colors, semantics, opacity, scales,
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     _dev_check(means3D, "means3D")
+    ext = _pybind()
+    if ext is not None:
+        e = torch.Tensor([])
+        z = lambda t: e if t is None else t
+        return _call_ext(ext.rasterize_gaussians, z(background), means3D, z(colors), z(semantics), z(opacity), z(scales),
+                         z(rotations), float(scale_modifier), z(cov3D_precomp), z(viewmatrix), z(projmatrix),
+                         float(tan_fovx), float(tan_fovy), int(image_height), int(image_width), z(sh), int(degree),
+                         z(campos), bool(prefiltered), bool(debug))
     dev = means3D.device
     P, H, W = means3D.size(0), int(image_height), int(image_width)
     S = semantics.size(1) if semantics is not None and semantics.ndimension() == 2 else 0
@@ -99,6 +156,15 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     stats (extension): (xyz_gradient_accum [P,2], denom [P,1], max_radii2D [P]) contiguous float32 tensors updated in
     place with this view's densification statistics (sgr_backward_ex)."""
     _dev_check(means3D, "means3D")
+    ext = _pybind()
+    if ext is not None and stats is None:
+        e = torch.Tensor([])
+        z = lambda t: e if t is None else t
+        return _call_ext(ext.rasterize_gaussians_backward, z(background), means3D, radii, z(colors), z(scales), z(rotations),
+                         float(scale_modifier), z(cov3D_precomp), z(viewmatrix), z(projmatrix), float(tan_fovx),
+                         float(tan_fovy), dL_dout_color, dL_dout_depth, dL_dout_alpha, z(dL_dout_semantic), z(sh),
+                         int(degree), z(campos), geomBuffer, int(R), binningBuffer, imageBuffer, alphas, z(semantics),
+                         bool(debug))
     dev = means3D.device
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
@@ -151,6 +217,9 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
 def mark_visible(means3D, viewmatrix, projmatrix):
     """markVisible (rasterize_points.cu:222-241)."""
     _dev_check(means3D, "means3D")
+    ext = _pybind()
+    if ext is not None:
+        return _call_ext(ext.mark_visible, means3D, viewmatrix, projmatrix)
     dev = means3D.device
     P = means3D.size(0)
     present = torch.zeros((P,), dtype=torch.bool, device=dev)
@@ -169,6 +238,13 @@ def rasterize_gaussians_filter(means3D, scales, rotations, scale_modifier, cov3D
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     _dev_check(means3D, "means3D")
+    ext = _pybind()
+    if ext is not None:
+        e = torch.Tensor([])
+        z = lambda t: e if t is None else t
+        return _call_ext(ext.rasterize_gaussians_filter, means3D, z(scales), z(rotations), float(scale_modifier),
+                         z(cov3D_precomp), viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy), int(image_height),
+                         int(image_width), bool(prefiltered), bool(debug))
     dev = means3D.device
     P = means3D.size(0)
     radii = torch.zeros((P,), dtype=torch.int32, device=dev)
@@ -192,6 +268,9 @@ def rasterize_gaussians_filter(means3D, scales, rotations, scale_modifier, cov3D
 def distCUDA2(points):
     """distCUDA2 (simple-knn/spatial.cu:16-26)."""
     _dev_check(points, "points")
+    ext = _pybind()
+    if ext is not None:
+        return _call_ext(ext.distCUDA2, points)
     dev = points.device
     P = points.size(0)
     means = torch.zeros((P,), dtype=torch.float32, device=dev)

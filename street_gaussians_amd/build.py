@@ -71,5 +71,48 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+EXT_NAME = "_C_pybind"
+
+
+def build_pybind(force: bool = False, verbose: bool = False) -> str:
+    """Builds street_gaussians_amd/_C_pybind*.so, the pybind module of csrc/ext.cpp, with torch.utils.cpp_extension
+    (the way the reference builds its `_C`, submodules/diff-gaussian-rasterization/setup.py:21-30): host C++ only, linked
+    against libsgr_hip.so next to it (rpath $ORIGIN).  In-tree, so it travels with the snapshot like the HIP library."""
+    import glob
+    import sysconfig
+    from torch.utils import cpp_extension as ce
+    src = os.path.join(CSRC, "ext.cpp")
+    suffix = sysconfig.get_config_var("EXT_SUFFIX") or ".so"
+    out = os.path.join(HERE, EXT_NAME + suffix)
+    deps = [src, os.path.join(HERE, "..", "include", "sgr.h")]
+    if not force and os.path.exists(out) and os.path.getmtime(out) > _newest(deps) and os.path.getmtime(out) > os.path.getmtime(LIB):
+        return out
+    torch_lib = os.path.abspath(os.path.join(os.path.dirname(__import__("torch").__file__), "lib"))
+    bdir = os.path.join(OBJ, "pybind")
+    os.makedirs(bdir, exist_ok=True)
+    for old in glob.glob(os.path.join(HERE, EXT_NAME + "*.so")):
+        os.remove(old)
+    # torch.utils.cpp_extension drives the compiler (ninja + c++): ext.cpp is host code, the device code is libsgr_hip.so
+    built = os.path.join(bdir, EXT_NAME + ".so")
+    try:
+        ce.load(name=EXT_NAME, sources=[src], build_directory=bdir, is_python_module=False, with_cuda=False,
+                verbose=verbose,
+                extra_cflags=["-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-Wno-deprecated-declarations"],
+                extra_include_paths=["/opt/rocm/include"],
+                extra_ldflags=["-L" + HERE, "-lsgr_hip", "-L" + torch_lib, "-lc10_hip", "-ltorch_python",
+                               "-Wl,-rpath,'$$ORIGIN'"])
+    except OSError:
+        # load() also dlopens what it built, from the build directory, where $ORIGIN does not reach libsgr_hip.so:
+        # the file is complete, it is loaded from its final place below
+        if not os.path.exists(built):
+            raise
+    if not os.path.exists(built):
+        raise RuntimeError(f"torch.utils.cpp_extension did not produce {built}")
+    import shutil
+    shutil.copyfile(built, out)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="-f" in sys.argv, verbose=True))
+    print(build_pybind(force="-f" in sys.argv, verbose=True))

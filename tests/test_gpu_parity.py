@@ -524,3 +524,34 @@ def test_full_size_properties(P, S):
     lhs = npy(g["colors"]).astype(np.float64).sum(0)
     rhs = (wts["color"].numpy().astype(np.float64) * a.astype(np.float64)).sum((1, 2))
     assert np.abs(lhs - rhs).max() <= 1e-3 * np.abs(rhs).max() + 1e-2
+
+
+def test_pybind_and_ctypes_bindings_agree():
+    """The pybind `_C` module (csrc/ext.cpp, torch.utils.cpp_extension) and the ctypes binding drive the same C ABI:
+    bit-identical outputs, the reference's error behaviour on both."""
+    from street_gaussians_amd._native import SgrError
+    cam, sc, kw = _kw("mid_20k_sem3")
+    wts = syn.loss_weights(cam, S=3)
+    prev = _C.binding()
+    out = {}
+    try:
+        for b in ("ctypes", "pybind"):
+            _C.set_binding(b)
+            assert _C.binding() == b
+            res, _ = raw_forward(kw)
+            g = raw_backward(kw, res, wts)
+            out[b] = (res, g)
+            with pytest.raises(SgrError, match=r"\[0, 32\]"):
+                bad = dict(kw, semantics=torch.zeros(sc.P, 40))
+                raw_forward(bad)
+            with pytest.raises(SgrError, match="no CPU path"):
+                _C.distCUDA2(torch.rand(10, 3))
+            assert torch.equal(_C.mark_visible(dev(sc.means3D), dev(cam.viewmatrix), dev(cam.projmatrix)),
+                               torch.from_numpy(oracle.mark_visible(sc.means3D, cam.viewmatrix, cam.projmatrix)).cuda())
+    finally:
+        _C.set_binding(prev)
+    for k in ["color", "depth", "alpha", "semantic", "radii"]:
+        assert torch.equal(out["ctypes"][0][k], out["pybind"][0][k]), k
+    assert out["ctypes"][0]["R"] == out["pybind"][0]["R"]
+    for k in out["ctypes"][1]:
+        assert torch.equal(out["ctypes"][1][k], out["pybind"][1][k]), k
