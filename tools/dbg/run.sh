@@ -1,3 +1,7 @@
 #!/bin/bash
-timeout 1200 python -m pytest tests -q --tb=short -m gpu -x 2>&1 | grep -v amdgpu.ids | grep -v "^{" | tail -8
-timeout 600 python tools/bench_binding.py 2>&1 | tail -1 | tee gpurun_out/binding_ab.json
+run() { timeout 600 python bench.py --no-cpu-baseline --no-other-configs --steps 200 "$@" 2>&1 | grep -v amdgpu.ids | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['stages_ms'])"; }
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_scene.py tests/test_gpu_multiview.py -q --tb=short -m gpu -x 2>&1 | grep -v amdgpu.ids | tail -6
+echo "== split"; run
+echo "== no split"; SGR_NO_SPLIT=1 run
+echo "== split 5M"; run --gaussians 5000000
+echo "== no split 5M"; SGR_NO_SPLIT=1 run --gaussians 5000000

@@ -1,14 +1,23 @@
 #!/bin/bash
+# Evidence run on the MI355X box: full `-m gpu` suite, smoke(), the default bench.py line, rocprofv3 kernel stats of a short
+# bench run, and the PMC passes (FETCH_SIZE / WRITE_SIZE / SQ, each in its own pass) over profiles/pmc_workload.py.
+# Everything lands in gpurun_out/ev_<tag>/; tools/pmc_summary.py turns the PMC passes into profiles/pmc_blend_bwd.json
+# (stamped with the kernel-source hash bench.py checks).  Copy what is cited into profiles/<round>/.
 R=$GRAFT_REPO_ROOT
-TAG=${1:-v3}
-mkdir -p $R/gpurun_out/ev_$TAG
-echo "== full gpu suite"; timeout 1500 python -m pytest tests -q --tb=short -m gpu 2>&1 | grep -v amdgpu.ids | tail -6 | tee $R/gpurun_out/ev_$TAG/pytest_gpu.log
-echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -2
-echo "== bench"; timeout 900 python bench.py 2>&1 | grep -v amdgpu.ids | tail -1 | tee $R/gpurun_out/ev_$TAG/bench.json | cut -c1-300
+TAG=${1:-r2}
+E=$R/gpurun_out/ev_$TAG
+mkdir -p $E
+rm -f $R/gpurun_out/parity_measured.jsonl $R/gpurun_out/fullsize_parity.json
+echo "== full gpu suite"; timeout 1500 python -m pytest tests -q --tb=short -m gpu 2>&1 | grep -v amdgpu.ids | grep -v "^{" | tail -6 | tee $E/pytest_gpu.log
+echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -v amdgpu.ids | tail -2 | tee $E/smoke.log
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ev_$TAG/stats -o bench -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $R/gpurun_out/ev_$TAG/stats.log 2>&1
-timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/ev_$TAG/fetch -o fetch -- python $R/profiles/pmc_workload.py > $R/gpurun_out/ev_$TAG/fetch.log 2>&1
-timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/ev_$TAG/write -o write -- python $R/profiles/pmc_workload.py > $R/gpurun_out/ev_$TAG/write.log 2>&1
-timeout 900 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $R/gpurun_out/ev_$TAG/sq -o sq -- python $R/profiles/pmc_workload.py > $R/gpurun_out/ev_$TAG/sq.log 2>&1
-rm -f $R/gpurun_out/ev_$TAG/*/*_kernel_trace.csv
-ls $R/gpurun_out/ev_$TAG/*
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $E/stats -o bench -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > $E/stats.log 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $E/fetch -o fetch -- python $R/profiles/pmc_workload.py > $E/fetch.log 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $E/write -o write -- python $R/profiles/pmc_workload.py > $E/write.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $E/sq -o sq -- python $R/profiles/pmc_workload.py > $E/sq.log 2>&1
+rm -f $E/*/*_kernel_trace.csv
+cd $R
+python tools/pmc_summary.py $E $E/pmc_blend_bwd.json > /dev/null 2>&1 && cp $E/pmc_blend_bwd.json profiles/pmc_blend_bwd.json
+echo "== bench (with the fresh traffic file)"; timeout 1200 python bench.py 2>&1 | grep -v amdgpu.ids | tail -1 | tee $E/bench.json | cut -c1-400
+cp $R/gpurun_out/parity_measured.jsonl $R/gpurun_out/fullsize_parity.json $E/ 2>/dev/null
+ls $E
