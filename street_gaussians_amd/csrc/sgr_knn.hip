@@ -4,6 +4,13 @@
 // sgr_scan_sort.hip on the 32 code bits), K17 per-1024 box AABBs, K18 pruned brute force.  No host
 // round trip: the bounding box stays in device memory.  FP contraction is off so the codes and the
 // distances reproduce the oracle bit for bit.
+//
+// K17/K18 work on the points GATHERED INTO MORTON ORDER once (12 B per point of scratch), so a box is a contiguous
+// 12 KB run.  K18 is wave-cooperative: the 64 lanes of a wave own 64 consecutive (spatially close) points; a candidate
+// box is scanned when ANY lane needs it -- its points are loaded 64 at a time with one coalesced 768-byte read and
+// handed to all lanes by v_readlane (scalar broadcast), every lane applying the reference's own per-point predicate and
+// insertion order, so the result is the reference's bit for bit.  (The reference walks the boxes with one thread per
+// point, a divergent loop of scattered 12-byte gathers, simple_knn.cu:147-183.)
 #include <string>
 
 #include "../../include/sgr.h"
@@ -114,17 +121,25 @@ sgr_knn_morton_kernel(uint32_t P, const float* __restrict__ pts, const SgrBox* _
     vals[i] = i;
 }
 
+// points in Morton order: spts[i] = pts[indices[i]]
+__global__ void __launch_bounds__(256)
+sgr_knn_gather_kernel(uint32_t P, const float* __restrict__ pts, const uint32_t* __restrict__ indices, float* __restrict__ spts) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const size_t j = indices[i];
+    spts[3 * (size_t)i] = pts[3 * j];
+    spts[3 * (size_t)i + 1] = pts[3 * j + 1];
+    spts[3 * (size_t)i + 2] = pts[3 * j + 2];
+}
+
 // K17 (simple_knn.cu:78-117): AABB of each run of 1024 Morton-sorted points
 __global__ void __launch_bounds__(256)
-sgr_knn_boxes_kernel(uint32_t P, const float* __restrict__ pts, const uint32_t* __restrict__ indices, SgrBox* boxes) {
+sgr_knn_boxes_kernel(uint32_t P, const float* __restrict__ spts, SgrBox* boxes) {
     __shared__ float lds[4][6];
     const uint32_t first = blockIdx.x * SGR_KNN_BOX;
     const uint32_t count = min((uint32_t)SGR_KNN_BOX, P - first);
     float mn[3], mx[3];
-    block_aabb([&](uint32_t i, float* p) {
-                   const size_t j = indices[i];
-                   p[0] = pts[3 * j]; p[1] = pts[3 * j + 1]; p[2] = pts[3 * j + 2];
-               },
+    block_aabb([&](uint32_t i, float* p) { p[0] = spts[3 * (size_t)i]; p[1] = spts[3 * (size_t)i + 1]; p[2] = spts[3 * (size_t)i + 2]; },
                first, count, mn, mx, lds);
     if (threadIdx.x == 0) {
         for (int k = 0; k < 3; k++) { boxes[blockIdx.x].mn[k] = mn[k]; boxes[blockIdx.x].mx[k] = mx[k]; }
@@ -153,38 +168,49 @@ __device__ __forceinline__ void updateKBest3(const float* ref, const float* q, f
     }
 }
 
-// K18 (simple_knn.cu:147-183)
+__device__ __forceinline__ float sgr_lane_bcast(float v, int k) {  // value of lane k (k wave-uniform) as a scalar
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
+}
+
+// K18 (simple_knn.cu:147-183), wave-cooperative (see the header of this file)
 __global__ void __launch_bounds__(256)
-sgr_knn_meandist_kernel(uint32_t P, const float* __restrict__ pts, const uint32_t* __restrict__ indices,
+sgr_knn_meandist_kernel(uint32_t P, const float* __restrict__ spts, const uint32_t* __restrict__ indices,
                         const SgrBox* __restrict__ boxes, float* __restrict__ dists) {
 #pragma clang fp contract(off)
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (int)P) return;
-    const uint32_t me = indices[idx];
-    const float point[3] = {pts[3 * (size_t)me], pts[3 * (size_t)me + 1], pts[3 * (size_t)me + 2]};
+    const int lane = threadIdx.x & 63;
+    const bool live = idx < (int)P;
+    const int ci = live ? idx : (int)P - 1;  // lanes past P stay in the wave for the cooperative loads
+    const float point[3] = {spts[3 * (size_t)ci], spts[3 * (size_t)ci + 1], spts[3 * (size_t)ci + 2]};
     float best[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
-    for (int i = max(0, idx - 3); i <= min((int)P - 1, idx + 3); i++) {
-        if (i == idx) continue;
-        const size_t j = indices[i];
-        const float q[3] = {pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]};
-        updateKBest3(point, q, best);
+    if (live) {
+        for (int i = max(0, idx - 3); i <= min((int)P - 1, idx + 3); i++) {  // :156-162
+            if (i == idx) continue;
+            const float q[3] = {spts[3 * (size_t)i], spts[3 * (size_t)i + 1], spts[3 * (size_t)i + 2]};
+            updateKBest3(point, q, best);
+        }
     }
     const float reject = best[2];
     best[0] = FLT_MAX; best[1] = FLT_MAX; best[2] = FLT_MAX;
     const int nboxes = (int)((P + SGR_KNN_BOX - 1) / SGR_KNN_BOX);
     for (int b = 0; b < nboxes; b++) {
-        const SgrBox box = boxes[b];
+        const SgrBox box = boxes[b];  // wave-uniform address: scalar loads
         const float dist = distBoxPoint(box, point);
-        if (dist > reject || dist > best[2]) continue;
-        const int hi = min((int)P, (b + 1) * SGR_KNN_BOX);
-        for (int i = b * SGR_KNN_BOX; i < hi; i++) {
-            if (i == idx) continue;
-            const size_t j = indices[i];
-            const float q[3] = {pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]};
-            updateKBest3(point, q, best);
+        const bool need = live && !(dist > reject || dist > best[2]);  // the reference's per-point test (:170-172)
+        if (__ballot(need) == 0ull) continue;                          // no lane of the wave wants this box
+        const int lo = b * SGR_KNN_BOX, hi = min((int)P, lo + SGR_KNN_BOX);
+        for (int c = lo; c < hi; c += 64) {
+            const int i = c + lane;
+            float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+            if (i < hi) { q0 = spts[3 * (size_t)i]; q1 = spts[3 * (size_t)i + 1]; q2 = spts[3 * (size_t)i + 2]; }
+            const int n = min(64, hi - c);
+            for (int k = 0; k < n; k++) {  // candidates in ascending order, exactly as the per-thread loop visits them
+                const float q[3] = {sgr_lane_bcast(q0, k), sgr_lane_bcast(q1, k), sgr_lane_bcast(q2, k)};
+                if (need && (c + k) != idx) updateKBest3(point, q, best);
+            }
         }
     }
-    dists[me] = (best[0] + best[1] + best[2]) / 3.0f;
+    if (live) dists[indices[idx]] = (best[0] + best[1] + best[2]) / 3.0f;
 }
 
 int sgr_knn_impl(int P, const float* points, float* meanDists, sgr_alloc_fn scratch, void* scratch_user, hipStream_t s,
@@ -197,13 +223,14 @@ int sgr_knn_impl(int P, const float* points, float* meanDists, sgr_alloc_fn scra
     const size_t nh = sgr_sort_hist_words(n);
     // carve the scratch
     char* p = (char*)256;
-    uint64_t* keys[2]; uint32_t* vals[2]; uint32_t *hist, *scan_tmp; SgrBox *part, *bb, *boxes;
+    uint64_t* keys[2]; uint32_t* vals[2]; uint32_t *hist, *scan_tmp; SgrBox *part, *bb, *boxes; float* spts;
     auto carve_all = [&](char* base) {
         char* q = base;
         sgr_carve(q, keys[0], (size_t)n); sgr_carve(q, keys[1], (size_t)n);
         sgr_carve(q, vals[0], (size_t)n); sgr_carve(q, vals[1], (size_t)n);
         sgr_carve(q, hist, nh); sgr_carve(q, scan_tmp, sgr_scan_tmp_count(nh));
         sgr_carve(q, part, (size_t)nb1); sgr_carve(q, bb, (size_t)1); sgr_carve(q, boxes, (size_t)nboxes);
+        sgr_carve(q, spts, (size_t)n * 3);
         return q;
     };
     const size_t bytes = (size_t)(carve_all(p) - p) + 256;
@@ -215,8 +242,9 @@ int sgr_knn_impl(int P, const float* points, float* meanDists, sgr_alloc_fn scra
     sgr_knn_minmax2_kernel<<<1, 256, 0, s>>>(nb1, part, bb);
     sgr_knn_morton_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, points, bb, keys[0], vals[0]);
     const int cur = sgr_launch_sort_pairs(keys, vals, n, 32, hist, scan_tmp, s);
-    sgr_knn_boxes_kernel<<<nboxes, 256, 0, s>>>(n, points, vals[cur], boxes);
-    sgr_knn_meandist_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, points, vals[cur], boxes, meanDists);
+    sgr_knn_gather_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, points, vals[cur], spts);
+    sgr_knn_boxes_kernel<<<nboxes, 256, 0, s>>>(n, spts, boxes);
+    sgr_knn_meandist_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, spts, vals[cur], boxes, meanDists);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("knn: ") + hipGetErrorString(e); return -SGR_E_HIP; }
     return 0;
