@@ -1,14 +1,5 @@
 #!/bin/bash
-timeout 600 python -m pytest tests/test_gpu_parity.py -q --tb=short -m gpu -k "knn" 2>&1 | grep -v amdgpu.ids | tail -4
-python - <<'PY'
-import torch, time
-from simple_knn._C import distCUDA2
-for n in (200000, 1000000):
-    g = torch.Generator().manual_seed(7)
-    pts = (torch.randn(n, 3, generator=g) * torch.tensor([30.0, 3.0, 40.0])).cuda()
-    distCUDA2(pts); torch.cuda.synchronize()
-    t = time.perf_counter()
-    for _ in range(5): distCUDA2(pts)
-    torch.cuda.synchronize()
-    print(n, "distCUDA2 ms", round(1e3 * (time.perf_counter() - t) / 5, 3))
-PY
+run() { timeout 600 python bench.py --no-cpu-baseline --no-other-configs --steps 200 "$@" 2>&1 | grep -v amdgpu.ids | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['stages_ms'])"; }
+timeout 900 python -m pytest tests/test_gpu_primitives.py tests/test_gpu_parity.py -q --tb=short -m gpu -x 2>&1 | grep -v amdgpu.ids | tail -4
+echo "== local shuffle"; run
+run --gaussians 5000000
