@@ -78,7 +78,10 @@ static inline void sgr_carve(char*& p, T*& out, size_t count) {
 }
 
 #define SGR_SCAN_ITEMS 2048   // elements per block in the device-wide scan
-#define SGR_SORT_ITEMS 2048   // keys per block in the radix sort (256 threads x 8)
+#ifndef SGR_SORT_IPT
+#define SGR_SORT_IPT 8         // keys per thread in the radix sort
+#endif
+#define SGR_SORT_ITEMS (256 * SGR_SORT_IPT)   // keys per block (256 threads)
 #define SGR_SORT_MAX_PASS 8
 
 static inline size_t sgr_scan_tmp_count(size_t n) { return (n + SGR_SCAN_ITEMS - 1) / SGR_SCAN_ITEMS + 1; }

@@ -112,7 +112,7 @@ void sgr_launch_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp,
 
 // ------------------------------------------------------------------------------------------------
 // radix sort
-// block b owns keys [b*2048, (b+1)*2048); wave w of the block owns 512 consecutive keys, read in 8
+// block b owns keys [b*ITEMS, (b+1)*ITEMS); wave w of the block owns ITEMS/4 consecutive keys, read in IPT
 // steps of 64 (lane l <-> key base + w*512 + step*64 + l), so memory order == (wave, step, lane).
 template <typename K>
 __global__ void __launch_bounds__(256)
@@ -123,7 +123,7 @@ sgr_sort_hist_kernel(const K* __restrict__ keys, uint32_t n, int shift, uint32_t
     __syncthreads();
     const uint32_t base = blockIdx.x * SGR_SORT_ITEMS;
 #pragma unroll
-    for (int s = 0; s < 8; s++) {
+    for (int s = 0; s < SGR_SORT_IPT; s++) {
         const uint32_t i = base + s * 256 + threadIdx.x;
         if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
     }
@@ -177,12 +177,12 @@ sgr_sort_scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ 
     for (int w = 0; w < 4; w++) cnt[w][tid] = 0;
     __syncthreads();
 
-    const uint32_t base = blockIdx.x * SGR_SORT_ITEMS + wave * 512;
+    const uint32_t base = blockIdx.x * SGR_SORT_ITEMS + wave * (64 * SGR_SORT_IPT);
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    K key[8];
-    uint32_t val[8], rnk[8];
+    K key[SGR_SORT_IPT];
+    uint32_t val[SGR_SORT_IPT], rnk[SGR_SORT_IPT];
 #pragma unroll
-    for (int s = 0; s < 8; s++) {
+    for (int s = 0; s < SGR_SORT_IPT; s++) {
         const uint32_t i = base + s * 64 + lane;
         const bool valid = i < n;
         key[s] = valid ? kin[i] : (K)0;
@@ -223,7 +223,7 @@ sgr_sort_scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ 
     }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < 8; s++) {
+    for (int s = 0; s < SGR_SORT_IPT; s++) {
         const uint32_t i = base + s * 64 + lane;
         if (i < n) {
             const uint32_t d = (uint32_t)(key[s] >> shift) & 255u;
@@ -236,7 +236,7 @@ sgr_sort_scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ 
     const uint32_t first = blockIdx.x * SGR_SORT_ITEMS;
     const uint32_t nloc = min((uint32_t)SGR_SORT_ITEMS, n - first);
 #pragma unroll
-    for (int s = 0; s < 8; s++) {
+    for (int s = 0; s < SGR_SORT_IPT; s++) {
         const uint32_t li = s * 256 + tid;
         if (li < nloc) {
             const K k = sK[li];
