@@ -555,3 +555,51 @@ def test_pybind_and_ctypes_bindings_agree():
     assert out["ctypes"][0]["R"] == out["pybind"][0]["R"]
     for k in out["ctypes"][1]:
         assert torch.equal(out["ctypes"][1][k], out["pybind"][1][k]), k
+
+
+def test_degenerate_inputs():
+    """Edge cases of the boundary: nothing visible (every Gaussian behind the camera: R = 0, zero images, zero
+    gradients, backward still legal), a 1x1 image, the maximum number of semantic channels (32), and an image wider
+    than the packed tile rect allows (an error, not a crash)."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from street_gaussians_amd._native import SgrError
+    cam, sc, kw = _kw("tiny_sh3_sem2")
+    # (1) everything behind the camera
+    behind = dict(kw, means3D=sc.means3D * torch.tensor([1.0, 1.0, -1.0]))
+    res, internal = raw_forward(behind)
+    assert res["R"] == 0 and int(res["radii"].abs().sum()) == 0
+    bg = npy(dev(kw["bg"]))
+    assert np.array_equal(npy(res["color"]), np.broadcast_to(bg[:, None, None], res["color"].shape))
+    assert float(res["alpha"].abs().max()) == 0.0 and float(res["depth"].abs().max()) == 0.0
+    wts = syn.loss_weights(cam, S=2)
+    g = raw_backward(behind, res, wts)
+    for k, v in g.items():
+        assert float(v.abs().max()) == 0.0, k
+    # (2) a 1x1 image against the oracle
+    cam1 = syn.make_camera(1, 1, fx=1.0)
+    sc1 = syn.make_scene(50, cam1, S=0, seed=2, scale_px=0.3, zmin=1.0, zmax=3.0, margin=0.3)
+    kw1 = oracle_kwargs(cam1, sc1)
+    fw1 = oracle.forward(**kw1)
+    res1, int1 = raw_forward(kw1)
+    assert res1["R"] == fw1.num_rendered and (npy(res1["radii"]) == fw1.radii).all()
+    image_close(npy(res1["color"]), fw1.color, name="1x1 color", max_outliers=0)
+    # (3) 32 semantic channels (the oracle follows the reference's limit of 20, so: linearity in the channels)
+    cam2 = syn.make_camera(96, 64, fx=100.0)
+    sc2 = syn.make_scene(400, cam2, S=32, seed=4, scale_px=0.02)
+    t = {k: dev(getattr(sc2, k)) for k in ["means3D", "scales", "rotations", "opacities", "shs", "semantics"]}
+    rast = GaussianRasterizer(settings(cam2))
+    full = rast(t["means3D"], None, t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"],
+                semantics=t["semantics"])
+    part = rast(t["means3D"], None, t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"],
+                semantics=t["semantics"][:, 7:20].contiguous())
+    assert full[4].shape == (32, 64, 96)
+    assert torch.allclose(full[4][7:20], part[4], rtol=1e-6, atol=1e-7) and torch.equal(full[0], part[0])
+    sem = t["semantics"].clone().requires_grad_(True)
+    out = rast(t["means3D"], None, t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"], semantics=sem)
+    out[4].sum().backward()
+    assert torch.isfinite(sem.grad).all() and float(sem.grad.abs().max()) > 0
+    assert torch.allclose(sem.grad, sem.grad[:, :1].expand_as(sem.grad), rtol=1e-5, atol=1e-7)  # dL/dsem = sum_pix alpha*T
+    # (4) an image the 10-bit packed tile rect cannot address
+    big = settings(cam)._replace(image_width=16400, image_height=8)
+    with pytest.raises(SgrError, match="not supported"):
+        GaussianRasterizer(big)(t["means3D"], None, t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
