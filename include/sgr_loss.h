@@ -40,6 +40,14 @@ int sgr_l1_forward(int C, int H, int W, const float* a, const float* b, const ui
 int sgr_l1_backward(int C, int H, int W, const float* a, const float* b, const uint8_t* mask, const float* out,
                     const float* upstream, float* dL_da, void* stream);
 
+/* The whole colour loss of train.py:100-104 in ONE backward kernel -- the producer of the rasterizer's dL/dout_color:
+ *   dL/dimg1 = upstream[0] * ( w_l1 * d l1_loss/dimg1  +  w_ssim * d ssim/dimg1 ),
+ * w_l1 = (1 - lambda_dssim) * lambda_l1, w_ssim = -lambda_dssim (the loss holds 1 - ssim).  partials / l1_out are what
+ * sgr_ssim_forward / sgr_l1_forward left behind; no intermediate gradient image is materialised. */
+int sgr_color_loss_backward(int C, int H, int W, const float* img1, const float* img2, const uint8_t* mask,
+                            const float* partials, const float* l1_out, float w_l1, float w_ssim, const float* upstream,
+                            float* dL_dimg1, void* stream);
+
 /* ---- the accumulation and depth terms of train.py:106-133 ---------------------------------------------------------
  * Binary-cross-entropy style terms on the accumulated opacity acc [H*W] (clamped to [1e-6, 1-1e-6] first):
  *   SGR_BCE_SKY     where(mask, -log(1 - acc), -log(acc)).mean()                                   train.py:107-109

@@ -24,7 +24,7 @@ SYMBOLS = [
     "sgr_test_wave_sum", "sgr_test_switches", "sgr_profile_enable", "sgr_profile_select", "sgr_profile_read", "sgr_masked_color_grad",
     "sgr_sh_grad_from_views", "sgr_scene_compose_forward", "sgr_scene_compose_backward",
     "sgr_scene_densification_stats", "sgr_ssim_workspace_floats", "sgr_ssim_forward", "sgr_ssim_backward",
-    "sgr_l1_workspace_floats", "sgr_l1_forward", "sgr_l1_backward", "sgr_bce_forward", "sgr_bce_backward",
+    "sgr_l1_workspace_floats", "sgr_l1_forward", "sgr_l1_backward", "sgr_color_loss_backward", "sgr_bce_forward", "sgr_bce_backward",
     "sgr_lidar_work_bytes", "sgr_lidar_depth_forward", "sgr_lidar_depth_backward", "sgr_densify_work_bytes", "sgr_densify_plan",
     "sgr_densify_map", "sgr_densify_gather", "sgr_densify_split_children", "sgr_densify_prune_mask",
     "sgr_densify_compact", "sgr_reset_opacity",
@@ -82,6 +82,8 @@ def lib():
         L.sgr_ssim_forward.argtypes = [i, i, i, vp, vp, vp, vp, vp, vp, vp]
         L.sgr_ssim_backward.restype = i
         L.sgr_ssim_backward.argtypes = [i, i, i, vp, vp, vp, vp, vp, vp, vp]
+        L.sgr_color_loss_backward.restype = i
+        L.sgr_color_loss_backward.argtypes = [i, i, i, vp, vp, vp, vp, vp, f, f, vp, vp, vp]
         L.sgr_l1_forward.restype = i
         L.sgr_l1_forward.argtypes = [i, i, i, vp, vp, vp, vp, vp, vp]
         L.sgr_l1_backward.restype = i

@@ -126,7 +126,8 @@ sgr_final_sum_kernel(const float* __restrict__ v, size_t n, float scale, const f
 __global__ void __launch_bounds__(256)
 sgr_ssim_bwd_kernel(int H, int W, int C, const float* __restrict__ img1, const float* __restrict__ img2,
                     const uint8_t* __restrict__ mask, SgrGauss11 g, const float* __restrict__ partials,
-                    const float* __restrict__ upstream, float* __restrict__ dimg1) {
+                    const float* __restrict__ upstream, float* __restrict__ dimg1, float w_ssim, float w_l1,
+                    const float* __restrict__ l1_out) {
     __shared__ float sp[3][SGR_LS_IN][SGR_LS_IN + 1];
     __shared__ float hb[3][SGR_LS_IN][SGR_LS_T + 1];
     const int c = blockIdx.z, x0 = blockIdx.x * SGR_LS_T, y0 = blockIdx.y * SGR_LS_T;
@@ -166,7 +167,12 @@ sgr_ssim_bwd_kernel(int H, int W, int C, const float* __restrict__ img1, const f
     float out = 0.f;
     if (!mask || mask[o]) {
         const float xv = img1[c * plane + o], yv = img2[c * plane + o];
-        out = (a + 2.f * xv * b + yv * d) * (upstream[0] / (float)cp);
+        out = w_ssim * ((a + 2.f * xv * b + yv * d) * (upstream[0] / (float)cp));
+        if (l1_out != nullptr) {  // fused colour loss: + w_l1 * d l1_loss / d img1  (loss_utils.py:21-37)
+            const float df = xv - yv;
+            const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+            out += w_l1 * upstream[0] * sg / l1_out[1];
+        }
     }
     dimg1[c * plane + o] = out;
 }
@@ -404,7 +410,22 @@ int sgr_ssim_backward(int C, int H, int W, const float* img1, const float* img2,
     if (!img1 || !img2 || !partials || !upstream || !dL_dimg1)
         return sgr_set_error(SGR_E_INVALID, "img1, img2, partials, upstream and dL_dimg1 are required");
     static const SgrGauss11 g = make_window();
-    sgr_ssim_bwd_kernel<<<tile_grid(C, H, W), 256, 0, stream>>>(H, W, C, img1, img2, mask, g, partials, upstream, dL_dimg1);
+    sgr_ssim_bwd_kernel<<<tile_grid(C, H, W), 256, 0, stream>>>(H, W, C, img1, img2, mask, g, partials, upstream, dL_dimg1,
+                                                                1.0f, 0.0f, nullptr);
+    LS_HIP(hipGetLastError());
+    return 0;
+}
+
+int sgr_color_loss_backward(int C, int H, int W, const float* img1, const float* img2, const uint8_t* mask,
+                            const float* partials, const float* l1_out, float w_l1, float w_ssim, const float* upstream,
+                            float* dL_dimg1, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (C <= 0 || H <= 0 || W <= 0) return sgr_set_error(SGR_E_INVALID, "C, H, W must be positive");
+    if (!img1 || !img2 || !partials || !l1_out || !upstream || !dL_dimg1)
+        return sgr_set_error(SGR_E_INVALID, "img1, img2, partials, l1_out, upstream and dL_dimg1 are required");
+    static const SgrGauss11 g = make_window();
+    sgr_ssim_bwd_kernel<<<tile_grid(C, H, W), 256, 0, stream>>>(H, W, C, img1, img2, mask, g, partials, upstream, dL_dimg1,
+                                                                w_ssim, w_l1, l1_out);
     LS_HIP(hipGetLastError());
     return 0;
 }

@@ -187,6 +187,60 @@ def lidar_depth_loss(depth: torch.Tensor, acc: torch.Tensor, lidar_depth: torch.
     return _Lidar.apply(d, _flat(acc, "acc", d), _flat(lidar_depth, "lidar_depth", d).detach(), _flat_mask(mask, d), keep)
 
 
+class _ColorLoss(torch.autograd.Function):
+    """(1 - lambda_dssim) * lambda_l1 * l1_loss + lambda_dssim * (1 - ssim)   (train.py:100-104) as one op: the two
+    forward kernels, then ONE backward kernel that writes dL/dimage -- the upstream gradient the rasterizer's backward
+    reads -- without materialising the two per-term gradient images and their sum."""
+
+    @staticmethod
+    def forward(ctx, img, gt, mask, lambda_dssim, lambda_l1):
+        L = _native.lib()
+        Cc, H, W = img.shape
+        dev = img.device
+        out_s = torch.empty(1, dtype=torch.float32, device=dev)
+        out_l = torch.empty(2, dtype=torch.float32, device=dev)
+        ws = torch.empty(max(L.sgr_ssim_workspace_floats(Cc, H, W), L.sgr_l1_workspace_floats(Cc, H, W)),
+                         dtype=torch.float32, device=dev)
+        partials = torch.empty(3 * Cc * H * W, dtype=torch.float32, device=dev) if img.requires_grad else None
+        with torch.cuda.device(dev):
+            check(L.sgr_l1_forward(Cc, H, W, _p(img), _p(gt), _p(mask), _p(out_l), _p(ws), _stream(dev)))
+            check(L.sgr_ssim_forward(Cc, H, W, _p(img), _p(gt), _p(mask), _p(out_s), _p(partials), _p(ws), _stream(dev)))
+        ctx.save_for_backward(img, gt, mask if mask is not None else torch.empty(0, device=dev),
+                              partials if partials is not None else torch.empty(0, device=dev), out_l)
+        ctx.has_mask = mask is not None
+        ctx.w_l1, ctx.w_ssim = (1.0 - float(lambda_dssim)) * float(lambda_l1), -float(lambda_dssim)
+        loss = ctx.w_l1 * out_l[0] + float(lambda_dssim) * (1.0 - out_s[0])
+        ctx.mark_non_differentiable(out_l)
+        return loss, out_l
+
+    @staticmethod
+    def backward(ctx, upstream, _unused):
+        img, gt, mask, partials, out_l = ctx.saved_tensors
+        Cc, H, W = img.shape
+        dev = img.device
+        if partials.numel() == 0:
+            raise RuntimeError("color_loss forward ran without requires_grad")
+        up = upstream.reshape(1).to(torch.float32).contiguous()
+        grad = torch.empty_like(img)
+        with torch.cuda.device(dev):
+            check(_native.lib().sgr_color_loss_backward(Cc, H, W, _p(img), _p(gt), _p(mask) if ctx.has_mask else None,
+                                                        _p(partials), _p(out_l), ctx.w_l1, ctx.w_ssim, _p(up), _p(grad),
+                                                        _stream(dev)))
+        return grad, None, None, None, None
+
+
+def color_loss(image: torch.Tensor, gt: torch.Tensor, mask: Optional[torch.Tensor] = None, lambda_dssim: float = 0.2,
+               lambda_l1: float = 1.0, return_l1: bool = False):
+    """train.py:100-104 in one op: ``(1 - lambda_dssim) * lambda_l1 * l1_loss(image, gt, mask) + lambda_dssim *
+    (1 - ssim(image, gt, mask=mask))``; its backward is a single kernel producing dL/dimage for the rasterizer.
+    With ``return_l1`` also returns the (detached) L1 term train.py logs (``scalar_dict['l1_loss']``)."""
+    a, b = _prep(image, "image"), _prep(gt, "gt")
+    if a.shape != b.shape:
+        raise RuntimeError("image and gt must have the same shape")
+    loss, out_l = _ColorLoss.apply(a, b.detach(), _prep_mask(mask, a.shape[1], a.shape[2]), lambda_dssim, lambda_l1)
+    return (loss, out_l[0]) if return_l1 else loss
+
+
 def l1_loss(network_output: torch.Tensor, gt: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """loss_utils.py:21-37: mean |network_output - gt| over the C values of the pixels selected by mask (1, H, W)."""
     a, b = _prep(network_output, "network_output"), _prep(gt, "gt")

@@ -98,3 +98,27 @@ def test_loss_argument_checks():
         losses.l1_loss(x.cpu(), x.cpu())
     assert float(losses.ssim(x, x)) == pytest.approx(1.0, abs=1e-6)
     assert float(losses.l1_loss(x, x)) == 0.0
+
+
+@pytest.mark.parametrize("H,W,masked,lam", [(64, 96, False, 0.2), (131, 77, True, 0.2), (320, 480, True, 0.5)])
+def test_fused_color_loss_matches_the_two_term_reference(H, W, masked, lam):
+    """losses.color_loss = train.py:100-104 in one op: same value and gradient as the two reference terms."""
+    g = torch.Generator().manual_seed(5)
+    img, gt = torch.rand(3, H, W, generator=g), torch.rand(3, H, W, generator=g)
+    mask = (torch.rand(1, H, W, generator=g) < 0.7) if masked else None
+    x64 = img.double().requires_grad_(True)
+    want = (1.0 - lam) * 1.0 * ref.l1_loss(x64, gt.double(), mask) + lam * (1.0 - ref.ssim(x64, gt.double(), mask=mask))
+    want.backward()
+    x = img.cuda().requires_grad_(True)
+    got, l1 = losses.color_loss(x, gt.cuda(), None if mask is None else mask.cuda(), lambda_dssim=lam, return_l1=True)
+    got.backward()
+    assert abs(got.item() - want.item()) <= 5e-6 * abs(want.item())
+    assert abs(l1.item() - ref.l1_loss(img.double(), gt.double(), mask).item()) <= 5e-6
+    scale = float(x64.grad.abs().max())
+    assert float((x.grad.cpu() - x64.grad).abs().max()) <= 3e-5 * scale
+    # and equals the sum of the two separate ops' gradients
+    y = img.cuda().requires_grad_(True)
+    two = (1.0 - lam) * losses.l1_loss(y, gt.cuda(), None if mask is None else mask.cuda()) + \
+        lam * (1.0 - losses.ssim(y, gt.cuda(), mask=None if mask is None else mask.cuda()))
+    two.backward()
+    assert torch.allclose(x.grad, y.grad, rtol=1e-5, atol=1e-9)

@@ -41,6 +41,6 @@ def test_loss_abi_symbols_are_exported():
     L = C.CDLL(_native.LIB_PATH)
     decl = open(os.path.join(ROOT, "include", "sgr_loss.h")).read()
     names = re.findall(r"^(?:int|size_t) (sgr_\w+)\(", decl, re.M)
-    assert len(names) == 11
+    assert len(names) == 12
     for n in names:
         assert hasattr(L, n), n
