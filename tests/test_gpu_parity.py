@@ -44,7 +44,21 @@ def _cases():
     cam = syn.make_camera(640, 400, fx=700.0)
     sc = syn.make_scene(4000, cam, S=0, seed=6, scale_px=0.05, zmin=0.3, zmax=10.0)  # huge splats, fat tiles
     out["huge_splats"] = (cam, sc, dict())
+    # giant, nearly degenerate splats (sigma of ~1e3 px along one axis, sub-pixel along the others): the conic's
+    # determinant cancels in fp32, which is where a cull box derived from the covariance could disagree with the
+    # conic the blend kernels evaluate
+    cam = syn.make_camera(400, 240, fx=420.0)
+    sc = syn.make_scene(600, cam, S=0, seed=8, scale_px=0.004, zmin=0.5, zmax=6.0)
+    sc.scales[::2] = sc.scales[::2] * torch.tensor([900.0, 0.02, 0.02])
+    sc.scales[1::4] = sc.scales[1::4] * torch.tensor([0.05, 400.0, 0.05])
+    out["giant_degenerate"] = (cam, sc, dict())
     return out
+
+
+# Not compared with the oracle: at sigma ~1e3 px the quadratic form -0.5*(A dx^2 + C dy^2) - B dx dy cancels by 4-6
+# digits, so two correct evaluation orders (the reference's, the pre-scaled FMA form of the kernels) differ by more
+# than the parity gate.  What must hold, and is tested, is that the CULL never changes a bit on such splats.
+ILL_CONDITIONED = {"giant_degenerate"}
 
 
 CASES = _cases()
@@ -70,7 +84,7 @@ def _kw(name):
     return cam, sc, oracle_kwargs(cam, sc, deg=opt.get("deg", 3), bg=opt.get("bg"))
 
 
-@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("name", [n for n in CASES if n not in ILL_CONDITIONED])
 def test_forward_matches_oracle(name):
     cam, sc, kw = _kw(name)
     fw = oracle.forward(**kw)
@@ -101,7 +115,7 @@ def test_forward_matches_oracle(name):
     fw.free()
 
 
-@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("name", [n for n in CASES if n not in ILL_CONDITIONED])
 def test_backward_matches_oracle(name):
     cam, sc, kw = _kw(name)
     S = sc.semantics.shape[1]
@@ -132,7 +146,7 @@ def _color_mag(fw, wts):
     return {"colors": gabs["colors"], "sh": np.abs(gabs["sh"]) + gabs["colors"][:, None, :] * 0.3}
 
 
-@pytest.mark.parametrize("name", ["mid_20k_sem3", "huge_splats", "sem19_deg1"])
+@pytest.mark.parametrize("name", ["mid_20k_sem3", "huge_splats", "sem19_deg1", "giant_degenerate"])
 def test_culling_is_invisible_and_backward_is_deterministic(name):
     """The ballot cull may only skip pairs that fail the alpha test: images must be BIT-identical with the cull
     on and off; gradients bit-identical run to run (no atomics), with the backward walking the forward's hit record
@@ -159,6 +173,8 @@ def test_culling_is_invisible_and_backward_is_deterministic(name):
     g_b2 = raw_backward(kw, res_b, wts)  # hit record written by the un-culled forward
     for k in g_a:
         assert torch.equal(g_a[k], g_b2[k]), f"hit record of the un-culled forward changed dL/d{k}"
+    if name in ILL_CONDITIONED:
+        return  # the comparisons below are rounding-level statements; they do not apply to cancelling quadratic forms
     with switches(_C.NO_DPP):
         g_c = raw_backward(kw, res_a, wts)
     for k in g_a:  # different summation order inside a wave: equal up to fp32 rounding
