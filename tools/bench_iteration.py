@@ -57,8 +57,10 @@ def iteration(fused):
     means3D, rot, scales, opac, shs, sem = flat
     m2d = torch.zeros(means3D.shape[0], 3, device=dev, requires_grad=True)
     color, radii, depth, alpha, semantic = rast(means3D, m2d, opac, shs=shs, scales=scales, rotations=rot, semantics=sem)
-    L = losses if fused else ref_loss
-    loss = 0.8 * L.l1_loss(color, gt, mask) + 0.2 * (1.0 - L.ssim(color, gt, mask=mask))
+    if fused:  # one forward pass + one backward pass over the image (losses.color_loss)
+        loss = losses.color_loss(color, gt, mask, lambda_dssim=0.2, lambda_l1=1.0)
+    else:
+        loss = 0.8 * ref_loss.l1_loss(color, gt, mask) + 0.2 * (1.0 - ref_loss.ssim(color, gt, mask=mask))
     loss.backward()
     return loss
 

@@ -47,8 +47,13 @@ N = sum(counts)
 ups = None
 
 
+leaves = [v for d in dicts for v in d.values() if torch.is_tensor(v) and v.requires_grad]
+
+
 def run(fn):
     global ups
+    for t in leaves:  # optimizer.zero_grad(set_to_none=True): the op's gradients become .grad, no accumulation kernels
+        t.grad = None
     outs = fn()
     if ups is None:
         ups = [torch.randn_like(o) for o in outs]

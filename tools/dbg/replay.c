@@ -1,0 +1,73 @@
+// scratch: visit statistics of the blend walk under different wave decompositions (CPU replay on the oracle's lists)
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdio.h>
+#include <omp.h>
+// out[0]=quadrant visits (>=1 hit), out[1]=sum over (wave,batch) max over 4 4x4 blocks, out[2]= same for 8x2 rows,
+// out[3]=sum over (wave,batch) max over 2 8x4 halves, out[4]=lane hits total, out[5]=sum of 4x4 block visits,
+// out[6]=sum over waves (no batching) of max over 4x4 blocks, out[7]=# (tile,batch) rounds,
+// out[8]=sum over (tile,batch) of max over 16 blocks (whole-WG lockstep), out[9]=sum 8x4 half visits
+void replay(int W, int H, const uint32_t* ranges, const uint32_t* plist, const float* m2d, const float* co,
+            const uint32_t* ncontrib, int batch, double* out) {
+  int gx = (W + 15) / 16, gy = (H + 15) / 16;
+  double acc[16] = {0};
+#pragma omp parallel
+  {
+    double a[16] = {0};
+#pragma omp for schedule(dynamic, 8)
+    for (int t = 0; t < gx * gy; ++t) {
+      uint32_t r0 = ranges[2 * t], r1 = ranges[2 * t + 1];
+      if (r1 <= r0) continue;
+      int tx = t % gx, ty = t / gx;
+      uint32_t nc[256]; uint32_t maxc = 0;
+      for (int p = 0; p < 256; ++p) {
+        int px = tx * 16 + (p & 15), py = ty * 16 + (p >> 4);
+        nc[p] = (px < W && py < H) ? ncontrib[py * W + px] : 0;
+        if (nc[p] > maxc) maxc = nc[p];
+      }
+      int tot44[4][4] = {{0}};
+      for (uint32_t b0 = 0; b0 < maxc; b0 += batch) {
+        int c44[4][4] = {{0}}, c82[4][4] = {{0}}, c84[4][2] = {{0}};
+        a[7] += 1;
+        for (uint32_t pos = b0; pos < b0 + batch && pos < maxc; ++pos) {
+          uint32_t g = plist[r0 + pos];
+          float X = m2d[2 * g], Y = m2d[2 * g + 1], A = co[4 * g], B = co[4 * g + 1], Cc = co[4 * g + 2], O = co[4 * g + 3];
+          uint32_t h44 = 0, h82 = 0, h84 = 0, hq = 0; int lanes = 0;
+          for (int p = 0; p < 256; ++p) {
+            if (pos >= nc[p]) continue;
+            int lx = p & 15, ly = p >> 4;
+            float dx = X - (float)(tx * 16 + lx), dy = Y - (float)(ty * 16 + ly);
+            float pw = -0.5f * (A * dx * dx + Cc * dy * dy) - B * dx * dy;
+            if (pw > 0.f) continue;
+            float al = fminf(0.99f, O * expf(pw));
+            if (al < 1.f / 255.f) continue;
+            int q = (ly >> 3) * 2 + (lx >> 3), qx = lx & 7, qy = ly & 7;
+            hq |= 1u << q; ++lanes;
+            h44 |= 1u << (q * 4 + (qy >> 2) * 2 + (qx >> 2));
+            h82 |= 1u << (q * 4 + (qy >> 1));
+            h84 |= 1u << (q * 2 + (qy >> 2));
+          }
+          a[4] += lanes;
+          for (int q = 0; q < 4; ++q) {
+            if (hq >> q & 1) a[0] += 1;
+            for (int k = 0; k < 4; ++k) { c44[q][k] += h44 >> (q * 4 + k) & 1; c82[q][k] += h82 >> (q * 4 + k) & 1; }
+            for (int k = 0; k < 2; ++k) c84[q][k] += h84 >> (q * 2 + k) & 1;
+          }
+        }
+        int m16 = 0;
+        for (int q = 0; q < 4; ++q) {
+          int m = 0, m2 = 0, m3 = 0;
+          for (int k = 0; k < 4; ++k) { if (c44[q][k] > m) m = c44[q][k]; if (c82[q][k] > m2) m2 = c82[q][k]; a[5] += c44[q][k]; tot44[q][k] += c44[q][k]; }
+          for (int k = 0; k < 2; ++k) { if (c84[q][k] > m3) m3 = c84[q][k]; a[9] += c84[q][k]; }
+          a[1] += m; a[2] += m2; a[3] += m3; if (m > m16) m16 = m;
+        }
+        a[8] += m16;
+      }
+      for (int q = 0; q < 4; ++q) { int m = 0; for (int k = 0; k < 4; ++k) if (tot44[q][k] > m) m = tot44[q][k]; a[6] += m; }
+    }
+#pragma omp critical
+    for (int i = 0; i < 16; ++i) acc[i] += a[i];
+  }
+  for (int i = 0; i < 16; ++i) out[i] = acc[i];
+}

@@ -1,2 +1,2 @@
-#!/bin/bash
-timeout 600 python -m pytest tests/test_gpu_parity.py -q --tb=short -m gpu -k "giant" 2>&1 | grep -v amdgpu.ids | tail -5
+cd $GRAFT_REPO_ROOT
+timeout 600 python tools/dbg/prof_scene2.py 2>&1 | grep -v amdgpu.ids | tail -5

@@ -19,5 +19,7 @@ rm -f $E/*/*_kernel_trace.csv
 cd $R
 python tools/pmc_summary.py $E $E/pmc_blend_bwd.json > /dev/null 2>&1 && cp $E/pmc_blend_bwd.json profiles/pmc_blend_bwd.json
 echo "== bench (with the fresh traffic file)"; timeout 1200 python bench.py 2>&1 | grep -v amdgpu.ids | tail -1 | tee $E/bench.json | cut -c1-400
+echo "== rows next to the path (n1-n4)"
+for t in iteration scene loss densify binding; do timeout 600 python tools/bench_$t.py 2>&1 | grep -v amdgpu.ids | tail -1 > $E/$t.json; done
 cp $R/gpurun_out/parity_measured.jsonl $R/gpurun_out/fullsize_parity.json $E/ 2>/dev/null
 ls $E
