@@ -20,20 +20,23 @@
 #define SGR_TILE_THREADS 256
 typedef float sgr_f2 __attribute__((ext_vector_type(2)));
 // list entries staged in LDS per round.  128 (not 256) keeps the S = 0 workgroup at 20 KB of LDS so that occupancy is
-// set by registers instead of LDS: measured +11 % time at 3 workgroups / CU vs 4.  The instantiations with many
-// semantic channels have wide rows (two 128 x 32-float row sets = 33 KB at 20 channels) but are limited to 2-3 waves
-// per SIMD by their registers anyway, so they stage 128 entries as well (64-entry rounds measured 6 % slower at
-// 2 M Gaussians + 19 channels); every instantiation has the deterministic two-row combine.
+// set by registers instead of LDS: measured +11 % time at 3 workgroups / CU vs 4.  The instantiations with more than 8
+// semantic channels have wide rows (two 128 x 32-float row sets = 33 KB at 20 channels): with the factored channel
+// recurrence they need 95-144 VGPRs (3-5 waves / SIMD), so LDS would be the limiter at 128 entries -- they stage 64
+// (2 M Gaussians + 19 channels: 2.40 ms vs 2.57 ms at 128).  Every instantiation has the deterministic two-row combine.
 #ifndef SGR_BWD_BATCH
 #define SGR_BWD_BATCH 128
 #endif
 #ifndef SGR_BWD_BATCH_WIDE
-#define SGR_BWD_BATCH_WIDE 128
+#define SGR_BWD_BATCH_WIDE 64
 #endif
 template <int SMAX>
 struct SgrBwdBatch { static constexpr int value = SMAX <= 8 ? SGR_BWD_BATCH : SGR_BWD_BATCH_WIDE; };
 #define SGR_ROW_BASE 11
 // 1: folded row stage of the wave reduction (7 DPP adds + 1 LDS add per hit at S = 0), 0: four row steps per register
+#ifndef SGR_FACTORED
+#define SGR_FACTORED 1
+#endif
 #ifndef SGR_FOLD
 #define SGR_FOLD 1
 #endif
@@ -357,9 +360,17 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
     sgr_f2 acc01 = {0.f, 0.f}, acc2D = {0.f, 0.f}, last01 = {0.f, 0.f}, last2D = {0.f, 0.f};
     const sgr_f2 dL01 = {dLdC0, dLdC1}, dL2D = {dLdC2, dLdD};
     float accA = 0.f, last_alpha = 0.f;
-    float accS[NS], lastS[NS];
+    constexpr int NREC = SGR_FACTORED ? 1 : NS;
+    float accS[NREC], lastS[NREC];
 #pragma unroll
-    for (int i = 0; i < NS; i++) { accS[i] = 0.f; lastS[i] = 0.f; }
+    for (int i = 0; i < NREC; i++) { accS[i] = 0.f; lastS[i] = 0.f; }
+    // SGR_FACTORED: the 5 + S per-channel recurrences of backward.cu:553-589 (accum_rec[ch] = last_alpha * last_c[ch] +
+    // (1 - last_alpha) * accum_rec[ch];  dL_dalpha += (c[ch] - accum_rec[ch]) * dL_dpixel[ch]) are linear in the
+    // channel values, and only their dL_dpixel-weighted sum is used: with u = sum_ch c[ch] * dL_dpixel[ch] (alpha's
+    // "colour" is 1) the sum is  u - Arec,  Arec <- last_alpha * u_last + (1 - last_alpha) * Arec: ONE scalar
+    // recurrence per pixel instead of 5 + S, same value up to rounding (the terms are summed before the subtraction
+    // instead of after it).
+    float Arec = 0.f, u_last = 0.f;
 
     // highest list position any pixel of the tile blended
     int mx = lastc;
@@ -446,12 +457,33 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                     T = T * inv1ma;  // T = T / (1 - alpha)
                     wm = alpha * T;
                     const float one_m_la = 1.0f - last_alpha;
+                    float d;
+                    if (SGR_FACTORED) {
+                        float u = fmaf(c.x, dLdC0, dLdA);
+                        u = fmaf(c.y, dLdC1, u);
+                        u = fmaf(c.z, dLdC2, u);
+                        u = fmaf(c.w, dLdD, u);
+                        if (SMAX > 0) {  // padded channels carry zeros end to end (sSem, dLdS), so no per-channel test
+                            const float4* sj = reinterpret_cast<const float4*>(&sSem[j * SMAX]);
+#pragma unroll
+                            for (int c4 = 0; c4 < SMAX / 4; c4++) {
+                                const float4 s4 = sj[c4];
+                                u = fmaf(s4.x, dLdS[4 * c4], u);
+                                u = fmaf(s4.y, dLdS[4 * c4 + 1], u);
+                                u = fmaf(s4.z, dLdS[4 * c4 + 2], u);
+                                u = fmaf(s4.w, dLdS[4 * c4 + 3], u);
+                            }
+                        }
+                        Arec = fmaf(last_alpha, u_last, one_m_la * Arec);
+                        d = u - Arec;
+                        u_last = u;
+                    } else {
                     const sgr_f2 c01 = {c.x, c.y}, c2D = {c.z, c.w};
                     const sgr_f2 la2 = {last_alpha, last_alpha};
                     acc01 = __builtin_elementwise_fma(la2, last01, one_m_la * acc01);
                     acc2D = __builtin_elementwise_fma(la2, last2D, one_m_la * acc2D);
                     const sgr_f2 t = __builtin_elementwise_fma(c2D - acc2D, dL2D, (c01 - acc01) * dL01);
-                    float d = t.x + t.y;
+                    d = t.x + t.y;
                     accA = fmaf(one_m_la, accA, last_alpha);
                     d = fmaf(1.0f - accA, dLdA, d);
                     if (SMAX > 0) {  // padded channels carry zeros end to end (sSem, dLdS), so no per-channel test
@@ -462,15 +494,16 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                             const float svv[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
                             for (int e = 0; e < 4; e++) {
-                                const int ch = 4 * c4 + e;
+                                const int ch = (4 * c4 + e) % NREC;
                                 accS[ch] = fmaf(last_alpha, lastS[ch], one_m_la * accS[ch]);
-                                d = fmaf(svv[e] - accS[ch], dLdS[ch], d);
+                                d = fmaf(svv[e] - accS[ch], dLdS[4 * c4 + e], d);
                                 lastS[ch] = svv[e];
                             }
                         }
                     }
                     last01 = c01;
                     last2D = c2D;
+                    }
                     last_alpha = alpha;
                     d *= T;
                     Gd = G * fmaf(-T_final * inv1ma, bgdot, d);  // backward.cu:611-614
@@ -681,9 +714,7 @@ sgr_blend_bwd_kernel_v2(SGR_BWD_ARGS) {
     const float bgdot = bg_color[0] * dLdC0 + bg_color[1] * dLdC1 + bg_color[2] * dLdC2;
     const float kx = (0.5f * (float)W) / SGR_LOG2E, ky = (0.5f * (float)H) / SGR_LOG2E;
 
-    sgr_f2 acc01 = {0.f, 0.f}, acc2D = {0.f, 0.f}, last01 = {0.f, 0.f}, last2D = {0.f, 0.f};
-    const sgr_f2 dL01 = {dLdC0, dLdC1}, dL2D = {dLdC2, dLdD};
-    float accA = 0.f, last_alpha = 0.f;
+    float Arec = 0.f, u_last = 0.f, last_alpha = 0.f;
 
     int mx = lastc;
 #pragma unroll
@@ -748,16 +779,14 @@ sgr_blend_bwd_kernel_v2(SGR_BWD_ARGS) {
                 T = T * inv1ma;  // T = T / (1 - alpha)
                 wm = alpha * T;
                 const float one_m_la = 1.0f - last_alpha;
-                const sgr_f2 c01 = {cc.x, cc.y}, c2D = {cc.z, cc.w};
-                const sgr_f2 la2 = {last_alpha, last_alpha};
-                acc01 = __builtin_elementwise_fma(la2, last01, one_m_la * acc01);
-                acc2D = __builtin_elementwise_fma(la2, last2D, one_m_la * acc2D);
-                const sgr_f2 t = __builtin_elementwise_fma(c2D - acc2D, dL2D, (c01 - acc01) * dL01);
-                float d = t.x + t.y;
-                accA = fmaf(one_m_la, accA, last_alpha);
-                d = fmaf(1.0f - accA, dLdA, d);
-                last01 = c01;
-                last2D = c2D;
+                // the factored channel recurrence of the reduction kernel (see SGR_FACTORED above)
+                float u = fmaf(cc.x, dLdC0, dLdA);
+                u = fmaf(cc.y, dLdC1, u);
+                u = fmaf(cc.z, dLdC2, u);
+                u = fmaf(cc.w, dLdD, u);
+                Arec = fmaf(last_alpha, u_last, one_m_la * Arec);
+                float d = u - Arec;
+                u_last = u;
                 last_alpha = alpha;
                 d *= T;
                 const float dopa = fmaf(-T_final * inv1ma, bgdot, d);  // backward.cu:611-614

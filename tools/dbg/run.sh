@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python tools/dbg/prof_scene2.py 2>&1 | grep -v amdgpu.ids | tail -5
+timeout 1200 python -m pytest tests -q --tb=short -m gpu -x 2>&1 | grep -v amdgpu.ids | grep -v "^{" | grep -E "passed|failed|error|Error|assert" | tail -8
