@@ -147,7 +147,8 @@ int sgr_export_internal(int which, int P, int R, int width, int height, char* ge
 
 /* ---- A/B switches of the blend kernels (tests, tools/gpu_ab.sh): bit 0 no quadrant cull, bit 1 no DPP wave
  * reduction, bit 2 no deterministic LDS combine, bit 3 the backward ignores the forward's hit record and redoes the
- * geometric cull, bit 4 the S = 0 backward runs the transposed-accumulation kernel (A/B design, slower).
+ * geometric cull, bit 4 the S = 0 backward runs the transposed-accumulation kernel (A/B design, slower),
+ * bit 5 the radix sorts run in their one-sweep (decoupled look-back) form (A/B design, slower; SGR_ONESWEEP).
  * mask >= 0 sets them process-wide, mask < 0 only queries; returns the previous mask.  The initial
  * value comes from the environment (SGR_NO_CULL, SGR_NO_DPP, SGR_NO_DET, SGR_NO_HITS, SGR_V2), read once. */
 int sgr_test_switches(int mask);

@@ -325,7 +325,7 @@ def sh_grad_from_views(means3D, campos, drgb, degree, M):
     return out
 
 
-NO_CULL, NO_DPP, NO_DET, NO_HITS, USE_V2 = 1, 2, 4, 8, 16
+NO_CULL, NO_DPP, NO_DET, NO_HITS, USE_V2, USE_ONESWEEP = 1, 2, 4, 8, 16, 32
 
 
 def test_switches(mask: int = -1) -> int:

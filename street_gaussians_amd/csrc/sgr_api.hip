@@ -58,7 +58,8 @@ static bool env_flag(const char* name) {
 
 // A/B switches of the blend kernels (tests and tools/gpu_ab.sh): bit 0 no quadrant cull, 1 no DPP reduction,
 // 2 no deterministic LDS combine, 3 backward ignores the forward's hit record, 4 the S = 0 backward runs the
-// transposed-accumulation kernel (an A/B design that measured 10 % slower than the cross-lane reduction).  Process-wide, set through
+// transposed-accumulation kernel (an A/B design that measured slower than the cross-lane reduction), 5 the
+// radix sorts run in their one-sweep form (an A/B design that measured slower, sgr_scan_sort.hip; SGR_ONESWEEP).  Process-wide, set through
 // sgr_test_switches(); the environment (SGR_NO_CULL / SGR_NO_DPP / SGR_NO_DET / SGR_NO_HITS / SGR_V2) only provides the
 // initial value, read ONCE -- the per-step path is one relaxed atomic load, no getenv.
 static std::atomic<int> g_switches{-1};
@@ -452,8 +453,11 @@ int sgr_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, con
 }
 
 int sgr_test_switches(int mask) {
-    const int prev = switches();
-    if (mask >= 0) g_switches.store(mask & 31, std::memory_order_relaxed);
+    const int prev = switches() | (sgr_sort_get_one_sweep() ? 32 : 0);
+    if (mask >= 0) {
+        g_switches.store(mask & 31, std::memory_order_relaxed);
+        sgr_sort_set_one_sweep((mask >> 5) & 1);
+    }
     return prev;
 }
 
@@ -639,6 +643,12 @@ int sgr_test_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_t* v
     uint32_t* vals[2] = {vals0, vals1};
     const int cur = sgr_launch_sort_pairs(keys, vals, n, end_bit, hist, scan_tmp, stream);
     SGR_STAGE("sort");
+    if (sgr_sort_get_one_sweep() && n) {  // one-sweep form: a look-back that gave up leaves its mark in the control block
+        uint32_t e = 0;
+        SGR_HIP(hipMemcpyAsync(&e, hist + SGR_SORT_MAX_PASS * 256 + SGR_SORT_MAX_PASS, 4, hipMemcpyDeviceToHost, stream));
+        SGR_HIP(hipStreamSynchronize(stream));
+        if (e) return sgr_set_error(SGR_E_HIP, "radix sort: look-back gave up");
+    }
     return cur;
 }
 int sgr_test_sort32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, uint32_t n, int end_bit,
@@ -649,6 +659,12 @@ int sgr_test_sort32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t*
     uint32_t* vals[2] = {vals0, vals1};
     const int cur = sgr_launch_sort_pairs32(keys, vals, n, end_bit, hist, scan_tmp, stream);
     SGR_STAGE("sort32");
+    if (sgr_sort_get_one_sweep() && n) {  // one-sweep form: a look-back that gave up leaves its mark in the control block
+        uint32_t e = 0;
+        SGR_HIP(hipMemcpyAsync(&e, hist + SGR_SORT_MAX_PASS * 256 + SGR_SORT_MAX_PASS, 4, hipMemcpyDeviceToHost, stream));
+        SGR_HIP(hipStreamSynchronize(stream));
+        if (e) return sgr_set_error(SGR_E_HIP, "radix sort: look-back gave up");
+    }
     return cur;
 }
 size_t sgr_test_sort_hist_words(uint32_t n) { return sgr_sort_hist_words(n ? n : 1); }

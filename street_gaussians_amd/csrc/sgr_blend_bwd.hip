@@ -567,14 +567,21 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
         for (int chunk = 0; chunk < BATCH / 64; chunk++) {
             uint64_t m = sBits[wave][chunk];
             m = sgr_uniform_u64(m);
+            // scalar bookkeeping kept short (SALU issues once per four cycles per SIMD): s_ff1 + s_bitset0 per survivor, and
+            // the odd survivor is taken first so that the loop is pairs only
+            if (__builtin_popcountll(m) & 1) {
+                const int j0 = chunk * 64 + sgr_pop_lowest(m);
+                const float4 a0 = sA[j0], q0 = sB[j0];
+                const float dx0 = a0.x - pxf, dy0 = a0.y - pyf;
+                const float pw0 = sgr_power2(q0.x, q0.y, q0.z, dx0, dy0);
+                const float G0 = __builtin_amdgcn_exp2f(pw0);
+                process(j0, q0, dx0, dy0, pw0, G0, fminf(0.99f, q0.w * G0), true);
+            }
             while (m) {
                 // two survivors per trip: LDS reads and exp() of both are independent of each other; only the
                 // per-pixel recurrences (process) are ordered
-                const int j0 = chunk * 64 + (__ffsll((unsigned long long)m) - 1);
-                m &= m - 1;
-                const bool two = m != 0;
-                const int j1 = two ? chunk * 64 + (__ffsll((unsigned long long)m) - 1) : j0;
-                m &= m - 1;
+                const int j0 = chunk * 64 + sgr_pop_lowest(m);
+                const int j1 = chunk * 64 + sgr_pop_lowest(m);
                 const float4 a0 = sA[j0], q0 = sB[j0];
                 const float4 a1 = sA[j1], q1 = sB[j1];
                 const float dx0 = a0.x - pxf, dy0 = a0.y - pyf, dx1 = a1.x - pxf, dy1 = a1.y - pyf;
@@ -583,7 +590,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                 const float G0 = __builtin_amdgcn_exp2f(pw0), G1 = __builtin_amdgcn_exp2f(pw1);
                 const float al0 = fminf(0.99f, q0.w * G0), al1 = fminf(0.99f, q1.w * G1);
                 process(j0, q0, dx0, dy0, pw0, G0, al0, true);
-                process(j1, q1, dx1, dy1, pw1, G1, al1, two);
+                process(j1, q1, dx1, dy1, pw1, G1, al1, true);
             }
         }
         sgr_lds_barrier();

@@ -114,63 +114,68 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                 uint64_t m = sBits[wave][chunk];
                 m = sgr_uniform_u64(m);
                 uint64_t hb = 0;  // wave-uniform (scalar registers)
+                // One blend step (forward.cu:425-445) of list slot j = chunk * 64 + bit.  The walk's bookkeeping is scalar
+                // (SALU issues once per four cycles per SIMD, and this kernel issues about as many scalar as vector
+                // instructions): bits are taken with s_ff1 + s_bitset0, the hit record is one s_bitset1.
+                auto blend_one = [&](const int j, const int bit, const float power2, const float alpha) __attribute__((always_inline)) {
+                    // skip if power > 0 or alpha < 1/255 (or the pixel is finished: thr = inf)
+                    const bool k1 = !(power2 > 0.0f), k2 = !(alpha < thr);
+                    const uint64_t hm = __builtin_amdgcn_ballot_w64(k1) & __builtin_amdgcn_ballot_w64(k2);
+                    if (hm == 0) return;
+                    const float test_T = T * (1.0f - alpha);
+                    const bool k3 = test_T < 0.0001f;  // forward.cu:431-436
+                    const bool blend = k1 && k2 && !k3;
+                    const float4 c = sC[j];
+                    const float w = blend ? alpha * T : 0.0f;
+                    C0 = fmaf(c.x, w, C0);
+                    C1 = fmaf(c.y, w, C1);
+                    C2 = fmaf(c.z, w, C2);
+                    Dp = fmaf(c.w, w, Dp);
+                    Wt += w;
+                    if (SMAX > 0) {
+                        const float4* sj = reinterpret_cast<const float4*>(&sSem[j * SMAX]);
+#pragma unroll
+                        for (int c4 = 0; c4 < SMAX / 4; c4++) {
+                            const float4 sv = sj[c4];
+                            sem[4 * c4] = fmaf(sv.x, w, sem[4 * c4]);
+                            sem[4 * c4 + 1] = fmaf(sv.y, w, sem[4 * c4 + 1]);
+                            sem[4 * c4 + 2] = fmaf(sv.z, w, sem[4 * c4 + 2]);
+                            sem[4 * c4 + 3] = fmaf(sv.w, w, sem[4 * c4 + 3]);
+                        }
+                    }
+                    T = blend ? test_T : T;
+                    last = blend ? (pos0 + (uint32_t)j + 1u) : last;
+                    // Some lane passed the alpha test: the backward has to visit (quadrant, instance).  (A superset of
+                    // the visits that blend: if every passing lane finishes on this very instance nothing is blended, and
+                    // the backward's own per-pixel test -- list position < n_contrib -- skips it.)
+                    hb = sgr_bitset1(hb, bit);
+                    const uint64_t sm = hm & __builtin_amdgcn_ballot_w64(k3);
+                    if (sm != 0) {
+                        thr = (k1 && k2 && k3) ? __builtin_inff() : thr;
+                        done_mask |= sm;
+                        if (done_mask == ~0ull) { m = 0; stop = true; }
+                    }
+                };
+                if (__builtin_popcountll(m) & 1) {  // odd one out first, so that the loop below is pairs only
+                    const int b0 = sgr_pop_lowest(m);
+                    const int j0 = chunk * 64 + b0;
+                    const float4 a0 = sA[j0], q0 = sB[j0];
+                    const float pw0 = sgr_power2(q0.x, q0.y, q0.z, a0.x - pxf, a0.y - pyf);
+                    blend_one(j0, b0, pw0, fminf(0.99f, q0.w * __builtin_amdgcn_exp2f(pw0)));
+                }
                 while (m) {
                     // two survivors per trip: their LDS reads and exp() are independent, only the blend is ordered
-                    const int b0 = __ffsll((unsigned long long)m) - 1;
-                    const int j0 = chunk * 64 + b0;
-                    m &= m - 1;
-                    const bool two = m != 0;
-                    const int b1 = two ? (__ffsll((unsigned long long)m) - 1) : b0;
-                    const int j1 = chunk * 64 + b1;
-                    m &= m - 1;  // no-op when m == 0
+                    const int b0 = sgr_pop_lowest(m);
+                    const int b1 = sgr_pop_lowest(m);
+                    const int j0 = chunk * 64 + b0, j1 = chunk * 64 + b1;
                     const float4 a0 = sA[j0], q0 = sB[j0];
                     const float4 a1 = sA[j1], q1 = sB[j1];
                     const float pw0 = sgr_power2(q0.x, q0.y, q0.z, a0.x - pxf, a0.y - pyf);
                     const float pw1 = sgr_power2(q1.x, q1.y, q1.z, a1.x - pxf, a1.y - pyf);
                     const float al0 = fminf(0.99f, q0.w * __builtin_amdgcn_exp2f(pw0));
                     const float al1 = fminf(0.99f, q1.w * __builtin_amdgcn_exp2f(pw1));
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        const int j = u ? j1 : j0;
-                        const float power2 = u ? pw1 : pw0;
-                        const float alpha = u ? al1 : al0;
-                        // forward.cu:425-430: skip if power > 0 or alpha < 1/255 (or the pixel is finished: thr = inf)
-                        const bool k1 = !(power2 > 0.0f), k2 = !(alpha < thr);
-                        const uint64_t hm = __builtin_amdgcn_ballot_w64(k1) & __builtin_amdgcn_ballot_w64(k2);
-                        if ((u == 0 || two) && hm != 0) {
-                            const float test_T = T * (1.0f - alpha);
-                            const bool k3 = test_T < 0.0001f;  // forward.cu:431-436
-                            const bool blend = k1 && k2 && !k3;
-                            const float4 c = sC[j];
-                            const float w = blend ? alpha * T : 0.0f;
-                            C0 = fmaf(c.x, w, C0);
-                            C1 = fmaf(c.y, w, C1);
-                            C2 = fmaf(c.z, w, C2);
-                            Dp = fmaf(c.w, w, Dp);
-                            Wt += w;
-                            if (SMAX > 0) {
-                                const float4* sj = reinterpret_cast<const float4*>(&sSem[j * SMAX]);
-#pragma unroll
-                                for (int c4 = 0; c4 < SMAX / 4; c4++) {
-                                    const float4 sv = sj[c4];
-                                    sem[4 * c4] = fmaf(sv.x, w, sem[4 * c4]);
-                                    sem[4 * c4 + 1] = fmaf(sv.y, w, sem[4 * c4 + 1]);
-                                    sem[4 * c4 + 2] = fmaf(sv.z, w, sem[4 * c4 + 2]);
-                                    sem[4 * c4 + 3] = fmaf(sv.w, w, sem[4 * c4 + 3]);
-                                }
-                            }
-                            T = blend ? test_T : T;
-                            last = blend ? (pos0 + (uint32_t)j + 1u) : last;
-                            const uint64_t sm = hm & __builtin_amdgcn_ballot_w64(k3);
-                            // some lane blended this instance (scalar): the backward has to visit (quadrant, instance)
-                            hb |= (hm != sm) ? (1ull << (u ? b1 : b0)) : 0ull;
-                            if (sm != 0) {
-                                thr = (k1 && k2 && k3) ? __builtin_inff() : thr;
-                                done_mask |= sm;
-                                if (done_mask == ~0ull) { m = 0; stop = true; }
-                            }
-                        }
-                    }
+                    blend_one(j0, b0, pw0, al0);
+                    blend_one(j1, b1, pw1, al1);  // if the wave finished on j0 every lane's threshold is +inf: a no-op
                 }
                 if (lane == 0) sHit[wave][chunk] = hb;
             }

@@ -85,9 +85,12 @@ static inline void sgr_carve(char*& p, T*& out, size_t count) {
 #define SGR_SORT_MAX_PASS 8
 
 static inline size_t sgr_scan_tmp_count(size_t n) { return (n + SGR_SCAN_ITEMS - 1) / SGR_SCAN_ITEMS + 1; }
-// dwords of the radix sort's digit table: [256 digits][nblocks] + the 256 per-digit totals
+// dwords of the radix sort's work area (sgr_scan_sort.hip): the [256 digits][nblocks] table + 256 totals; sized for
+// the one-sweep A/B form, which needs more: a control block (digit counts of up to 8 passes, tickets, error flag) + a
+// look-back table of 256 64-bit words per block
+#define SGR_SORT_CTRL_WORDS (SGR_SORT_MAX_PASS * 256 + 64)
 static inline size_t sgr_sort_hist_words(size_t n) {
-    return (size_t)256 * ((n + SGR_SORT_ITEMS - 1) / SGR_SORT_ITEMS) + 256;
+    return (size_t)SGR_SORT_CTRL_WORDS + (size_t)512 * ((n + SGR_SORT_ITEMS - 1) / SGR_SORT_ITEMS);
 }
 
 // Carve the geometry buffer.  base may be (char*)256 to compute the required size: *end - base.
@@ -162,6 +165,8 @@ static inline size_t sgr_required(F carve) {
 void sgr_launch_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, bool inclusive, hipStream_t s,
                      uint32_t* total_out = nullptr, const uint32_t* gather = nullptr);
 // stable LSD radix sorts on key bits [0, end_bit); return the index (0/1) of the buffer pair holding the result
+int sgr_sort_get_one_sweep();
+void sgr_sort_set_one_sweep(int on);  // A/B: 1 = the one-sweep form instead of histogram + row scan + scatter per pass
 int sgr_launch_sort_pairs(uint64_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
                           uint32_t* scan_tmp, hipStream_t s);
 int sgr_launch_sort_pairs32(uint32_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
@@ -191,5 +196,16 @@ __device__ __forceinline__ uint64_t sgr_uniform_u64(uint64_t v) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
     return ((uint64_t)hi << 32) | (uint64_t)lo;
+}
+// Scalar bit bookkeeping for wave-uniform 64-bit masks (hipcc expands `m &= m - 1` into s_add_u32 / s_addc_u32 /
+// s_and_b64 and `hb |= 1ull << b` into s_lshl_b64 / s_or_b64; the walks of the blend kernels are SALU-heavy).
+__device__ __forceinline__ int sgr_pop_lowest(uint64_t& m) {  // m != 0: index of its lowest set bit, cleared in m
+    const int b = __builtin_ctzll(m);
+    asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(b));
+    return b;
+}
+__device__ __forceinline__ uint64_t sgr_bitset1(uint64_t m, int b) {
+    asm("s_bitset1_b64 %0, %1" : "+s"(m) : "s"(b));
+    return m;
 }
 #endif

@@ -4,13 +4,24 @@
 // to 64, simple-knn's Morton sort (simple_knn.cu:210-213).
 //
 // Scan: reduce-then-scan over 2048-element blocks; wave64 shuffles inside a block.
-// Sort: 8-bit digits.  Per pass, three launches: an LDS-privatised per-block digit histogram; a scan of
-// the [digit][block] table in which workgroup d scans row d and emits the row total (the scatter turns the
-// 256 totals into digit bases itself -- a generic device-wide scan would cost three launches here, and at
-// these sizes every launch is ~5 us of GPU time); and a scatter that ranks its 2048-key block with a wave64
-// ballot-match (8 ballots per key give the set of lanes sharing the digit; popcount of the lower
-// lanes is the stable rank) and per-wave LDS digit counters -- no atomics, fully deterministic.
+// Sort: 8-bit digits.  The scatter ranks its 2048-key block with a wave64 ballot-match (8 ballots per key give
+// the set of lanes sharing the digit; popcount of the lower lanes is the stable rank) and per-wave LDS digit
+// counters -- no atomics on data, fully deterministic.  Where a block's keys of one digit start in the output is the
+// digit's global base + the counts of all earlier blocks; two ways to get that:
+//   * three launches per pass (default): an LDS-privatised per-block digit histogram, a scan of the [digit][block]
+//     table in which workgroup d scans row d and emits the row total (the scatter turns the 256 totals into digit
+//     bases itself), and the scatter -- 3 * npass launches of ~5 us or more each;
+//   * one sweep (A/B, switch bit 5 / SGR_ONESWEEP=1): ONE histogram kernel per sort gives the global digit counts of
+//     every pass, and each pass is a single kernel in which the blocks publish their digit counts and look back over
+//     their predecessors' (decoupled look-back on a [block][digit] status table; block ids are handed out by an
+//     atomic ticket so that every predecessor is already running) -- npass + 1 launches.  Measured SLOWER on MI355X
+//     (tile sort of 7.8 M pairs 0.242 vs 0.138 ms, depth sort + scan of 1 M keys 0.161 vs 0.110 ms; 5 M Gaussians:
+//     1.09 vs 0.69 ms): 8 workgroups x 256 CUs publish at the same moment and the look-back walks device-scope words
+//     that live beyond the per-XCD L2s; the launches it removes are cheaper than that.  Kept for the A/B.
 #include "sgr_common.h"
+
+#include <atomic>
+#include <cstdlib>
 
 
 // ------------------------------------------------------------------------------------------------
@@ -161,11 +172,20 @@ sgr_sort_rowscan_kernel(uint32_t* __restrict__ hist, uint32_t nblocks, uint32_t*
 // order (digit-major, stable), then written out by consecutive threads -- every digit's keys of this block form one
 // contiguous run in global memory (8 keys on average at 256 digits, 32 at the 64 digits of the tile sort's second
 // pass), instead of 64 scattered 4-byte stores per wave instruction.
-template <typename K>
+// ONE (one-sweep form): `totals` = the pass's global digit counts, `status` = the [block][digit] look-back table,
+// `ticket` = the pass's block-id counter, `err` = set if a look-back gave up (never observed; it bounds the spin).
+// Status word: bits 0-47 count, bits 48-55 state (1 = this block's count, 2 = inclusive prefix up to this block),
+// bits 56-63 = pass + 1 (words of earlier passes read as empty, so the table is zeroed once per sort).
+#define SGR_OS_AGG (1ull << 48)
+#define SGR_OS_PREFIX (2ull << 48)
+#define SGR_OS_VALUE ((1ull << 48) - 1ull)
+template <typename K, bool ONE>
 __global__ void __launch_bounds__(256)
 sgr_sort_scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* __restrict__ kout,
                         uint32_t* __restrict__ vout, uint32_t n, int shift, uint32_t nblocks,
-                        const uint32_t* __restrict__ hist_scanned, const uint32_t* __restrict__ totals) {
+                        const uint32_t* __restrict__ hist_scanned, const uint32_t* __restrict__ totals,
+                        unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket, uint32_t* __restrict__ err,
+                        uint32_t pass_tag) {
     __shared__ uint32_t cnt[4][256];    // per wave: count of each digit, then its block-local start for that wave
     __shared__ uint32_t lstart[256];    // block-local start of each digit
     __shared__ uint32_t gbase[256];     // global position of the digit's first key of this block
@@ -173,11 +193,13 @@ sgr_sort_scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ 
     __shared__ K sK[SGR_SORT_ITEMS];
     __shared__ uint32_t sV[SGR_SORT_ITEMS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (ONE && tid == 0) lds4[0] = atomicAdd(ticket, 1u);  // block id in start order: every lower id is already running
 #pragma unroll
     for (int w = 0; w < 4; w++) cnt[w][tid] = 0;
     __syncthreads();
+    const uint32_t block = ONE ? lds4[0] : blockIdx.x;
 
-    const uint32_t base = blockIdx.x * SGR_SORT_ITEMS + wave * (64 * SGR_SORT_IPT);
+    const uint32_t base = block * SGR_SORT_ITEMS + wave * (64 * SGR_SORT_IPT);
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     K key[SGR_SORT_IPT];
     uint32_t val[SGR_SORT_IPT], rnk[SGR_SORT_IPT];
@@ -212,7 +234,34 @@ sgr_sort_scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ 
         const uint32_t c0 = cnt[0][tid], c1 = cnt[1][tid], c2 = cnt[2][tid], c3 = cnt[3][tid];
         uint32_t all;
         // digit base over the whole array (contains a barrier), then the block-local digit starts (another scan)
-        const uint32_t g = hist_scanned[(size_t)tid * nblocks + blockIdx.x] + sgr_block_excl_scan256(totals[tid], lds4, all);
+        uint32_t before;  // keys of digit `tid` in the blocks before this one
+        if (ONE) {
+            const unsigned long long tag = (unsigned long long)pass_tag << 56;
+            const uint32_t c = c0 + c1 + c2 + c3;
+            unsigned long long* mine = status + (size_t)block * 256 + tid;
+            __hip_atomic_store(mine, tag | (block == 0 ? SGR_OS_PREFIX : SGR_OS_AGG) | c, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long sum = 0;
+            uint32_t spins = 0;
+            for (uint32_t pb = block; pb > 0;) {
+                const unsigned long long w = __hip_atomic_load(status + (size_t)(pb - 1) * 256 + tid, __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT);
+                if ((w >> 56) != pass_tag) {  // not published yet
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 22)) { atomicOr(err, 1u); break; }
+                    continue;
+                }
+                sum += w & SGR_OS_VALUE;
+                if (w & SGR_OS_PREFIX) break;
+                pb--;
+            }
+            if (block > 0)
+                __hip_atomic_store(mine, tag | SGR_OS_PREFIX | (sum + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            before = (uint32_t)sum;
+        } else {
+            before = hist_scanned[(size_t)tid * nblocks + block];
+        }
+        const uint32_t g = before + sgr_block_excl_scan256(totals[tid], lds4, all);
         const uint32_t ls = sgr_block_excl_scan256(c0 + c1 + c2 + c3, lds4, all);
         gbase[tid] = g;
         lstart[tid] = ls;
@@ -233,7 +282,7 @@ sgr_sort_scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ 
         }
     }
     __syncthreads();
-    const uint32_t first = blockIdx.x * SGR_SORT_ITEMS;
+    const uint32_t first = block * SGR_SORT_ITEMS;
     const uint32_t nloc = min((uint32_t)SGR_SORT_ITEMS, n - first);
 #pragma unroll
     for (int s = 0; s < SGR_SORT_IPT; s++) {
@@ -248,10 +297,51 @@ sgr_sort_scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ 
     }
 }
 
+// One-sweep prologue: the global digit counts of every pass in one read of the keys (LDS-privatised, one atomic per
+// non-empty (pass, digit) per workgroup), and the look-back table zeroed.  Workgroups stride over 4096-key chunks.
+template <typename K>
+__global__ void __launch_bounds__(256)
+sgr_sort_hist_all_kernel(const K* __restrict__ keys, uint32_t n, int npass, uint32_t* __restrict__ ghist,
+                         unsigned long long* __restrict__ status, size_t status_words) {
+    __shared__ uint32_t h[SGR_SORT_MAX_PASS][256];
+    for (int p = 0; p < npass; p++) h[p][threadIdx.x] = 0;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < status_words; i += (size_t)gridDim.x * 256) status[i] = 0ull;
+    for (uint32_t chunk = blockIdx.x; (size_t)chunk * 4096 < n; chunk += gridDim.x) {
+#pragma unroll 4
+        for (int s = 0; s < 16; s++) {
+            const uint32_t i = chunk * 4096u + s * 256 + threadIdx.x;
+            if (i < n) {
+                const K k = keys[i];
+                for (int p = 0; p < npass; p++) atomicAdd(&h[p][(uint32_t)(k >> (8 * p)) & 255u], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int p = 0; p < npass; p++) {
+        const uint32_t c = h[p][threadIdx.x];
+        if (c) atomicAdd(&ghist[p * 256 + threadIdx.x], c);
+    }
+}
+
+// 0 = three launches per pass (default), 1 = one sweep; set through sgr_test_switches bit 5 / SGR_ONESWEEP
+static std::atomic<int> g_sort_one_sweep{-1};
+void sgr_sort_set_one_sweep(int on) { g_sort_one_sweep.store(on ? 1 : 0, std::memory_order_relaxed); }
+int sgr_sort_get_one_sweep() {
+    int v = g_sort_one_sweep.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("SGR_ONESWEEP");
+        v = (e && *e && *e != '0') ? 1 : 0;
+        g_sort_one_sweep.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
 // Sorts n pairs on key bits [0, end_bit).  keys[0]/vals[0] hold the input; returns the index (0/1)
-// of the pair of buffers that holds the sorted output.  hist: sgr_sort_hist_words(n) dwords (scan_tmp is unused).
-// The per-block digit histogram depends on where the previous pass left the keys, so it is
-// recomputed before every scatter pass.
+// of the pair of buffers that holds the sorted output.  hist: sgr_sort_hist_words(n) dwords (scan_tmp is unused):
+// three launches -- the [digit][block] table + 256 totals, recomputed before every scatter pass (the per-block digit
+// histogram depends on where the previous pass left the keys);
+// one sweep -- [control: 8 x 256 digit counts, 8 tickets, error flag | status table, 256 x 64 bit per block].
 template <typename K>
 static int sort_pairs_impl(K* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
                            uint32_t* scan_tmp, hipStream_t s) {
@@ -259,12 +349,29 @@ static int sort_pairs_impl(K* const keys[2], uint32_t* const vals[2], uint32_t n
     const int npass = (end_bit + 7) / 8;
     const uint32_t nblocks = (n + SGR_SORT_ITEMS - 1) / SGR_SORT_ITEMS;
     int cur = 0;
+    if (sgr_sort_get_one_sweep() && npass <= SGR_SORT_MAX_PASS) {
+        uint32_t* ghist = hist;
+        uint32_t* tickets = hist + SGR_SORT_MAX_PASS * 256;
+        uint32_t* err = tickets + SGR_SORT_MAX_PASS;
+        unsigned long long* status = reinterpret_cast<unsigned long long*>(hist + SGR_SORT_CTRL_WORDS);
+        (void)hipMemsetAsync(hist, 0, SGR_SORT_CTRL_WORDS * sizeof(uint32_t), s);
+        const uint32_t chunks = (n + 4095u) / 4096u;
+        sgr_sort_hist_all_kernel<K><<<chunks < 1024u ? chunks : 1024u, 256, 0, s>>>(keys[0], n, npass, ghist, status,
+                                                                                   (size_t)nblocks * 256);
+        for (int p = 0; p < npass; p++) {
+            sgr_sort_scatter_kernel<K, true><<<nblocks, 256, 0, s>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n,
+                                                                     8 * p, nblocks, nullptr, ghist + p * 256, status,
+                                                                     tickets + p, err, (uint32_t)p + 1u);
+            cur ^= 1;
+        }
+        return cur;
+    }
     for (int p = 0; p < npass; p++) {
         sgr_sort_hist_kernel<K><<<nblocks, 256, 0, s>>>(keys[cur], n, 8 * p, nblocks, hist);
         uint32_t* totals = hist + (size_t)256 * nblocks;
         sgr_sort_rowscan_kernel<<<256, 256, 0, s>>>(hist, nblocks, totals);
-        sgr_sort_scatter_kernel<K><<<nblocks, 256, 0, s>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, 8 * p,
-                                                           nblocks, hist, totals);
+        sgr_sort_scatter_kernel<K, false><<<nblocks, 256, 0, s>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n,
+                                                                  8 * p, nblocks, hist, totals, nullptr, nullptr, nullptr, 0u);
         cur ^= 1;
     }
     return cur;

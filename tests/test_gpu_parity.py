@@ -173,6 +173,12 @@ def test_culling_is_invisible_and_backward_is_deterministic(name):
     g_b2 = raw_backward(kw, res_b, wts)  # hit record written by the un-culled forward
     for k in g_a:
         assert torch.equal(g_a[k], g_b2[k]), f"hit record of the un-culled forward changed dL/d{k}"
+    with switches(_C.USE_ONESWEEP):  # the radix sorts in their one-sweep A/B form: the same order, bit for bit
+        res_s, int_s = raw_forward(kw)
+        for k in ["keys", "point_list", "ranges", "point_offsets"]:
+            assert torch.equal(int_a(k), int_s(k)), f"sort form changed {k}"
+        for k in ["color", "depth", "alpha", "semantic"]:
+            assert torch.equal(res_a[k], res_s[k]), f"sort form changed {k}"
     if name in ILL_CONDITIONED:
         return  # the comparisons below are rounding-level statements; they do not apply to cancelling quadratic forms
     with switches(_C.NO_DPP):

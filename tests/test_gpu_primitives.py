@@ -42,8 +42,10 @@ def test_scan(n, inclusive):
 @pytest.mark.parametrize("n,end_bit,dup", [(1, 46, False), (100, 46, True), (2048, 46, True), (2049, 40, False),
                                            (70001, 46, True), (3_000_000, 46, False), (1_000_003, 32, True),
                                            (500_000, 41, True)])
-def test_sort_pairs_stable(n, end_bit, dup):
+@pytest.mark.parametrize("one_sweep", [False, True])
+def test_sort_pairs_stable(n, end_bit, dup, one_sweep, sort_mode):
     L, check = _lib()
+    sort_mode(one_sweep)
     rng = np.random.default_rng(n)
     hi = 1 << end_bit
     if dup:  # few distinct keys -> stability is exercised
@@ -54,7 +56,8 @@ def test_sort_pairs_stable(n, end_bit, dup):
     k0 = torch.from_numpy(keys.view(np.int64)).cuda()
     v0 = torch.from_numpy(vals.view(np.int32)).cuda()
     k1, v1 = torch.zeros_like(k0), torch.zeros_like(v0)
-    hist = torch.zeros(L.sgr_test_sort_hist_words(n), dtype=torch.int32, device="cuda")
+    # the work area arrives dirty (torch.empty in production): here, with everything a stale run could have left
+    hist = torch.full((L.sgr_test_sort_hist_words(n),), -1, dtype=torch.int32, device="cuda")
     tmp = torch.zeros(L.sgr_test_scan_tmp_words(hist.numel()), dtype=torch.int32, device="cuda")
     cur = check(L.sgr_test_sort(_vp(k0), _vp(k1), _vp(v0), _vp(v1), n, end_bit, _vp(hist), _vp(tmp), None))
     torch.cuda.synchronize()
@@ -65,9 +68,12 @@ def test_sort_pairs_stable(n, end_bit, dup):
     assert (vs == vals[order]).all()
 
 
-@pytest.mark.parametrize("n,end_bit,dup", [(1, 14, False), (4097, 14, True), (2_500_000, 14, True), (1_000_000, 32, False)])
-def test_sort_pairs32_stable(n, end_bit, dup):
+@pytest.mark.parametrize("n,end_bit,dup", [(1, 14, False), (4097, 14, True), (2_500_000, 14, True), (1_000_000, 32, False),
+                                           (20_000_003, 15, False)])
+@pytest.mark.parametrize("one_sweep", [False, True])
+def test_sort_pairs32_stable(n, end_bit, dup, one_sweep, sort_mode):
     L, check = _lib()
+    sort_mode(one_sweep)
     rng = np.random.default_rng(n + 1)
     hi = 1 << end_bit
     keys = (rng.integers(0, 61, n, dtype=np.uint64) * (hi // 64) if dup else rng.integers(0, hi, n, dtype=np.uint64)).astype(np.uint32)
@@ -77,6 +83,10 @@ def test_sort_pairs32_stable(n, end_bit, dup):
     k1, v1 = torch.zeros_like(k0), torch.zeros_like(v0)
     hist = torch.zeros(L.sgr_test_sort_hist_words(n), dtype=torch.int32, device="cuda")
     tmp = torch.zeros(L.sgr_test_scan_tmp_words(hist.numel()), dtype=torch.int32, device="cuda")
+    if n > 1:  # a first sort of other data leaves its look-back table behind: the second must not read it as its own
+        kk = torch.from_numpy(np.roll(keys, 1).view(np.int32)).cuda()
+        check(L.sgr_test_sort32(_vp(kk), _vp(torch.zeros_like(kk)), _vp(v0.clone()), _vp(torch.zeros_like(v0)), n, end_bit,
+                                _vp(hist), _vp(tmp), None))
     cur = check(L.sgr_test_sort32(_vp(k0), _vp(k1), _vp(v0), _vp(v1), n, end_bit, _vp(hist), _vp(tmp), None))
     torch.cuda.synchronize()
     ks = (k1 if cur else k0).cpu().numpy().view(np.uint32)
@@ -84,6 +94,18 @@ def test_sort_pairs32_stable(n, end_bit, dup):
     order = np.argsort(keys, kind="stable")
     assert (ks == keys[order]).all()
     assert (vs == vals[order]).all()
+
+
+@pytest.fixture
+def sort_mode():
+    """Selects the radix sort's form (three launches per pass / the one-sweep A/B form) for one test."""
+    from street_gaussians_amd import _C
+    prev = _C.test_switches()
+
+    def set_mode(one_sweep):
+        _C.test_switches((prev & ~_C.USE_ONESWEEP) | (_C.USE_ONESWEEP if one_sweep else 0))
+    yield set_mode
+    _C.test_switches(prev)
 
 
 def test_wave_sum_dpp_equals_shuffle():
