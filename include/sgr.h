@@ -135,6 +135,10 @@ int sgr_profile_read(double* sum_ms, int* counts);
 /* which stages are recorded (bit i = stage i; default all): a timed region that only needs the dominant kernel records
  * two events per step instead of eighteen.  stage_mask < 0 only queries; returns the previous mask. */
 int sgr_profile_select(int stage_mask);
+/* Records only every k-th occurrence of each selected stage (k >= 1; default 1): an event pair drains the queue
+ * around the bracketed launch (~10 us each side), which a throughput measurement should not pay every step.
+ * Returns the previous k; k < 1 only queries. */
+int sgr_profile_sample(int every);
 
 /* ---- introspection for parity tests: copies one internal array, densely packed, to dst (device). -------------
  * which: 0 depths f32[P] | 1 clamped u8[3P] | 2 means2D f32[2P] | 3 cov3D f32[6P] | 4 conic_opacity f32[4P]

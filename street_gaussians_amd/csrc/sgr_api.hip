@@ -85,6 +85,8 @@ struct SgrProf {
     std::atomic<bool> on{false};
     std::atomic<int> mask{(1 << SGR_PROF_STAGES) - 1};  // stages that are recorded (sgr_profile_select)
     std::atomic<int> n{0};  // claimed (begin, end) slots
+    std::atomic<int> every{1};  // record every k-th occurrence of a stage (sgr_profile_sample)
+    std::atomic<unsigned> seen[SGR_PROF_STAGES];
     hipEvent_t ev[SGR_PROF_SLOTS][2];
     int stage[SGR_PROF_SLOTS];
     bool created = false;
@@ -95,6 +97,8 @@ static void prof_begin(int stage, hipStream_t s) {
     t_prof_slot = -1;
     if (!g_prof.on.load(std::memory_order_relaxed)) return;
     if (!((g_prof.mask.load(std::memory_order_relaxed) >> stage) & 1)) return;
+    const int every = g_prof.every.load(std::memory_order_relaxed);
+    if (every > 1 && g_prof.seen[stage].fetch_add(1u, std::memory_order_relaxed) % (unsigned)every != 0) return;
     const int i = g_prof.n.fetch_add(1, std::memory_order_relaxed);
     if (i >= SGR_PROF_SLOTS) return;
     g_prof.stage[i] = stage;
@@ -476,6 +480,17 @@ int sgr_profile_enable(int on) {
     g_prof.n.store(0);
     g_prof.on.store(on != 0);
     return 0;
+}
+
+// An event pair costs ~10 us of GPU idle time each side of the bracketed launch (the queue drains at the marker), so
+// a timed region that wants its throughput undisturbed records only every k-th occurrence of a stage.
+int sgr_profile_sample(int every) {
+    const int prev = g_prof.every.load();
+    if (every >= 1) {
+        g_prof.every.store(every);
+        for (int i = 0; i < SGR_PROF_STAGES; i++) g_prof.seen[i].store(0u);
+    }
+    return prev;
 }
 
 int sgr_profile_select(int stage_mask) {

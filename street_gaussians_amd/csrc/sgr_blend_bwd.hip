@@ -305,7 +305,6 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
     __shared__ float4 sB[BATCH];  // {qa, qb, qc, opacity}
     __shared__ float4 sC[BATCH];  // {r, g, b, depth}
     __shared__ uint32_t sU[BATCH];
-    __shared__ uint32_t sFlag[BATCH];
     __shared__ uint64_t sBits[4][4];
     __shared__ int sMax[4];
     // The (up to four) wave partials of an instance meet in LDS with ds_add_f32.  DET: two zero-initialised
@@ -394,7 +393,6 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
         const bool stager = tid < BATCH;  // whole waves: the batch is a multiple of 64
         const int pos = stager ? hi - tid : -1;
         uint32_t mask4 = 0;
-        if (stager) sFlag[tid] = 0;
 #pragma unroll
         for (int row = tid; row < NROW * BATCH; row += SGR_TILE_THREADS) {
             float4* z = reinterpret_cast<float4*>(&sAcc[row * ACCW]);
@@ -459,6 +457,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                     const float one_m_la = 1.0f - last_alpha;
                     float d;
                     if (SGR_FACTORED) {
+                        Arec = fmaf(last_alpha, u_last, one_m_la * Arec);  // before u: u can then be formed in u_last's register
                         float u = fmaf(c.x, dLdC0, dLdA);
                         u = fmaf(c.y, dLdC1, u);
                         u = fmaf(c.z, dLdC2, u);
@@ -474,7 +473,6 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                                 u = fmaf(s4.w, dLdS[4 * c4 + 3], u);
                             }
                         }
-                        Arec = fmaf(last_alpha, u_last, one_m_la * Arec);
                         d = u - Arec;
                         u_last = u;
                     } else {
@@ -518,7 +516,14 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                 // 17 instead of 26 instructions per visit, same sums up to rounding.
                 const float gx = Gd * dx, gy = Gd * dy;
                 // dG/ddelx / G = (2*qa*dx + qb*dy)/log2e  (qa = -0.5*log2e*A, qb = -log2e*B; 1/log2e is in kx, ky)
-                const float ax = fmaf(q.x + q.x, dx, q.y * dy), ay = fmaf(q.z + q.z, dy, q.y * dx);
+                // built on the two products sgr_power2 already formed (qa*dx + qb*dy and qc*dy: common subexpressions)
+                float ax, ay;
+                {
+#pragma clang fp contract(off)
+                    const float e1 = fmaf(q.y, dy, q.x * dx), e2 = q.z * dy;
+                    ax = fmaf(q.x, dx, e1);
+                    ay = fmaf(q.y, dx, e2 + e2);
+                }
                 v[0] = gx;
                 v[1] = gy;
                 v[2] = fabsf(Gd) * fmaf(fabsf(ax), kx, fabsf(ay) * ky);
@@ -542,7 +547,6 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
 #pragma unroll
                     for (int i = 0; i < NG; i++)
                         if (fold_leader && 4 * i + fold_t0 < NVAL / 4) atomicAdd(&dst[16 * i], g[i]);
-                    if (lane == 0) sFlag[j] = 1u;
                     return;
                 } else if (DPP) {
                     sgr_wave_reduce_scatter<NVAL>(v, r);
@@ -561,7 +565,6 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                     (void)k;
 #pragma unroll
                     for (int t = 0; t < NVAL / 4; t++) atomicAdd(&dst[4 * t], r[t]);
-                    if (k == 0) sFlag[j] = 1u;
                 }
         };
         for (int chunk = 0; chunk < BATCH / 64; chunk++) {
@@ -594,9 +597,11 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
             }
         }
         sgr_lds_barrier();
-        // one row per touched (tile, instance): plain stores, written exactly once
-        const uint32_t flags = stager ? sFlag[tid] : 0u;
-        if (flags) {
+        // One row per (tile, instance) some quadrant was asked to visit: plain stores, written exactly once.  With the
+        // forward's hit record that is the set of instances that blended into the tile (plus the rare one whose every
+        // passing pixel finished on it: a row of zeros); flagging rows per visit instead cost an LDS store + exec
+        // juggling in the walk.
+        if (mask4 != 0) {
             const uint32_t u = sU[tid];
             touched[u] = 1;  // the per-Gaussian reduction only reads rows that were written (no 64 B/instance memset)
             float4* row = reinterpret_cast<float4*>(partials + (size_t)u * row_stride);
