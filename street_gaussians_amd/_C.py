@@ -128,7 +128,8 @@ def rasterize_gaussians(background, means3D, colors, semantics, opacity, scales,
         out_depth = torch.empty((1, H, W), **fopt)
         out_alpha = torch.empty((1, H, W), **fopt)
         out_semantic = torch.empty((S, H, W), **fopt)
-        radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+        # the preprocess kernel writes every element (0 for culled Gaussians): no zero fill (rasterize_points.cu:74)
+        radii = (torch.empty if P else torch.zeros)((P,), dtype=torch.int32, device=dev)
         geom, binning, img = _Grow(dev), _Grow(dev), _Grow(dev)
         keep = []
         def p(t, n):

@@ -57,7 +57,9 @@ rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3
     auto bo = means3D.options().dtype(torch::kByte);
     torch::Tensor out_color = torch::empty({3, H, W}, fo), out_depth = torch::empty({1, H, W}, fo);
     torch::Tensor out_alpha = torch::empty({1, H, W}, fo), out_semantic = torch::empty({S, H, W}, fo);
-    torch::Tensor radii = torch::zeros({P}, means3D.options().dtype(torch::kInt32));
+    // the preprocess kernel writes every element (0 for culled Gaussians): no zero fill (rasterize_points.cu:74)
+    torch::Tensor radii = P ? torch::empty({P}, means3D.options().dtype(torch::kInt32))
+                            : torch::zeros({P}, means3D.options().dtype(torch::kInt32));
     torch::Tensor geom = torch::empty({0}, bo), binning = torch::empty({0}, bo), img = torch::empty({0}, bo);
     int M = 0;
     if (sh.defined() && sh.numel() != 0 && sh.size(0) != 0) M = sh.size(1);

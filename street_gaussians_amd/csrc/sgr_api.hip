@@ -161,13 +161,19 @@ static uint32_t getHigherMsb(uint32_t n) {
     return msb;
 }
 
-// The camera arrives as three device arrays; a one-wave kernel packs it (plus the host-side scalars)
-// into a device-resident SgrCam so no device->host copy is needed.
-__global__ void sgr_pack_camera_kernel(SgrCam* cam, const float* view, const float* proj, const float* campos,
-                                       float tan_fovx, float tan_fovy, float focal_x, float focal_y, int W, int H,
-                                       int gx, int gy, float scale_modifier) {
+// The camera arrives as three device arrays; a small kernel packs it (plus the host-side scalars) into a
+// device-resident SgrCam so no device->host copy is needed.  The same launch clears what the forward needs cleared before
+// its first real kernel -- the 16 header words (flags, num_rendered) and the T tile ranges (rasterizer_impl.cu:313) --
+// which were two memset dispatches of ~5 us each.
+__global__ void __launch_bounds__(256)
+sgr_pack_camera_kernel(SgrCam* cam, const float* view, const float* proj, const float* campos, float tan_fovx,
+                       float tan_fovy, float focal_x, float focal_y, int W, int H, int gx, int gy, float scale_modifier,
+                       uint32_t* header, uint2* ranges, int T) {
     const int t = threadIdx.x;
+    for (int i = blockIdx.x * 256 + t; i < T; i += gridDim.x * 256) ranges[i] = make_uint2(0u, 0u);
+    if (blockIdx.x != 0) return;
     if (t < 16) {
+        header[t] = 0u;
         cam->view[t] = view[t];
         cam->proj[t] = proj ? proj[t] : 0.f;
     }
@@ -185,12 +191,14 @@ static SgrCam* cam_slot(const SgrGeomView& gv) { return reinterpret_cast<SgrCam*
 static_assert(sizeof(SgrCam) <= 48 * 4, "SgrCam must fit the geometry header");
 
 static void pack_camera(const SgrGeomView& gv, const float* view, const float* proj, const float* campos,
-                        float tan_fovx, float tan_fovy, int W, int H, float scale_modifier, hipStream_t s) {
+                        float tan_fovx, float tan_fovy, int W, int H, float scale_modifier, uint2* ranges, int T,
+                        hipStream_t s) {
     const float focal_y = H / (2.0f * tan_fovy);  // rasterizer_impl.cu:225-226
     const float focal_x = W / (2.0f * tan_fovx);
     const int gx = (W + SGR_BLOCK_X - 1) / SGR_BLOCK_X, gy = (H + SGR_BLOCK_Y - 1) / SGR_BLOCK_Y;
-    sgr_pack_camera_kernel<<<1, 64, 0, s>>>(cam_slot(gv), view, proj, campos, tan_fovx, tan_fovy, focal_x, focal_y, W, H,
-                                            gx, gy, scale_modifier);
+    const int nb = std::max(1, std::min(64, (T + 255) / 256));
+    sgr_pack_camera_kernel<<<nb, 256, 0, s>>>(cam_slot(gv), view, proj, campos, tan_fovx, tan_fovy, focal_x, focal_y, W, H,
+                                             gx, gy, scale_modifier, gv.header, ranges, T);
 }
 
 extern "C" {
@@ -252,9 +260,7 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     int* radii_ptr = radii ? radii : gv.internal_radii;  // rasterizer_impl.cu:232-235
 
     prof_begin(0, stream);
-    SGR_HIP(hipMemsetAsync(gv.header, 0, 16 * sizeof(uint32_t), stream));
-    SGR_HIP(hipMemsetAsync(iv.ranges, 0, T * sizeof(uint2), stream));  // rasterizer_impl.cu:313
-    pack_camera(gv, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, W, H, scale_modifier, stream);
+    pack_camera(gv, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, W, H, scale_modifier, iv.ranges, (int)T, stream);
     SGR_STAGE("pack_camera");
 
     sgr_launch_preprocess(P, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,

@@ -59,6 +59,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer, alpha, semantics)
         ctx.mark_non_differentiable(radii)
+        # autograd would otherwise hand the backward a zero-filled gradient for EVERY output it has none for, radii
+        # included (a P-element fill kernel per step); the backward below fills in only the ones it reads
+        ctx.set_materialize_grads(False)
         return color, radii, depth, alpha, semantic
 
     @staticmethod
@@ -67,6 +70,15 @@ class _RasterizeGaussians(torch.autograd.Function):
         raster_settings = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer,
          alpha, semantics) = ctx.saved_tensors
+        if grad_color is None:
+            grad_color = torch.zeros((3,) + alpha.shape[1:], dtype=alpha.dtype, device=alpha.device)
+        if grad_depth is None:
+            grad_depth = torch.zeros_like(alpha)
+        if grad_alpha is None:
+            grad_alpha = torch.zeros_like(alpha)
+        if grad_semantic is None:
+            ns = semantics.shape[1] if semantics is not None and semantics.dim() == 2 else 0
+            grad_semantic = torch.zeros((ns,) + alpha.shape[1:], dtype=alpha.dtype, device=alpha.device)
         args = (raster_settings.bg, means3D, radii, colors_precomp, scales, rotations, raster_settings.scale_modifier,
                 cov3Ds_precomp, raster_settings.viewmatrix, raster_settings.projmatrix, raster_settings.tanfovx,
                 raster_settings.tanfovy, grad_color, grad_depth, grad_alpha, grad_semantic, sh,

@@ -375,6 +375,22 @@ def test_autograd_api_and_error_behaviour():
     grad_close(npy(t["scales"].grad), ref["scales"], name="scales")
     grad_close(npy(t["rotations"].grad), ref["rotations"], name="rotations")
     grad_close(npy(t["semantics"].grad), ref["semantics"], name="semantics")
+    # a loss on the colour image alone (train.py's usual case): the outputs without a gradient count as zero, exactly
+    # as if zeros had been passed for them
+    def only_color(explicit_zeros):
+        for p_ in list(t.values()) + [m2d]:
+            p_.grad = None
+        c_, _, d_, a_, s_ = rast(t["means3D"], m2d, t["opacities"], shs=t["shs"], scales=t["scales"],
+                                 rotations=t["rotations"], semantics=t["semantics"])
+        if explicit_zeros:
+            torch.autograd.backward([c_, d_, a_, s_], [dev(wts["color"]), torch.zeros_like(d_), torch.zeros_like(a_),
+                                                       torch.zeros_like(s_)])
+        else:
+            (c_ * dev(wts["color"])).sum().backward()
+        return {k: v.grad.clone() for k, v in t.items()}
+    ga, gb = only_color(False), only_color(True)
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k
     # eval mode: means2D=None, no semantics (street_gaussian_renderer.py:170-173)
     with torch.no_grad():
         out = rast(t["means3D"], None, t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
