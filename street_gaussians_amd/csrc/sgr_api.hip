@@ -24,7 +24,7 @@ void sgr_launch_filter(int P, const float* means3D, const float* scales, const f
 void sgr_launch_gather_tiles(int P, const uint32_t* order, const uint32_t* tiles_touched, uint32_t* tt_sorted, hipStream_t s);
 void sgr_launch_duplicate(int P, const SgrGeomView& gv, const uint32_t* order, const uint32_t* offs_incl, uint32_t* keys,
                           uint32_t* vals, int gx, hipStream_t s);
-void sgr_launch_tile_ranges(int L, const uint32_t* keys, uint2* ranges, hipStream_t s);
+void sgr_launch_tile_ranges(int L, const uint32_t* keys, uint2* ranges, uint8_t* touched, hipStream_t s);
 void sgr_launch_compose_keys(int L, const uint32_t* tile_keys, const uint32_t* point_list, const float4* rec, uint64_t* out,
                              hipStream_t s);
 void sgr_launch_blend_fwd(bool cull, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W, int H,
@@ -327,7 +327,7 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
         SGR_STAGE("sort");
         prof_end(stream);
         prof_begin(4, stream);
-        sgr_launch_tile_ranges(R, bv.keys[cur], iv.ranges, stream);
+        sgr_launch_tile_ranges(R, bv.keys[cur], iv.ranges, bv.touched, stream);
         SGR_STAGE("tile_ranges");
         prof_end(stream);
     }
@@ -403,19 +403,25 @@ int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, 
     const SgrImgView iv = sgr_img_carve(image_buffer, N, T);
     const int* radii_ptr = radii ? radii : gv.internal_radii;
     const int stride = sgr_partial_row_stride(S);
-    // scratch = [P float4: conic + depth terms between the two per-Gaussian stages][R partial rows][R flag bytes]
+    // scratch = [P float4: conic + depth terms between the two per-Gaussian stages][R partial rows]
     const size_t cd_bytes = sgr_align_up((size_t)P * sizeof(float4), 256);
     const size_t bytes = sgr_align_up((size_t)R * stride * sizeof(float), 256);
-    char* sbase = scratch(cd_bytes + bytes + (size_t)R, scratch_user);
+    char* sbase = scratch(cd_bytes + bytes, scratch_user);
     if (!sbase) return fail(SGR_E_ALLOC, "backward scratch allocation failed");
     float4* cd = reinterpret_cast<float4*>(sbase);
     float* partials = reinterpret_cast<float*>(sbase + cd_bytes);
-    uint8_t* touched = reinterpret_cast<uint8_t*>(sbase + cd_bytes + bytes);  // one byte per (tile, instance) row
+    // One byte per (tile, instance) row: "written by this backward".  It lives in the binning buffer and arrives zeroed
+    // by the forward's tile-ranges launch; the rows a backward writes are a function of the forward's hit record alone,
+    // so repeated backwards over one forward re-mark the same bytes.  The A/B switches that change the visited set
+    // (no cull / no hit record) clear it explicitly, before and after.
+    uint8_t* touched = nullptr;
     if (R > 0) {
         const SgrBinView bv = sgr_bin_carve(binning_buffer, (size_t)R);
+        touched = bv.touched;
         const int cur = sorted_index(W, H);
+        const bool odd_set = (switches() & (1 | 8)) != 0;
         prof_begin(6, stream);
-        SGR_HIP(hipMemsetAsync(touched, 0, (size_t)R, stream));  // rows themselves are never cleared
+        if (odd_set) SGR_HIP(hipMemsetAsync(touched, 0, (size_t)R, stream));
         prof_end(stream);
         prof_begin(7, stream);
         const int sw = switches();
@@ -435,6 +441,7 @@ int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, 
                          dL_drot, dL_dsemantic, sink, stream);
     SGR_STAGE("gauss_bwd");
     prof_end(stream);
+    if (touched && (switches() & (1 | 8)) != 0) SGR_HIP(hipMemsetAsync(touched, 0, (size_t)R, stream));
     return 0;
 }
 

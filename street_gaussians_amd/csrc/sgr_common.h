@@ -54,6 +54,7 @@ struct SgrBinView {
     uint32_t* scan_tmp;
     uint32_t* header;    // [0]=index (0/1) of the buffer pair holding the sorted result
     uint8_t* hit4;       // per sorted instance: bit q = the forward blended it into >= 1 pixel of quadrant q of its tile
+    uint8_t* touched;    // per partial-gradient row: written by the backward (cleared by the forward's tile-ranges launch)
 };
 
 // optional sink of the backward for this view's densification statistics (sgr_backward_ex); all three or none
@@ -136,6 +137,7 @@ static inline SgrBinView sgr_bin_carve(char* base, size_t R, char** end = nullpt
     sgr_carve(p, v.hist, nh);
     sgr_carve(p, v.scan_tmp, sgr_scan_tmp_count(nh));
     sgr_carve(p, v.hit4, Rn);
+    sgr_carve(p, v.touched, Rn);
     if (end) *end = p;
     return v;
 }

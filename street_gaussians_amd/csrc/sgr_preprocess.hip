@@ -258,9 +258,12 @@ sgr_duplicate_kernel(int P, SgrGeomView gv, const uint32_t* __restrict__ order, 
 
 // ---- K9: tile ranges from the sorted tile keys (rasterizer_impl.cu:116-138) -------------------
 __global__ void __launch_bounds__(256)
-sgr_tile_ranges_kernel(int L, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges) {
+sgr_tile_ranges_kernel(int L, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges, uint8_t* __restrict__ touched) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= L) return;
+    // one byte per partial-gradient row of the backward ("row written"), cleared here instead of by a memset dispatch
+    // in front of the backward's dominant kernel (the index spaces coincide: one row per instance)
+    touched[idx] = 0;
     const uint32_t currtile = keys[idx];
     if (idx == 0) {
         ranges[currtile].x = 0;
@@ -323,9 +326,9 @@ void sgr_launch_duplicate(int P, const SgrGeomView& gv, const uint32_t* order, c
                                                                                              vals, gx);
 }
 
-void sgr_launch_tile_ranges(int L, const uint32_t* keys, uint2* ranges, hipStream_t s) {
+void sgr_launch_tile_ranges(int L, const uint32_t* keys, uint2* ranges, uint8_t* touched, hipStream_t s) {
     if (L <= 0) return;
-    sgr_tile_ranges_kernel<<<(L + 255) / 256, 256, 0, s>>>(L, keys, ranges);
+    sgr_tile_ranges_kernel<<<(L + 255) / 256, 256, 0, s>>>(L, keys, ranges, touched);
 }
 
 void sgr_launch_compose_keys(int L, const uint32_t* tile_keys, const uint32_t* point_list, const float4* rec, uint64_t* out,
