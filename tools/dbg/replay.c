@@ -9,7 +9,7 @@
 // out[6]=sum over waves (no batching) of max over 4x4 blocks, out[7]=# (tile,batch) rounds,
 // out[8]=sum over (tile,batch) of max over 16 blocks (whole-WG lockstep), out[9]=sum 8x4 half visits
 void replay(int W, int H, const uint32_t* ranges, const uint32_t* plist, const float* m2d, const float* co,
-            const uint32_t* ncontrib, int batch, double* out) {
+            const uint32_t* ncontrib, int batch, double* out, float* tile_cost) {
   int gx = (W + 15) / 16, gy = (H + 15) / 16;
   double acc[16] = {0};
 #pragma omp parallel
@@ -26,9 +26,9 @@ void replay(int W, int H, const uint32_t* ranges, const uint32_t* plist, const f
         nc[p] = (px < W && py < H) ? ncontrib[py * W + px] : 0;
         if (nc[p] > maxc) maxc = nc[p];
       }
-      int tot44[4][4] = {{0}};
+      int tot44[4][4] = {{0}}; double tcost = 0;
       for (uint32_t b0 = 0; b0 < maxc; b0 += batch) {
-        int c44[4][4] = {{0}}, c82[4][4] = {{0}}, c84[4][2] = {{0}};
+        int c44[4][4] = {{0}}, c82[4][4] = {{0}}, c84[4][2] = {{0}}; int cq[4] = {0,0,0,0};
         a[7] += 1;
         for (uint32_t pos = b0; pos < b0 + batch && pos < maxc; ++pos) {
           uint32_t g = plist[r0 + pos];
@@ -50,21 +50,22 @@ void replay(int W, int H, const uint32_t* ranges, const uint32_t* plist, const f
           }
           a[4] += lanes;
           for (int q = 0; q < 4; ++q) {
-            if (hq >> q & 1) a[0] += 1;
+            if (hq >> q & 1) { a[0] += 1; cq[q]++; }
             for (int k = 0; k < 4; ++k) { c44[q][k] += h44 >> (q * 4 + k) & 1; c82[q][k] += h82 >> (q * 4 + k) & 1; }
             for (int k = 0; k < 2; ++k) c84[q][k] += h84 >> (q * 2 + k) & 1;
           }
         }
-        int m16 = 0;
+        int m16 = 0, mq = 0; { int cq[4]={0,0,0,0}; (void)cq; }
         for (int q = 0; q < 4; ++q) {
           int m = 0, m2 = 0, m3 = 0;
           for (int k = 0; k < 4; ++k) { if (c44[q][k] > m) m = c44[q][k]; if (c82[q][k] > m2) m2 = c82[q][k]; a[5] += c44[q][k]; tot44[q][k] += c44[q][k]; }
           for (int k = 0; k < 2; ++k) { if (c84[q][k] > m3) m3 = c84[q][k]; a[9] += c84[q][k]; }
           a[1] += m; a[2] += m2; a[3] += m3; if (m > m16) m16 = m;
         }
-        a[8] += m16;
+        a[8] += m16; for (int q = 0; q < 4; ++q) if (cq[q] > mq) mq = cq[q]; tcost += mq + 6;
       }
       for (int q = 0; q < 4; ++q) { int m = 0; for (int k = 0; k < 4; ++k) if (tot44[q][k] > m) m = tot44[q][k]; a[6] += m; }
+      tile_cost[t] = (float)tcost;
     }
 #pragma omp critical
     for (int i = 0; i < 16; ++i) acc[i] += a[i];

@@ -1,0 +1,71 @@
+import sys, os, ctypes as C, time, heapq
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+import numpy as np, torch
+from helpers import oracle_kwargs
+from oracle import oracle
+from street_gaussians_amd import synthetic as syn
+cam = syn.make_camera(1920, 1280, fx=2050.0)
+sc = syn.make_scene(1_000_000, cam, S=0, seed=0)
+fw = oracle.forward(**oracle_kwargs(cam, sc))
+L = C.CDLL("/tmp/replay.so")
+p = lambda a: a.ctypes.data_as(C.c_void_p)
+gx, gy = 120, 80
+out = np.zeros(16); cost = np.zeros(gx * gy, np.float32)
+arrs = [np.ascontiguousarray(x) for x in (fw.ranges.astype(np.uint32), fw.point_list.astype(np.uint32), fw.means2D.astype(np.float32), fw.conic_opacity.astype(np.float32), fw.n_contrib.astype(np.uint32))]
+L.replay(1920, 1280, *[p(a) for a in arrs], 128, p(out), p(cost))
+print("tile cost: mean", cost.mean(), "max", cost.max(), "min", cost.min(), "p10", np.percentile(cost, 10), "p90", np.percentile(cost, 90))
+ST = 8
+sgx = (gx + ST - 1) // ST; sgy = (gy + ST - 1) // ST
+nst = sgx * sgy
+nblocks = ((nst + 7) // 8) * 8 * ST * ST
+def tile_of(b):
+    x, q = b & 7, b >> 3
+    st, within = (q // 64) * 8 + x, q % 64
+    tx, ty = (st % sgx) * ST + within % ST, (st // sgx) * ST + within // ST
+    return ty * gx + tx if tx < gx and ty < gy else -1
+def simulate(order_per_xcd, slots_per_cu=8, cus=32):
+    """processor sharing per CU: each CU has unit capacity shared by its resident WGs; a new WG goes to the CU with a free slot (fewest resident)."""
+    worst = 0.0
+    for tasks in order_per_xcd:
+        tasks = [c for c in tasks]
+        # event simulation
+        res = [[] for _ in range(cus)]  # remaining work of resident WGs per CU
+        t = 0.0; i = 0
+        # initial fill round robin
+        while i < len(tasks) and any(len(r) < slots_per_cu for r in res):
+            k = min(range(cus), key=lambda c: len(res[c])); res[k].append(tasks[i]); i += 1
+        while any(res):
+            # next completion: per CU, the WG with least remaining finishes after rem * n
+            best = None
+            for c in range(cus):
+                if res[c]:
+                    m = min(res[c]); dt = m * len(res[c])
+                    if best is None or dt < best[0]: best = (dt, c)
+            dt, cfin = best
+            for c in range(cus):
+                if res[c]:
+                    dec = dt / len(res[c])
+                    res[c] = [r - dec for r in res[c]]
+            t += dt
+            for c in range(cus):
+                done = [r for r in res[c] if r <= 1e-9]
+                if done:
+                    res[c] = [r for r in res[c] if r > 1e-9]
+                    for _ in done:
+                        if i < len(tasks):
+                            res[c].append(tasks[i]); i += 1
+        worst = max(worst, t)
+    return worst
+cur = [[] for _ in range(8)]
+for b in range(nblocks):
+    tl = tile_of(b)
+    cur[b & 7].append(float(cost[tl]) if tl >= 0 else 0.0)
+ideal = cost.sum() / 256
+print("ideal (perfect balance over 256 CUs):", ideal)
+print("current order makespan:", simulate(cur))
+lpt = [sorted(x, reverse=True) for x in cur]
+print("LPT within XCD:", simulate(lpt))
+allc = sorted([float(c) for c in cost], reverse=True)
+lptg = [allc[x::8] for x in range(8)]
+print("global LPT dealt over XCDs:", simulate(lptg))
