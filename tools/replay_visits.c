@@ -1,4 +1,5 @@
-// scratch: visit statistics of the blend walk under different wave decompositions (CPU replay on the oracle's lists)
+// Visit statistics of the blend walk under different wave decompositions: a CPU replay of the oracle's per-tile lists
+// (driven by tools/sim_tile_order.py; measurement tooling, not part of the product).
 #include <math.h>
 #include <stdint.h>
 #include <string.h>

@@ -1,19 +1,35 @@
-import sys, os, ctypes as C, time, heapq
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests"))
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+#!/usr/bin/env python
+"""CPU-side study of the blend walks on the benchmark scene (no GPU): replays the oracle's per-tile lists
+(tools/replay_visits.c, built into /tmp on the fly), prints the visit statistics quoted in DESIGN.md sections 3 and 10
+-- (quadrant, instance) visits, lanes hitting, what 4x4 / 8x2 / 8x4 sub-wave units would need -- and simulates how the
+9600 tiles of a launch fill 8 XCDs x 32 CUs x 8 workgroup slots (processor sharing per CU) in the shipped supertile order
+and longest-first.  Uses oracle/ as the source of the lists: a measurement tool, not part of the product.
+
+    python tools/sim_tile_order.py [gaussians]
+"""
+import subprocess
+import sys, os, ctypes as C, time
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "tests"))
+sys.path.insert(0, os.path.join(HERE, ".."))
 import numpy as np, torch
 from helpers import oracle_kwargs
 from oracle import oracle
 from street_gaussians_amd import synthetic as syn
 cam = syn.make_camera(1920, 1280, fx=2050.0)
-sc = syn.make_scene(1_000_000, cam, S=0, seed=0)
+sc = syn.make_scene(int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000, cam, S=0, seed=0)
 fw = oracle.forward(**oracle_kwargs(cam, sc))
-L = C.CDLL("/tmp/replay.so")
+subprocess.check_call(["gcc", "-O2", "-fopenmp", "-shared", "-fPIC", os.path.join(HERE, "replay_visits.c"), "-o",
+                       "/tmp/replay_visits.so", "-lm"])
+L = C.CDLL("/tmp/replay_visits.so")
 p = lambda a: a.ctypes.data_as(C.c_void_p)
 gx, gy = 120, 80
 out = np.zeros(16); cost = np.zeros(gx * gy, np.float32)
 arrs = [np.ascontiguousarray(x) for x in (fw.ranges.astype(np.uint32), fw.point_list.astype(np.uint32), fw.means2D.astype(np.float32), fw.conic_opacity.astype(np.float32), fw.n_contrib.astype(np.uint32))]
 L.replay(1920, 1280, *[p(a) for a in arrs], 128, p(out), p(cost))
+names = ["quadrant_visits", "max4_4x4_per_batch", "max4_8x2_per_batch", "max2_8x4_per_batch", "lane_hits", "sum_4x4_visits",
+         "max4_4x4_nobatch", "rounds", "max16_per_batch", "sum_8x4_visits"]
+print({n: float(out[i]) for i, n in enumerate(names)})
 print("tile cost: mean", cost.mean(), "max", cost.max(), "min", cost.min(), "p10", np.percentile(cost, 10), "p90", np.percentile(cost, 90))
 ST = 8
 sgx = (gx + ST - 1) // ST; sgy = (gy + ST - 1) // ST
