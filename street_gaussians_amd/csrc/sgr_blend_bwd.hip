@@ -300,7 +300,10 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
 #pragma clang fp contract(off)
     constexpr int NS = SMAX > 0 ? SMAX : 1;
     constexpr int NVAL = (SGR_ROW_BASE + SMAX + 3) / 4 * 4;  // values per row, padded to float4s
-    constexpr int ACCW = NVAL;                                 // LDS row stride (16-B aligned rows)
+    // LDS row stride: 16-B aligned rows, and an ODD number of float4s so that the float4 reads / writes of 16 consecutive
+    // rows (flush, zero fill) spread over all 64 banks -- at 16 / 24 / 32 floats per row (4, 12, 20 channels) they fell
+    // on 4-8 banks (SQ_LDS_BANK_CONFLICT: 102 M cycles per launch at 20 channels, none at S = 0)
+    constexpr int ACCW = NVAL + (((NVAL / 4) & 1) ? 0 : 4);
     __shared__ float4 sA[BATCH];  // {x, y, -, -}
     __shared__ float4 sB[BATCH];  // {qa, qb, qc, opacity}
     __shared__ float4 sC[BATCH];  // {r, g, b, depth}
