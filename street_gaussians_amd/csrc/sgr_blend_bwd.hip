@@ -17,6 +17,8 @@
 // [3..5] dL/dconic (x, y, w), [6] dL/dopacity, [7..9] dL/drgb, [10] dL/ddepth, [11..11+S) dL/dsemantic.
 #include "sgr_math.h"
 
+#include <type_traits>
+
 #define SGR_TILE_THREADS 256
 typedef float sgr_f2 __attribute__((ext_vector_type(2)));
 // list entries staged in LDS per round.  128 (not 256) keeps the S = 0 workgroup at 20 KB of LDS so that occupancy is
@@ -29,6 +31,14 @@ typedef float sgr_f2 __attribute__((ext_vector_type(2)));
 #endif
 #ifndef SGR_BWD_BATCH_WIDE
 #define SGR_BWD_BATCH_WIDE 64
+#endif
+// Waves per SIMD the channel-carrying instantiations are compiled for (register cap = 512 / waves).  The wide kernels
+// live on occupancy: uncapped, 12 / 16 / 20 / 24 channels take 101 / 111 / 120 / 128 VGPRs (4-5 waves); capped at 96
+// (80 for 12 and 16 channels, no spills; 13 spilled dwords at 20) they measured 1.67 -> 1.41, 1.88 -> 1.65 (1 M
+// Gaussians) and 2.14 -> 1.99 ms (2 M + 19 channels); 6 waves at 20 channels spills into the walk (2.07 ms).  1-8
+// channels are LDS-limited at 128-entry rounds (64-entry rounds measured 5 % slower there).
+#ifndef SGR_BWD_WAVES
+#define SGR_BWD_WAVES(SMAX) ((SMAX) >= 12 && (SMAX) <= 16 ? 6 : ((SMAX) >= 20 && (SMAX) <= 24 ? 5 : 1))
 #endif
 template <int SMAX>
 struct SgrBwdBatch { static constexpr int value = SMAX <= 8 ? SGR_BWD_BATCH : SGR_BWD_BATCH_WIDE; };
@@ -509,7 +519,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                     d *= T;
                     Gd = G * fmaf(-T_final * inv1ma, bgdot, d);  // backward.cu:611-614
                 }
-                if (SMAX > 0) {
+                if (SMAX > 0 && !(DPP && SGR_FOLD)) {
 #pragma unroll
                     for (int ch = 0; ch < SMAX; ch++) v[SGR_ROW_BASE + ch] = wm * dLdS[ch];
                 }
@@ -543,13 +553,28 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                 // them in rows 0..3 of register t; the flush below swaps the middle pair back.
                 float r[NVAL / 4];
                 if (DPP && SGR_FOLD) {
-                    constexpr int NG = (NVAL / 4 + 3) / 4;
-                    float g[NG];
-                    sgr_wave_reduce_fold<NVAL>(v, g);
+                    // 16 values at a time (one result register, one ds_add_f32 each): the same instructions as one
+                    // pass over all NVAL values, but the channel products w * dL/dsemantic are formed chunk by chunk,
+                    // so a wide instantiation keeps 16 + 8 instead of NVAL + NVAL/2 reduction registers live
                     float* dst = sAcc + (acc_fold_off + j * ACCW);  // j is wave-uniform: scalar multiply
+                    auto fold_chunk = [&](auto C0, auto CN) __attribute__((always_inline)) {
+                        constexpr int c0 = decltype(C0)::value, cn = decltype(CN)::value;
+                        float vv[cn], g[1];
 #pragma unroll
-                    for (int i = 0; i < NG; i++)
-                        if (fold_leader && 4 * i + fold_t0 < NVAL / 4) atomicAdd(&dst[16 * i], g[i]);
+                        for (int k = 0; k < cn; k++) {
+                            const int idx = c0 + k;
+                            vv[k] = idx < SGR_ROW_BASE ? v[idx < NVAL ? idx : 0]
+                                                       : (idx - SGR_ROW_BASE < SMAX ? wm * dLdS[(idx - SGR_ROW_BASE) % NS] : 0.0f);
+                        }
+                        sgr_wave_reduce_fold<cn>(vv, g);
+                        if (fold_leader && fold_t0 < cn / 4) atomicAdd(&dst[c0], g[0]);
+                    };
+                    fold_chunk(std::integral_constant<int, 0>{}, std::integral_constant<int, (NVAL < 16 ? NVAL : 16)>{});
+                    if constexpr (NVAL > 16)
+                        fold_chunk(std::integral_constant<int, 16>{}, std::integral_constant<int, (NVAL - 16 < 16 ? NVAL - 16 : 16)>{});
+                    if constexpr (NVAL > 32)
+                        fold_chunk(std::integral_constant<int, 32>{}, std::integral_constant<int, (NVAL - 32 < 16 ? NVAL - 32 : 16)>{});
+                    static_assert(NVAL <= 48, "add a fold chunk");
                     return;
                 } else if (DPP) {
                     sgr_wave_reduce_scatter<NVAL>(v, r);
@@ -653,7 +678,8 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
     ranges, point_list, W, H, S, gx, gy, bg_color, rec, semantics, alphas, n_contrib, hit4, dL_dpixels,               \
         dL_dpixel_depths, dL_dalphas, dL_dpixel_semantics, partials, row_stride, touched
 template <int SMAX, bool CULL, bool DPP, bool DET>
-__global__ void __launch_bounds__(SGR_TILE_THREADS) sgr_blend_bwd_kernel(SGR_BWD_ARGS) {
+__global__ void __launch_bounds__(SGR_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(SGR_BWD_WAVES(SMAX))))
+sgr_blend_bwd_kernel(SGR_BWD_ARGS) {
     sgr_blend_bwd_body<SMAX, CULL, DPP, DET, SgrBwdBatch<SMAX>::value>(SGR_BWD_PASS);
 }
 // S = 0 (the training configuration of the benchmark): 64 VGPRs fit without spilling, so ask for 8 waves / SIMD
