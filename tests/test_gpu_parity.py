@@ -296,6 +296,67 @@ def test_random_scenes_against_oracle(seed):
     fw.free()
 
 
+@pytest.mark.parametrize("S", [5, 11, 14, 16, 18])
+def test_every_channel_width_against_oracle(S):
+    """One case per kernel instantiation the reference's channel limit allows (SMAX = 8, 12, 16, 20; 4 and 20 are in
+    CASES): they are compiled with different register caps, round sizes and reduction chunking."""
+    cam = syn.make_camera(224, 160, fx=250.0)
+    sc = syn.make_scene(3000, cam, S=S, seed=40 + S, scale_px=0.01)
+    kw = oracle_kwargs(cam, sc, deg=2)
+    wts = syn.loss_weights(cam, S=S, seed=S)
+    fw = oracle.forward(**kw)
+    res, internal = raw_forward(kw)
+    assert res["R"] == fw.num_rendered
+    image_close(npy(res["semantic"]), fw.semantic, name="semantic")
+    image_close(npy(res["color"]), fw.color, name="color")
+    g = raw_backward(kw, res, wts)
+    same = oracle_backward_same_state(oracle, fw, res, wts, S)
+    for k in GRAD_KEYS:
+        grad_close(npy(g[k]).reshape(same[k].shape), same[k], name=f"same-state S{S}:{k}", **SAME_STATE_GATE)
+    g2 = raw_backward(kw, res, wts)
+    for k in g:
+        assert torch.equal(g[k], g2[k]), f"S={S}: {k} not deterministic"
+    fw.free()
+
+
+@pytest.mark.parametrize("S", [24, 32])
+def test_widest_instantiations_agree_with_the_narrower_ones(S):
+    """More than 20 channels is beyond the reference (NUM_CLASSES = 20, config.h:16) and so beyond the oracle; the API
+    allows up to 32.  Channels are independent of each other in the forward, and in the backward they meet only in a
+    sum: a run with S channels must reproduce, bit for bit, the run with its first S/2 channels -- semantic image,
+    and every gradient when the upstream gradient of the other half is zero."""
+    cam = syn.make_camera(200, 144, fx=230.0)
+    sc = syn.make_scene(2500, cam, S=S, seed=70 + S, scale_px=0.012)
+    h = S // 2
+    kw = oracle_kwargs(cam, sc, deg=1)
+    kw_h = dict(kw, semantics=kw["semantics"][:, :h].contiguous())
+    wts = syn.loss_weights(cam, S=S, seed=S)
+    wts["semantic"] = wts["semantic"].clone()
+    wts["semantic"][h:] = 0
+    wts_h = dict(wts, semantic=wts["semantic"][:h].contiguous())
+    res, _ = raw_forward(kw)
+    res_h, _ = raw_forward(kw_h)
+    assert torch.equal(res["semantic"][:h], res_h["semantic"])
+    for k in ["color", "depth", "alpha"]:
+        assert torch.equal(res[k], res_h[k]), k
+    g, g_h = raw_backward(kw, res, wts), raw_backward(kw_h, res_h, wts_h)
+    for k in GRAD_KEYS:
+        if k == "semantics":
+            assert torch.equal(g[k][:, :h], g_h[k]), "semantics (first half)"
+        else:
+            assert torch.equal(g[k], g_h[k]), k
+    # the second half of the channel gradients: the same statement with the halves swapped
+    wts2 = dict(wts, semantic=syn.loss_weights(cam, S=S, seed=S)["semantic"].clone())
+    wts2["semantic"][:h] = 0
+    kw_t = dict(kw, semantics=kw["semantics"][:, h:].contiguous())
+    res_t, _ = raw_forward(kw_t)
+    assert torch.equal(res["semantic"][h:], res_t["semantic"])
+    g2 = raw_backward(kw, res, wts2)
+    g_t = raw_backward(kw_t, res_t, dict(wts2, semantic=wts2["semantic"][h:].contiguous()))
+    assert torch.equal(g2["semantics"][:, h:], g_t["semantics"])
+    assert torch.equal(g2["means3D"], g_t["means3D"])
+
+
 def test_precomputed_colors_and_cov3D():
     cam, sc, _ = CASES["mid_20k_sem3"]
     g = torch.Generator().manual_seed(5)
