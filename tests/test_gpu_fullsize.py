@@ -1,6 +1,6 @@
 """`-m gpu` parity at BASELINE.json's single-GPU sizes: the HIP path against the C oracle on the same seeded
-inputs -- configs[1] (500 k Gaussians), the headline configuration (1 M) and configs[2] (2 M + 19 semantic
-channels), all 1920x1280, SH degree 3, forward + backward.
+inputs -- configs[1] (500 k Gaussians), the headline configuration (1 M), configs[2] (2 M + 19 semantic
+channels) and configs[4]'s rasterizer load (5 M), all 1920x1280, SH degree 3, forward + backward.
 
 Integer outputs must be bit-exact.  Images and the nine gradient tensors are held to the north-star gate,
 |a-b| <= 1e-4 * max(|a|, |b|) + floor, and every measured figure (max error, elements outside the gate, threshold
@@ -99,7 +99,7 @@ def _save(name, rec):
 
 
 @pytest.mark.parametrize("name,P,S", [("configs1_500k", 500_000, 0), ("headline_1M", 1_000_000, 0),
-                                      ("configs2_2M_S19", 2_000_000, 19)])
+                                      ("configs2_2M_S19", 2_000_000, 19), ("configs4_5M", 5_000_000, 0)])
 def test_baseline_size_matches_oracle(name, P, S):
     cam = syn.make_camera(1920, 1280, fx=2050.0)
     sc = syn.make_scene(P, cam, S=S, seed=0)
