@@ -45,6 +45,8 @@ if ROOT not in sys.path:
 from street_gaussians_amd import synthetic as syn  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+# "partials_memset": since the row flags are cleared inside the forward's tile-ranges launch this bracket is empty on
+# the shipped path (it reads the event pair's own ~5 us); only the no-cull / no-hit-record A/B switches still clear there
 STAGES = ["preprocess", "scan", "duplicate", "sort", "tile_ranges", "blend_fwd", "partials_memset", "blend_bwd",
           "gauss_bwd"]
 
