@@ -31,7 +31,7 @@ names = ["quadrant_visits", "max4_4x4_per_batch", "max4_8x2_per_batch", "max2_8x
          "max4_4x4_nobatch", "rounds", "max16_per_batch", "sum_8x4_visits"]
 print({n: float(out[i]) for i, n in enumerate(names)})
 print("tile cost: mean", cost.mean(), "max", cost.max(), "min", cost.min(), "p10", np.percentile(cost, 10), "p90", np.percentile(cost, 90))
-ST = 8
+ST = int(os.environ.get("SGR_SIM_ST", "8"))
 sgx = (gx + ST - 1) // ST; sgy = (gy + ST - 1) // ST
 nst = sgx * sgy
 nblocks = ((nst + 7) // 8) * 8 * ST * ST
