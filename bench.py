@@ -66,9 +66,12 @@ def parse():
                     help="N > 1 exchange: factored = all-reduce of the dense parameter gradients + all-gather of per-view "
                          "dRGB with a local rebuild of dL/dSH (60 B/Gaussian on the wire); bucket = one flat all-reduce "
                          "of everything (236 B/Gaussian)")
-    ap.add_argument("--exchange", choices=["overlap", "blocking"], default="overlap",
-                    help="N > 1: overlap = the exchange runs on a side stream under the NEXT step's forward (training: the "
-                         "optimiser sees gradients one step late; no staleness with > 1 view per rank); blocking = inside the step")
+    ap.add_argument("--exchange", choices=["overlap", "blocking"], default="blocking",
+                    help="N > 1: blocking (default, the reported value) = the exchange completes inside the step, i.e. the "
+                         "optimiser sees this step's summed gradients (north_star's semantics); overlap = the exchange runs on "
+                         "a side stream under the NEXT step's forward (gradients one step late).  With the default the overlap "
+                         "schedule is measured as an extra region and printed under `exchange_overlap`")
+    ap.add_argument("--densify-every", type=int, default=10, help="configs[4] loop: one densify_and_prune every k iterations")
     ap.add_argument("--step-times", action="store_true", help="debug: also print 10 individually synchronised steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the 500k / 2M+S19 / 5M runs (N = 1 only)")
@@ -219,20 +222,13 @@ class Workload:
             def bucket():
                 return multiview.GradReducer(list(params.values()), force=force_dist)
             if args.reduce == "factored":
-                try:
-                    dense = [v for k, v in params.items() if k != "shs"]
-                    self.reducer = multiview.FactoredGradReducer(dense, params["shs"], params["means3D"], force=force_dist)
-                    self.reducer.warm_up()  # RCCL's lazy communicator / channel set-up is not part of a training step
-                except Exception as ex:  # measurement harness only: fall back to the plain bucket and say so
-                    print(f"[bench] factored exchange unavailable ({type(ex).__name__}: {ex}); using --reduce bucket",
-                          file=sys.stderr)
-                    if self.reducer is not None:
-                        self.reducer.close()
-                    args.reduce = "bucket"
-                    self.reducer = None
-            if self.reducer is None:
+                # no silent downgrade: a broken factored exchange must fail the run (a SCALE line quoted on the 236
+                # B/Gaussian bucket while the config says "factored" would be a wrong number)
+                dense = [v for k, v in params.items() if k != "shs"]
+                self.reducer = multiview.FactoredGradReducer(dense, params["shs"], params["means3D"], force=force_dist)
+            else:
                 self.reducer = bucket()
-                self.reducer.warm_up()
+            self.reducer.warm_up()  # RCCL's lazy communicator / channel set-up is not part of a training step
 
     def step(self):
         p, w, S = self.params, self.w, self.S
@@ -283,7 +279,125 @@ class Workload:
                                          st.image_width, p["shs"].detach(), 3, st.campos, False, False)
         R = int(out[0])
         n_contrib = native.export_internal("n_contrib", self.P, R, self.args.height, self.args.width, out[6], out[7], out[8])
+        self.V_in = int(native.mark_visible(p["means3D"].detach(), st.viewmatrix, st.projmatrix).sum().item())
         return R, V, int(n_contrib.to(torch.int64).sum().item())
+
+
+class DensifyLoop:
+    """BASELINE.json configs[4] as written: 5 M Gaussians, 1920x1280, SH degree 3, with the densify / prune step ACTIVE
+    between iterations, so that P, R and the three scratch buffers change under load ("one synthetic densify
+    step (clone 5 % + split 5 %, prune 5 %) between iterations so buffers are re-sized").
+
+    The loop is the reference's (train.py:187-210): every iteration the rasterizer forward + backward, with
+    `set_max_radii2D` + `add_densification_stats` applied by the backward's fused statistics sink
+    (GaussianRasterizer.stats_sink = scene.FlatStats.sink(), street_gaussian_model.py:551-571); every
+    `densify_every`-th iteration `densify_and_prune` (gaussian_model.py:522-553) through
+    street_gaussians_amd.densify.densify_and_prune on the RAW parameters and their Adam moments, after which the
+    activations are re-applied (exp / sigmoid / normalize, gaussian_model.py:224-251), the statistics are re-created
+    as zeros (:545-547) and the next forward runs on the changed P.  Thresholds (max_grad, percent_dense * extent,
+    min_opacity) are quantiles of the statistics of an untimed calibration interval, chosen for ~5 % clones, ~5 % splits
+    and ~5 % pruned per step.  reset_opacity (train.py:207-208) is exercised by tests/test_gpu_densify_loop.py, not here:
+    it makes every splat transparent, i.e. it would replace the stress workload by a trivial one."""
+
+    def __init__(self, args, P, dev, densify_every):
+        from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+        self.args, self.dev, self.every = args, dev, max(1, densify_every)
+        W, H = args.width, args.height
+        cam = self.cam = syn.make_camera(W, H, fx=2050.0 * W / 1920.0)
+        sc = syn.make_scene(P, cam, sh_degree_max=3, S=0, seed=0)
+        d = lambda t: t.to(dev).contiguous()
+        op = sc.opacities.clamp(1e-6, 1 - 1e-6)
+        # raw parameters as the reference's GaussianModel stores them (gaussian_model.py:120-127)
+        self.params = {"xyz": d(sc.means3D), "f_dc": d(sc.shs[:, :1, :]), "f_rest": d(sc.shs[:, 1:, :]),
+                       "opacity": d(torch.log(op / (1 - op))), "scaling": d(torch.log(sc.scales)), "rotation": d(sc.rotations)}
+        self.states = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in self.params.items()}
+        self.w = {k: v.to(dev) for k, v in syn.loss_weights(cam, S=0, seed=1).items()}
+        self.st = GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=torch.zeros(3, device=dev),
+            scale_modifier=1.0, viewmatrix=cam.viewmatrix.to(dev), projmatrix=cam.projmatrix.to(dev), sh_degree=3,
+            campos=cam.campos.to(dev), prefiltered=False, debug=False)
+        self.rast = GaussianRasterizer(self.st)
+        self.kw = None
+        self.log = []
+        self.max_R = 0
+        self._activate()
+
+    def _activate(self):
+        from street_gaussians_amd import scene
+        p = self.params
+        self.P = p["xyz"].shape[0]
+        self.inputs = {"means3D": p["xyz"], "scales": torch.exp(p["scaling"]),
+                       "rotations": torch.nn.functional.normalize(p["rotation"]), "opacities": torch.sigmoid(p["opacity"]),
+                       "shs": torch.cat([p["f_dc"], p["f_rest"]], 1).contiguous()}
+        for t in self.inputs.values():
+            t.requires_grad_(True)
+        self.means2D = torch.zeros(self.P, 3, device=self.dev, requires_grad=True)
+        self.stats = scene.FlatStats([self.P], self.dev)
+        self.rast.stats_sink = self.stats.sink()
+
+    def step(self):
+        from street_gaussians_amd import rasterizer
+        i, w = self.inputs, self.w
+        for t in list(i.values()) + [self.means2D]:
+            t.grad = None
+        color, radii, depth, alpha, _ = self.rast(i["means3D"], self.means2D, i["opacities"], shs=i["shs"],
+                                                  scales=i["scales"], rotations=i["rotations"])
+        torch.autograd.backward([color, depth, alpha], [w["color"], w["depth"], w["alpha"]])
+        self.max_R = max(self.max_R, rasterizer.last_num_rendered())
+
+    def calibrate(self):
+        """Thresholds from the statistics accumulated so far (untimed): ~10 % of the points over max_grad, half of those
+        small enough to be cloned, ~5 % of the points under min_opacity."""
+        st, p = self.stats, self.params
+        g = (st.xyz_gradient_accum[:, 0:1] / st.denom).nan_to_num(0.0).flatten()
+        q = lambda t, f: float(torch.kthvalue(t.float().flatten(), max(1, int(f * t.numel()))).values)
+        max_grad = q(g, 0.90)
+        sel = g >= max_grad
+        big = torch.exp(p["scaling"]).max(dim=1).values
+        thr = q(big[sel], 0.5) if int(sel.sum()) else 1.0
+        self.kw = dict(max_grad=max_grad, min_opacity=q(torch.sigmoid(p["opacity"]), 0.05), extent=1.0,
+                       percent_dense=thr, percent_big_ws=1e9, prune_big=False)
+
+    def densify(self):
+        from street_gaussians_amd import densify
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        new_p, new_s, scal, _ = densify.densify_and_prune(self.params, self.stats.xyz_gradient_accum, self.stats.denom,
+                                                          states=self.states, **self.kw)
+        self.params, self.states = new_p, new_s
+        self._activate()
+        torch.cuda.synchronize()
+        scal = dict(scal)
+        scal["ms"] = round(1e3 * (time.perf_counter() - t0), 3)
+        scal["gaussians_after"] = self.P
+        self.log.append(scal)
+
+    def run(self, fence, n_densify=3):
+        every = self.every
+        for _ in range(every):  # untimed calibration interval (also the warm-up)
+            self.step()
+        self.calibrate()
+        P0, self.max_R = self.P, 0
+        steps = every * n_densify
+        fence()
+        t0 = time.perf_counter()
+        for it in range(steps):
+            self.step()
+            if (it + 1) % every == 0:
+                self.densify()
+        fence()
+        dt = time.perf_counter() - t0
+        d_ms = sum(x["ms"] for x in self.log)
+        return {"config": "configs[4] 5M + densify/prune active in the loop (train.py:187-210)", "gaussians_start": P0,
+                "gaussians_end": self.P, "steps": steps, "densify_every": every, "densify_steps": len(self.log),
+                "ms_per_step_amortised": round(1e3 * dt / steps, 4), "iters_per_s_amortised": round(steps / dt, 3),
+                "raster_ms_per_step": round((1e3 * dt - d_ms) / steps, 4),
+                "densify_ms_mean": round(d_ms / max(1, len(self.log)), 3), "densify_log": self.log,
+                "max_num_rendered_R": self.max_R, "thresholds": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in self.kw.items()},
+                "note": "rasterizer forward+backward every iteration with the fused densification-statistics sink; "
+                        "densify_and_prune (plan + gather kernels, raw parameters + 12 Adam moment tensors) every "
+                        f"{every}th iteration, then exp/sigmoid/normalize re-activation; P, R and the geometry / binning / "
+                        "backward scratch buffers change size at each of those steps"}
 
 
 def load_scene_file(path, S):
@@ -333,6 +447,27 @@ def blend_bytes(S, R, N, V):
     return (44 + 4 * S) * R + (28 + 4 * S) * N + (48 + 4 * S) * V, (44 + 4 * S) * R + (24 + 4 * S) * N
 
 
+def stage_bytes(P, V_in, V, R, N, T, S, M=16):
+    """SURVEY 8d algorithmic (compulsory) bytes of every stage of one forward + backward: B_pre, B_scan, B_dup, B_sort
+    (read + write once; the depth pre-sort of this implementation is part of the sort's job, its time is reported under
+    "scan" next to B_scan), B_rng, B_blend_f, B_blend_b, B_pre_b.  B_zero does not apply (no gradient zero fills)."""
+    bb, bf = blend_bytes(S, R, N, V)
+    return {"preprocess": 12 * P + (28 + 12 * M) * V_in + 79 * V, "scan": 8 * P, "duplicate": 12 * R, "sort": 24 * R,
+            "tile_ranges": 8 * R + 8 * T, "blend_fwd": bf, "blend_bwd": bb,
+            "gauss_bwd": (111 + 12 * M) * V + (64 + 12 * M) * V}
+
+
+def stage_hbm_frac(stage_ms, sb):
+    """Per stage: SURVEY 8d bytes / measured time, as a fraction of the 8 TB/s HBM peak (+ the whole step)."""
+    out = {}
+    for k, b in sb.items():
+        ms = stage_ms.get(k)
+        out[k] = round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms else None
+    tot_ms = sum(v for k, v in stage_ms.items() if v and k in sb)
+    out["all_stages"] = round(sum(sb.values()) / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tot_ms else None
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -368,9 +503,10 @@ def main():
     for _ in range(args.warmup):
         wl.step()
     L = _native.lib()
-    # ---- the timed region: EXACTLY args.steps steps between two fences; only the dominant kernel carries events, and
-    # only on every 8th step (every step when there are fewer than 64)
-    every = 8 if args.steps >= 64 else 1
+    # ---- the timed region: EXACTLY args.steps steps between two fences; only the dominant kernel carries events
+    # (at most every 8th step whatever --steps is: an event pair drains the queue ~10 us each side of the launch it
+    # brackets, which taxed a 20-step region by ~1 % when every step carried one; at least 3 samples)
+    every = max(1, min(8, (args.steps - 1) // 2))
     dt, timed = profiled_steps(L, wl, fence, args.steps, 1 << 7, every=every)
     if args.step_times:
         ts = []
@@ -405,6 +541,8 @@ def main():
     if rank == 0:
         bwd_ms = timed["blend_bwd"]
         algo_bytes, fwd_bytes = blend_bytes(S, R, N, V)
+        T_tiles = ((args.width + 15) // 16) * ((args.height + 15) // 16)
+        sb = stage_bytes(args.gaussians, wl.V_in, V, R, N, T_tiles, S)
         achieved = algo_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms else None
         fwd_ms = stage_ms["blend_fwd"]
         traffic, valu, traffic_note = None, None, None
@@ -475,6 +613,9 @@ def main():
                                        "algorithmic_bytes_per_launch": fwd_bytes},
                          "stages_ms": {k: (round(v, 4) if v is not None else None) for k, v in stage_ms.items()},
                          "stages_ms_source": "extra pass after the timed region, every stage bracketed by HIP events",
+                         "stages_bytes": sb, "stages_hbm_frac": stage_hbm_frac(stage_ms, sb),
+                         "stages_bytes_source": "SURVEY 8d algorithmic bytes (B_pre, B_scan, B_dup, B_sort = 24 R, B_rng, "
+                                                "B_blend_f, B_blend_b, B_pre_b); frac = bytes / stage time / 8 TB/s",
                          "sum_n_contrib_pairs": pairs_blended,
                          "note": "blend kernels are VALU/exp/LDS bound (SURVEY 8d); HBM fraction is reported as the "
                                  "metric demands"},
@@ -508,8 +649,8 @@ def main():
 
 def other_configs(args, L, dev, fence):
     """BASELINE.json's other single-GPU configurations on the same build (untimed extras of the N = 1 run): configs[1]
-    500 k Gaussians, configs[2] 2 M Gaussians + 19 semantic channels, configs[4]'s per-GPU load 5 M Gaussians (its
-    densify step is timed by tools/bench_densify.py)."""
+    500 k Gaussians, configs[2] 2 M Gaussians + 19 semantic channels, configs[4]'s per-GPU load 5 M Gaussians -- first the
+    rasterizer alone, then the loop as configs[4] words it, with densify / prune active between iterations (DensifyLoop)."""
     out = []
     for name, P, S in (("configs[1] 500k", 500_000, 0), ("configs[2] 2M + 19 semantic channels", 2_000_000, 19),
                        ("configs[4] 5M (rasterizer only)", 5_000_000, 0)):
@@ -523,9 +664,10 @@ def other_configs(args, L, dev, fence):
             _, st = profiled_steps(L, wl, fence, 10, 0x1FF)
             R, V, _ = wl.counts()
             bb, fb = blend_bytes(S, R, args.width * args.height, V)
+            sb = stage_bytes(P, wl.V_in, V, R, args.width * args.height, ((args.width + 15) // 16) * ((args.height + 15) // 16), S)
             out.append({"config": name, "gaussians": P, "semantic_channels": S, "steps": steps,
                         "ms_per_step": round(1e3 * dt / steps, 4), "iters_per_s": round(steps / dt, 3),
-                        "num_rendered_R": R, "visible_V": V,
+                        "num_rendered_R": R, "visible_V": V, "stages_hbm_frac": stage_hbm_frac(st, sb),
                         "blend_bwd_ms": round(st["blend_bwd"], 4) if st["blend_bwd"] else None,
                         "blend_fwd_ms": round(st["blend_fwd"], 4) if st["blend_fwd"] else None,
                         "blend_bwd_hbm_frac": round(bb / (st["blend_bwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if st["blend_bwd"] else None,
@@ -533,6 +675,14 @@ def other_configs(args, L, dev, fence):
             del wl
         except Exception as ex:  # an extra: never lose the headline over it
             out.append({"config": name, "error": f"{type(ex).__name__}: {ex}"[:200]})
+    try:  # configs[4] as written: the densify / prune step active between iterations
+        torch.cuda.empty_cache()
+        loop = DensifyLoop(args, 5_000_000, dev, args.densify_every)
+        out.append(loop.run(fence))
+        del loop
+    except Exception as ex:
+        out.append({"config": "configs[4] 5M + densify/prune active in the loop", "error": f"{type(ex).__name__}: {ex}"[:300]})
+    torch.cuda.empty_cache()
     return out
 
 

@@ -74,12 +74,25 @@ int sgr_backward(int P, int D, int M, int R, int S, const float* background, int
  * (lib/models/street_gaussian_model.py:551-571) in place -- for every Gaussian with radii > 0:
  *   xyz_gradient_accum[g,0] += |dL/dmean2D[g,:2]|,  xyz_gradient_accum[g,1] += |dL/dmean2D[g,2]|,  denom[g] += 1,
  *   max_radii2D[g] = max(max_radii2D[g], radii[g])
- * -- instead of six masked torch ops per sub-model afterwards.  The three arrays cover all P Gaussians of the call in
- * its order (street_gaussians_amd.scene.FlatStats keeps the sub-models' statistics as views of such arrays). */
+ * -- instead of six masked torch ops per sub-model afterwards.  With segments == NULL the three arrays cover all P
+ * Gaussians of the call in its order.  The reference rebuilds the list of rendered sub-models per frame
+ * (street_gaussian_model.py:230-250: only the actors visible at that timestamp), so the rasterized set is in general a
+ * SUBSET of the persistent per-model statistics: `segments` (host array, sorted by src_start, non-overlapping, at most
+ * SGR_MAX_STAT_SEGMENTS) maps the call's Gaussians [src_start, src_start + count) to the persistent rows
+ * [dst_offset, dst_offset + count); Gaussians in no segment leave no statistics.  The three arrays then have the
+ * caller's persistent length (street_gaussians_amd.scene.FlatStats keeps the sub-models' statistics as views of them). */
+#define SGR_MAX_STAT_SEGMENTS 128
+typedef struct sgr_stat_segment {
+    int src_start;  /* first Gaussian of the segment in this call's order */
+    int count;
+    int dst_offset; /* its first row in the persistent arrays */
+} sgr_stat_segment;
 typedef struct sgr_backward_extras {
-    float* xyz_gradient_accum; /* [P,2] or NULL */
+    float* xyz_gradient_accum; /* [P,2] (or the persistent [total,2] with segments), or NULL */
     float* denom;              /* [P,1] */
     float* max_radii2D;        /* [P]   */
+    const sgr_stat_segment* segments; /* host memory; NULL = identity map over the call's P Gaussians */
+    int n_segments;
 } sgr_backward_extras;
 int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, int width, int height,
                     const float* means3D, const float* shs, const float* colors_precomp, const float* semantics,
@@ -103,6 +116,14 @@ int sgr_masked_color_grad(int P, const char* geom_buffer, const float* dL_dcolor
  * (campos [V,3], dL_drgb [V,P,3]); coefficients k >= (D+1)^2 are written as zeros, like sgr_backward does. */
 int sgr_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* campos, const float* dL_drgb,
                            float* dL_dsh, void* stream);
+/* The same with explicit per-view strides (in floats): view v reads its camera centre at campos + v*campos_view_stride,
+ * its dL_drgb rows at dL_drgb + v*drgb_view_stride, and -- means_view_stride > 0 -- its own positions at
+ * means3D + v*means_view_stride (a posed sub-model, street_gaussian_model.py:287-330: actor positions differ per frame and
+ * travel with the exchange); means_view_stride == 0: one set of positions for all views.  Lets the rebuild read straight
+ * out of all-gathered payload rows. */
+int sgr_sh_grad_from_views_ex(int P, int D, int M, int V, const float* means3D, size_t means_view_stride,
+                              const float* campos, size_t campos_view_stride, const float* dL_drgb,
+                              size_t drgb_view_stride, float* dL_dsh, void* stream);
 
 /* CudaRasterizer::Rasterizer::markVisible  (cuda_rasterizer/rasterizer.h:24-29, rasterizer_impl.cu:141-153).
  * present[P] as bytes (0/1). */

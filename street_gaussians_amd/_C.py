@@ -64,8 +64,16 @@ def _call_ext(fn, *args):
         raise SgrError(str(ex).split("\n")[0]) from None
 
 
+class _StatSegment(C.Structure):  # sgr_stat_segment (include/sgr.h)
+    _fields_ = [("src_start", C.c_int), ("count", C.c_int), ("dst_offset", C.c_int)]
+
+
 class _BackwardExtras(C.Structure):  # sgr_backward_extras (include/sgr.h)
-    _fields_ = [("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p), ("max_radii2D", C.c_void_p)]
+    _fields_ = [("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p), ("max_radii2D", C.c_void_p),
+                ("segments", C.POINTER(_StatSegment)), ("n_segments", C.c_int)]
+
+
+MAX_STAT_SEGMENTS = 128  # SGR_MAX_STAT_SEGMENTS
 
 
 def _dev_check(t: torch.Tensor, name: str):
@@ -155,7 +163,9 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:126-220).  Returns
     (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dsemantic).
     stats (extension): (xyz_gradient_accum [P,2], denom [P,1], max_radii2D [P]) contiguous float32 tensors updated in
-    place with this view's densification statistics (sgr_backward_ex)."""
+    place with this view's densification statistics (sgr_backward_ex); or a 4-tuple whose last element is a list of
+    (src_start, count, dst_offset) segments mapping this call's Gaussians to rows of PERSISTENT statistics tensors of
+    any length (a frame renders a subset of the sub-models, street_gaussian_model.py:230-250)."""
     _dev_check(means3D, "means3D")
     ext = _pybind()
     if ext is not None and stats is None:
@@ -196,11 +206,25 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
         extras = None
         if stats is not None:
-            acc, den, mr = stats
-            for t, n in ((acc, 2 * P), (den, P), (mr, P)):
+            acc, den, mr = stats[:3]
+            segments = stats[3] if len(stats) > 3 else None
+            rows = P if segments is None else den.numel()
+            for t, n in ((acc, 2 * rows), (den, rows), (mr, rows)):
                 if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n):
-                    raise SgrError("densification statistics must be contiguous float32 HIP tensors covering all P Gaussians")
-            extras = _BackwardExtras(acc.data_ptr(), den.data_ptr(), mr.data_ptr())
+                    raise SgrError("densification statistics must be contiguous float32 HIP tensors " +
+                                   ("covering all P Gaussians" if segments is None else "of one common length"))
+            seg_arr, nseg = None, 0
+            if segments is not None:
+                nseg = len(segments)
+                if nseg > MAX_STAT_SEGMENTS:
+                    raise SgrError(f"at most {MAX_STAT_SEGMENTS} statistics segments per call")
+                seg_arr = (_StatSegment * max(nseg, 1))()
+                for k, (s0, cnt, d0) in enumerate(segments):
+                    if d0 < 0 or cnt < 0 or d0 + cnt > rows:
+                        raise SgrError("statistics segment outside the persistent tensors")
+                    seg_arr[k] = _StatSegment(int(s0), int(cnt), int(d0))
+                keep.append(seg_arr)
+            extras = _BackwardExtras(acc.data_ptr(), den.data_ptr(), mr.data_ptr(), seg_arr, nseg)
         check(_native.lib().sgr_backward_ex(
             P, int(degree), M, int(R), S, p(background, "bg"), W, H, p(means3D, "means3D"), p(sh, "sh"),
             p(colors, "colors_precomp"), p(semantics, "semantics"), p(alphas, "alpha"), p(scales, "scales"),
@@ -323,6 +347,18 @@ def sh_grad_from_views(means3D, campos, drgb, degree, M):
         check(_native.lib().sgr_sh_grad_from_views(P, int(degree), int(M), V, C.c_void_p(means3D.data_ptr()),
                                                    C.c_void_p(campos.data_ptr()), C.c_void_p(drgb.data_ptr()),
                                                    C.c_void_p(out.data_ptr()), _stream(dev)))
+    return out
+
+
+def sh_grad_from_rows(P, degree, M, V, means_ptr, means_stride, campos_ptr, campos_stride, drgb_ptr, drgb_stride, device):
+    """sgr_sh_grad_from_views_ex on raw device addresses + per-view strides (in floats): the rebuild of
+    multiview.FactoredGradReducer reads its inputs straight out of the all-gathered payload rows.  -> [P, M, 3]."""
+    out = torch.empty((int(P), int(M), 3), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        check(_native.lib().sgr_sh_grad_from_views_ex(int(P), int(degree), int(M), int(V), C.c_void_p(means_ptr),
+                                                      int(means_stride), C.c_void_p(campos_ptr), int(campos_stride),
+                                                      C.c_void_p(drgb_ptr), int(drgb_stride), C.c_void_p(out.data_ptr()),
+                                                      _stream(device)))
     return out
 
 

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsgr_hip.so")
+# SGR_LIB: another BUILD of the same library (tools/gpu_ab.sh variants built with other -D switches); never a fallback
+LIB_PATH = os.environ.get("SGR_LIB") or os.path.join(_HERE, "libsgr_hip.so")
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
@@ -22,7 +23,7 @@ SYMBOLS = [
     "sgr_knn", "sgr_geometry_bytes", "sgr_binning_bytes", "sgr_image_bytes", "sgr_partial_row_floats",
     "sgr_export_internal", "sgr_test_scan", "sgr_test_sort", "sgr_test_sort32", "sgr_test_sort_hist_words", "sgr_test_scan_tmp_words",
     "sgr_test_wave_sum", "sgr_test_switches", "sgr_profile_enable", "sgr_profile_select", "sgr_profile_sample", "sgr_profile_read", "sgr_masked_color_grad",
-    "sgr_sh_grad_from_views", "sgr_scene_compose_forward", "sgr_scene_compose_backward",
+    "sgr_sh_grad_from_views", "sgr_sh_grad_from_views_ex", "sgr_scene_compose_forward", "sgr_scene_compose_backward",
     "sgr_scene_densification_stats", "sgr_ssim_workspace_floats", "sgr_ssim_forward", "sgr_ssim_backward",
     "sgr_l1_workspace_floats", "sgr_l1_forward", "sgr_l1_backward", "sgr_color_loss_backward", "sgr_bce_forward", "sgr_bce_backward",
     "sgr_lidar_work_bytes", "sgr_lidar_depth_forward", "sgr_lidar_depth_backward", "sgr_densify_work_bytes", "sgr_densify_plan",
@@ -69,6 +70,8 @@ def lib():
         L.sgr_masked_color_grad.argtypes = [i, vp, vp, vp, vp]
         L.sgr_sh_grad_from_views.restype = i
         L.sgr_sh_grad_from_views.argtypes = [i, i, i, i, vp, vp, vp, vp, vp]
+        L.sgr_sh_grad_from_views_ex.restype = i
+        L.sgr_sh_grad_from_views_ex.argtypes = [i, i, i, i, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, vp]
         L.sgr_scene_compose_forward.restype = i
         L.sgr_scene_compose_forward.argtypes = [i, vp, i, i, vp, vp, vp, vp, vp, vp, ALLOC_FN, vp, vp]
         L.sgr_scene_compose_backward.restype = i

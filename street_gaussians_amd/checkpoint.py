@@ -43,12 +43,24 @@ def models_from_state(state: Dict) -> "OrderedDict[str, Dict[str, torch.Tensor]]
 
 
 def state_from_models(models: Dict[str, Dict], is_final: bool = True, iteration: Optional[int] = None,
-                      others: Optional[Dict] = None) -> Dict:
+                      others: Optional[Dict] = None, device=None) -> Dict:
     """The inverse: a dictionary with the reference's layout, ready for ``torch.save``.  With ``is_final`` only the raw
-    parameters are written, like ``state_dict(is_final=True)``."""
+    parameters are written, like ``state_dict(is_final=True)``.
+
+    The seven parameters are written the way the reference's own ``state_dict`` holds them -- ``nn.Parameter`` with
+    ``requires_grad=True`` -- because ``GaussianModel.load_state_dict`` (gaussian_model.py:157-164) ASSIGNS the entries to
+    ``_xyz``, ``_features_dc``, ... as they are and ``training_setup`` builds the optimiser over them; the reference reads
+    the file with ``torch.load`` without ``map_location`` and renders from the loaded tensors directly, so a file that is
+    to be resumed / rendered BY THE REFERENCE must be saved from GPU tensors (``device="cuda"`` moves them; the default
+    keeps the device the tensors are on, so that saving works on a machine without a GPU)."""
     state = {}
     for name, m in models.items():
-        sd = {theirs: torch.as_tensor(m[ours]) for theirs, ours in PARAM_KEYS.items()}
+        sd = {}
+        for theirs, ours in PARAM_KEYS.items():
+            t = torch.as_tensor(m[ours]).detach()
+            if device is not None:
+                t = t.to(device)
+            sd[theirs] = torch.nn.Parameter(t.float().contiguous().clone(), requires_grad=True)
         if not is_final:
             for k in EXTRA_KEYS:
                 if k in m:

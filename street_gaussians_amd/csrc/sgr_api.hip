@@ -7,6 +7,7 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <string>
 
 #include "../../include/sgr.h"
@@ -43,8 +44,9 @@ void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, cons
                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dsemantic,
                           const SgrStatSink& sink, hipStream_t s);
 void sgr_launch_masked_color_grad(int P, const uint32_t* clamped, const float* dL_dcolor, float* out, hipStream_t s);
-void sgr_launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* campos,
-                                   const float* drgb, float* dL_dsh, hipStream_t s);
+void sgr_launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, size_t means_stride,
+                                   const float* campos, size_t campos_stride, const float* drgb, size_t drgb_stride,
+                                   float* dL_dsh, hipStream_t s);
 void sgr_launch_wave_sum_test(const float* in, float* out_dpp, float* out_shfl, int nwaves, hipStream_t s);
 int sgr_knn_impl(int P, const float* points, float* meanDists, sgr_alloc_fn scratch, void* scratch_user, hipStream_t s,
                  std::string& err);
@@ -189,6 +191,7 @@ sgr_pack_camera_kernel(SgrCam* cam, const float* view, const float* proj, const 
 // the SgrCam lives in the header block of the geometry buffer (words 16.. of the 64-word header)
 static SgrCam* cam_slot(const SgrGeomView& gv) { return reinterpret_cast<SgrCam*>(gv.header + 16); }
 static_assert(sizeof(SgrCam) <= 48 * 4, "SgrCam must fit the geometry header");
+static_assert(SGR_STAT_SEG_MAX == SGR_MAX_STAT_SEGMENTS, "sgr_common.h and include/sgr.h disagree");
 
 static void pack_camera(const SgrGeomView& gv, const float* view, const float* proj, const float* campos,
                         float tan_fovx, float tan_fovy, int W, int H, float scale_modifier, uint2* ranges, int T,
@@ -199,6 +202,22 @@ static void pack_camera(const SgrGeomView& gv, const float* view, const float* p
     const int nb = std::max(1, std::min(64, (T + 255) / 256));
     sgr_pack_camera_kernel<<<nb, 256, 0, s>>>(cam_slot(gv), view, proj, campos, tan_fovx, tan_fovy, focal_x, focal_y, W, H,
                                              gx, gy, scale_modifier, gv.header, ranges, T);
+}
+
+// One 256-byte device block per DEVICE for the whole process (allocated on first use, kept): the flag word of
+// sgr_visible_filter's `prefiltered` check and the counters of sgr_densify_prune_mask.  Both users finish with a stream
+// synchronisation, so the block is handed out under a mutex that is held until they return -- no per-thread allocations
+// that are never freed, and two host threads cannot interleave on the same words.
+SgrFlagBlock sgr_acquire_flag_block() {
+    static std::mutex mu;
+    static uint32_t* blk[64] = {};
+    SgrFlagBlock b;
+    b.lock = std::unique_lock<std::mutex>(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return b;
+    if (!blk[dev] && hipMalloc((void**)&blk[dev], 256) != hipSuccess) blk[dev] = nullptr;
+    b.ptr = blk[dev];
+    return b;
 }
 
 extern "C" {
@@ -381,6 +400,23 @@ int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, 
         sink.accum = extras->xyz_gradient_accum;
         sink.denom = extras->denom;
         sink.max_radii = extras->max_radii2D;
+        if (extras->segments != nullptr) {
+            const int n = extras->n_segments;
+            if (n < 0 || n > SGR_STAT_SEG_MAX)
+                return fail(SGR_E_INVALID, "statistics sink: at most 128 segments per call");
+            int end = 0;
+            for (int i = 0; i < n; i++) {
+                const sgr_stat_segment& sg = extras->segments[i];
+                if (sg.src_start < end || sg.count < 0 || sg.dst_offset < 0 || (long)sg.src_start + sg.count > (long)P)
+                    return fail(SGR_E_INVALID, "statistics sink: segments must be sorted, non-overlapping and inside [0, P)");
+                end = sg.src_start + sg.count;
+                sink.start[i] = sg.src_start;
+                sink.count[i] = sg.count;
+                sink.shift[i] = sg.dst_offset - sg.src_start;
+            }
+            sink.nseg = n;
+            if (n == 0) sink.accum = sink.denom = sink.max_radii = nullptr;  // nothing of this frame is tracked
+        }
     }
     (void)colors_precomp; (void)scale_modifier; (void)viewmatrix; (void)projmatrix; (void)campos;
     (void)tan_fovx; (void)tan_fovy;  // already resident in the geometry buffer's camera block
@@ -464,8 +500,22 @@ int sgr_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, con
     if (P <= 0) return 0;
     if (D < 0 || D > 3 || M < (D + 1) * (D + 1) || V < 0) return fail(SGR_E_INVALID, "need 0 <= D <= 3, M >= (D+1)^2, V >= 0");
     if (!means3D || !campos || !dL_drgb || !dL_dsh) return fail(SGR_E_INVALID, "means3D, campos, dL_drgb and dL_dsh are required");
-    sgr_launch_sh_grad_from_views(P, D, M, V, means3D, campos, dL_drgb, dL_dsh, stream);
+    sgr_launch_sh_grad_from_views(P, D, M, V, means3D, 0, campos, 3, dL_drgb, (size_t)3 * P, dL_dsh, stream);
     SGR_STAGE("sh_grad_from_views");
+    return 0;
+}
+
+int sgr_sh_grad_from_views_ex(int P, int D, int M, int V, const float* means3D, size_t means_view_stride,
+                              const float* campos, size_t campos_view_stride, const float* dL_drgb,
+                              size_t drgb_view_stride, float* dL_dsh, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int debug = 0;
+    if (P <= 0) return 0;
+    if (D < 0 || D > 3 || M < (D + 1) * (D + 1) || V < 0) return fail(SGR_E_INVALID, "need 0 <= D <= 3, M >= (D+1)^2, V >= 0");
+    if (!means3D || !campos || !dL_drgb || !dL_dsh) return fail(SGR_E_INVALID, "means3D, campos, dL_drgb and dL_dsh are required");
+    sgr_launch_sh_grad_from_views(P, D, M, V, means3D, means_view_stride, campos, campos_view_stride, dL_drgb,
+                                  drgb_view_stride, dL_dsh, stream);
+    SGR_STAGE("sh_grad_from_views_ex");
     return 0;
 }
 
@@ -528,17 +578,6 @@ int sgr_profile_read(double* sum_ms, int* counts) {
     return n;
 }
 
-// One 256-byte device block per (host thread, device), allocated on first use and kept: the flag word of
-// sgr_visible_filter's `prefiltered` check.  Neither entry point below allocates, frees or synchronises on its
-// normal path; everything is queued on the caller's stream.
-static uint32_t* filter_flag_block() {
-    static thread_local uint32_t* blk[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!blk[dev] && hipMalloc((void**)&blk[dev], 256) != hipSuccess) blk[dev] = nullptr;
-    return blk[dev];
-}
-
 int sgr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
                      void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -572,8 +611,10 @@ int sgr_visible_filter(int P, int width, int height, const float* means3D, const
     SgrGeomView gv;
     memset(&gv, 0, sizeof(gv));
     uint32_t* flag = nullptr;
+    SgrFlagBlock fb;
     if (prefiltered) {  // only then can the kernel raise the "filtered although prefiltered" flag
-        flag = filter_flag_block();
+        fb = sgr_acquire_flag_block();
+        flag = fb.ptr;
         if (!flag) return fail(SGR_E_HIP, "flag block allocation failed");
         SGR_HIP(hipMemsetAsync(flag, 0, 4, stream));
         gv.header = flag;

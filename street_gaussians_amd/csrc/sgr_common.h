@@ -58,10 +58,17 @@ struct SgrBinView {
 };
 
 // optional sink of the backward for this view's densification statistics (sgr_backward_ex); all three or none
+#define SGR_STAT_SEG_MAX 128  // == SGR_MAX_STAT_SEGMENTS (include/sgr.h)
 struct SgrStatSink {
     float* accum = nullptr;      // xyz_gradient_accum [P,2]
     float* denom = nullptr;      // [P,1]
     float* max_radii = nullptr;  // max_radii2D [P]
+    // optional map from this call's Gaussians to the persistent rows (a frame renders a subset of the sub-models):
+    // segment s covers [start[s], start[s] + count[s]) -> rows shift[s] + index; nseg == 0: identity
+    int nseg = 0;
+    int start[SGR_STAT_SEG_MAX];
+    int count[SGR_STAT_SEG_MAX];
+    int shift[SGR_STAT_SEG_MAX];  // dst_offset - src_start
 };
 
 struct SgrImgView {
@@ -160,6 +167,13 @@ static inline size_t sgr_required(F carve) {
 }
 
 #ifdef __HIPCC__
+#include <mutex>
+// process-wide 256-byte device block of the current device, held (mutex) until the struct is destroyed (sgr_api.hip)
+struct SgrFlagBlock {
+    uint32_t* ptr = nullptr;
+    std::unique_lock<std::mutex> lock;
+};
+SgrFlagBlock sgr_acquire_flag_block();
 // ---- primitives shared by several translation units (defined in sgr_scan_sort.hip); declared HERE only, so a changed
 // signature cannot leave a stale copy behind in another file --------------------------------------------------------
 // device-wide scan: out may alias in; tmp needs sgr_scan_tmp_count(n) words; tmp[nblocks] (and *total_out) receive the

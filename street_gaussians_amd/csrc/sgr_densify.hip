@@ -255,16 +255,15 @@ int sgr_densify_prune_mask(int n, const sgr_densify_params* p, int variant, cons
             return sgr_set_error(SGR_E_INVALID, "the actor rule needs box, box_normals and rotation");
         for (int a = 0; a < 3; a++) { bx.lo[a] = box[a]; bx.hi[a] = box[3 + a]; }
     }
-    static thread_local uint32_t* cnt[64] = {};  // 16-byte counter block per (host thread, device), kept
-    int dev = 0;
-    DN_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) return sgr_set_error(SGR_E_INVALID, "device index out of range");
-    if (!cnt[dev]) DN_HIP(hipMalloc((void**)&cnt[dev], 256));
-    DN_HIP(hipMemsetAsync(cnt[dev], 0, 16, stream));
+    // 16 bytes of counters in the process-wide per-device block (held until this call has read them back)
+    SgrFlagBlock fb = sgr_acquire_flag_block();
+    if (!fb.ptr) return sgr_set_error(SGR_E_HIP, "counter block allocation failed");
+    uint32_t* cnt = fb.ptr + 16;  // words 16..19: the first words belong to sgr_visible_filter's flag
+    DN_HIP(hipMemsetAsync(cnt, 0, 16, stream));
     sgr_densify_prune_kernel<<<(n + 255) / 256, 256, 0, stream>>>(n, *p, variant, xyz, scaling, rotation, opacity, sph, bx,
-                                                                 box_normals, prune, cnt[dev]);
+                                                                 box_normals, prune, cnt);
     uint32_t h[4];
-    DN_HIP(hipMemcpyAsync(h, cnt[dev], 16, hipMemcpyDeviceToHost, stream));
+    DN_HIP(hipMemcpyAsync(h, cnt, 16, hipMemcpyDeviceToHost, stream));
     DN_HIP(hipStreamSynchronize(stream));
     for (int k = 0; k < 4; k++) counts[k] = h[k];
     return 0;

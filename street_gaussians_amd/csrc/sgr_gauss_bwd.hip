@@ -88,10 +88,23 @@ sgr_row_sum_kernel(int P, int S, const int* __restrict__ radii, SgrGeomView gv, 
         const int r = radii[idx];
         if (sink.accum != nullptr && r > 0) {
 #pragma clang fp contract(off)
-            sink.accum[2 * (size_t)idx] += sqrtf(acc[0] * acc[0] + acc[1] * acc[1]);  // norm of grad[:, :2]
-            sink.accum[2 * (size_t)idx + 1] += fabsf(acc[2]);                          // norm of grad[:, 2:]
-            sink.denom[idx] += 1.0f;
-            sink.max_radii[idx] = fmaxf(sink.max_radii[idx], (float)r);
+            // persistent row of this Gaussian: identity, or through the frame's segment map (binary search over the
+            // segment starts, kernel arguments -> scalar loads)
+            long row = idx;
+            if (sink.nseg > 0) {
+                int lo = 0, hi = sink.nseg - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (sink.start[mid] <= idx) lo = mid; else hi = mid - 1;
+                }
+                row = (idx >= sink.start[lo] && idx < sink.start[lo] + sink.count[lo]) ? (long)idx + sink.shift[lo] : -1;
+            }
+            if (row >= 0) {
+                sink.accum[2 * (size_t)row] += sqrtf(acc[0] * acc[0] + acc[1] * acc[1]);  // norm of grad[:, :2]
+                sink.accum[2 * (size_t)row + 1] += fabsf(acc[2]);                          // norm of grad[:, 2:]
+                sink.denom[row] += 1.0f;
+                sink.max_radii[row] = fmaxf(sink.max_radii[row], (float)r);
+            }
         }
     } else if (q == 1) {
         dL_dopacity[idx] = acc[6];

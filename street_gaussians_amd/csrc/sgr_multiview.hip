@@ -22,10 +22,13 @@ sgr_masked_color_grad_kernel(int P, const uint32_t* __restrict__ clamped, const 
 }
 
 // dL_dsh[g][k][c] = sum_v Y_k(dir_v(g)) * drgb[v][g][c]   (k < (D+1)^2; zero above)
+// means_stride / drgb_stride / campos_stride: floats between consecutive views (means_stride == 0: one set of
+// positions for every view -- a static model; > 0: the positions of a posed model differ per view and travel with the
+// exchange).  The strides let the kernel read straight out of the all-gathered payload rows.
 __global__ void __launch_bounds__(SGR_MV_THREADS)
-sgr_sh_grad_from_views_kernel(int P, int D, int M, int V, const float* __restrict__ means3D,
-                              const float* __restrict__ campos, const float* __restrict__ drgb,
-                              float* __restrict__ dL_dsh) {
+sgr_sh_grad_from_views_kernel(int P, int D, int M, int V, const float* __restrict__ means3D, size_t means_stride,
+                              const float* __restrict__ campos, size_t campos_stride, const float* __restrict__ drgb,
+                              size_t drgb_stride, float* __restrict__ dL_dsh) {
     const int gidx = blockIdx.x * SGR_MV_THREADS + threadIdx.x;
     const bool live = gidx < P;
     const int idx = live ? gidx : P - 1;
@@ -34,13 +37,18 @@ sgr_sh_grad_from_views_kernel(int P, int D, int M, int V, const float* __restric
     float acc[48];
 #pragma unroll
     for (int k = 0; k < 48; k++) acc[k] = 0.f;
-    const float p[3] = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+    float p[3] = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
     for (int v = 0; v < V; v++) {
-        const float* g = drgb + ((size_t)v * P + idx) * 3;
+        const float* g = drgb + (size_t)v * drgb_stride + (size_t)idx * 3;
         const float d0 = g[0], d1 = g[1], d2 = g[2];
-        if (d0 == 0.f && d1 == 0.f && d2 == 0.f) continue;  // culled / fully clamped in this view
+        if (d0 == 0.f && d1 == 0.f && d2 == 0.f) continue;  // culled / fully clamped / not rendered in this view
+        if (means_stride) {
+            const float* mp = means3D + (size_t)v * means_stride + (size_t)idx * 3;
+            p[0] = mp[0]; p[1] = mp[1]; p[2] = mp[2];
+        }
+        const float* cp = campos + (size_t)v * campos_stride;
         // same expressions as the per-view backward (sgr_gauss_bwd.hip)
-        const float ox = p[0] - campos[3 * v], oy = p[1] - campos[3 * v + 1], oz = p[2] - campos[3 * v + 2];
+        const float ox = p[0] - cp[0], oy = p[1] - cp[1], oz = p[2] - cp[2];
         const float len = sqrtf(ox * ox + oy * oy + oz * oz);
         float Y[16];
         sgr_sh_basis(D, ox / len, oy / len, oz / len, Y);
@@ -83,9 +91,10 @@ void sgr_launch_masked_color_grad(int P, const uint32_t* clamped, const float* d
                                                                                                         dL_dcolor, out);
 }
 
-void sgr_launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* campos,
-                                   const float* drgb, float* dL_dsh, hipStream_t s) {
+void sgr_launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, size_t means_stride,
+                                   const float* campos, size_t campos_stride, const float* drgb, size_t drgb_stride,
+                                   float* dL_dsh, hipStream_t s) {
     if (P <= 0) return;
     sgr_sh_grad_from_views_kernel<<<(P + SGR_MV_THREADS - 1) / SGR_MV_THREADS, SGR_MV_THREADS, 0, s>>>(
-        P, D, M, V, means3D, campos, drgb, dL_dsh);
+        P, D, M, V, means3D, means_stride, campos, campos_stride, drgb, drgb_stride, dL_dsh);
 }

@@ -27,7 +27,8 @@ max for the screen radii.  Works with the gloo backend on CPU tensors (tests/tes
 """
 from __future__ import annotations
 
-from typing import Iterable, List, Optional
+from dataclasses import dataclass
+from typing import Iterable, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -111,6 +112,11 @@ class GradReducer:
         else:
             torch._foreach_copy_(self._views, grads)
             self._works = self._collective(async_op=True)
+        # a gradient that still IS a view of the bucket (installed by the previous wait()) must not be accumulated into
+        # while the collective runs on the bucket: detach it, the next backward allocates a fresh one
+        for p, v in zip(self.params, self._views):
+            if p.grad is not None and p.grad.data_ptr() == v.data_ptr():
+                p.grad = None
         self._inflight = True
 
     def wait(self) -> None:
@@ -141,6 +147,34 @@ class GradReducer:
         self.wait()
 
 
+@dataclass
+class SHSegment:
+    """One sub-model of a scene graph for the factored exchange: its SH LEAF parameters as the reference stores them
+    (features_dc [n, C, 3] with C = 1 for the background and C = fourier_dim for an actor, features_rest [n, M-1, 3];
+    gaussian_model.py:120-123, gaussian_model_actor.py:45-60) and where its Gaussians are.
+
+    means is not None   a static model: world positions [n, 3], replicated on every rank (view directions are
+                        recomputed from them locally);
+    means is None       a posed model (actor): its world positions differ per frame
+                        (street_gaussian_model.py:287-330), so the positions of the view travel with its dRGB
+                        (24 B instead of 12 B per Gaussian and view -- actors are a few % of a street scene)."""
+    features_dc: torch.Tensor
+    features_rest: Optional[torch.Tensor]
+    means: Optional[torch.Tensor] = None
+
+    @property
+    def n(self) -> int:
+        return int(self.features_dc.shape[0])
+
+    @property
+    def fourier_dim(self) -> int:
+        return int(self.features_dc.shape[1])
+
+    @property
+    def posed(self) -> bool:
+        return self.means is None
+
+
 class FactoredGradReducer:
     """Exchange step for view-sharded training with SH colours: dense parameters through a flat all-reduce bucket, the
     SH gradient through an all-gather of per-view dRGB + a local rebuild (module docstring).
@@ -151,43 +185,102 @@ class FactoredGradReducer:
                   rebuilt sum over all views.  Leaf tensors only: a non-leaf SH tensor (e.g. the output of
                   scene.compose) has already sent this view's dL/dSH down the graph.
     means3D       positions [P, 3] (view directions are recomputed from them on every rank)
+    segments      instead of (shs, means3D): the scene graph as a list of ``SHSegment`` -- background + actors, whose
+                  composed SH tensor is a ``cat`` over sub-models with per-frame actor poses and a per-frame Fourier mix
+                  of the actors' DC term (street_gaussian_model.py:287-449).  The rasterizer then sees a NON-leaf SH
+                  tensor; detach it before the rasterizer call (``shs.detach()``) so that no dL/dSH flows down the
+                  graph, and declare every frame with ``set_frame`` -- the exchange stays at 12 (static) / 24 (posed)
+                  bytes per Gaussian and view instead of the 192 B/Gaussian of a flat bucket.
     views_per_rank  rasterizer backward calls every rank makes per step (equal on all ranks)
 
-    The per-view dL/dcolour, geometry buffer and camera centre are picked up from the rasterizer's backward through
-    ``rasterizer.BACKWARD_OBSERVERS``; call ``close()`` (or use it as a context manager) to detach.  ``mask_fn`` /
-    ``rebuild_fn`` default to the HIP kernels and exist so the collective logic can be tested on CPU tensors with the
-    gloo backend; there is no CPU implementation in the product.
+    The per-view dL/dcolour, geometry buffer, camera centre and positions are picked up from the rasterizer's backward
+    through ``rasterizer.BACKWARD_OBSERVERS``; call ``close()`` (or use it as a context manager) to detach.
+    ``mask_fn`` / ``rebuild_fn`` default to the HIP kernels and exist so the collective logic can be tested on CPU
+    tensors with the gloo backend; there is no CPU implementation in the product.
+
+    The payload buffer is double-buffered and guarded by events: a rasterizer backward that runs between ``begin()`` and
+    ``wait()`` (the overlap schedule, or k > 1 accumulation) writes the OTHER buffer, and a buffer is only reused once
+    the all-gather that read it has completed on the side stream.
     """
 
-    def __init__(self, dense_params: Iterable[torch.Tensor], shs: torch.Tensor, means3D: torch.Tensor,
+    def __init__(self, dense_params: Iterable[torch.Tensor], shs=None, means3D: Optional[torch.Tensor] = None,
                  group: Optional[dist.ProcessGroup] = None, views_per_rank: int = 1, mode: str = "all_reduce",
-                 force: bool = False, mask_fn=None, rebuild_fn=None):
+                 force: bool = False, mask_fn=None, rebuild_fn=None, segments: Optional[Sequence[SHSegment]] = None):
         from . import rasterizer as _rast
         self.dense = GradReducer(dense_params, group=group, mode=mode, force=force)
-        self.shs_parts = list(shs) if isinstance(shs, (tuple, list)) else [shs]
-        for t in self.shs_parts:
-            if not t.is_leaf:
-                raise ValueError("FactoredGradReducer needs LEAF SH parameters (their .grad is replaced)")
-        self.M = sum(int(t.shape[1]) for t in self.shs_parts)
-        self.shs = self.shs_parts[0] if len(self.shs_parts) == 1 else None
-        self.means3D, self.group, self.force = means3D, group, force
+        self._single = None
+        if segments is None:
+            if shs is None or means3D is None:
+                raise ValueError("give (shs, means3D) or segments")
+            parts = list(shs) if isinstance(shs, (tuple, list)) else [shs]
+            if len(parts) == 1:  # one [P, M, 3] parameter: its gradient is the rebuilt tensor as a whole
+                self._single = parts[0]
+                segments = [SHSegment(parts[0][:, :1, :], parts[0][:, 1:, :] if parts[0].shape[1] > 1 else None, means3D)]
+            else:
+                segments = [SHSegment(parts[0], parts[1], means3D)]
+        self.segments = list(segments)
+        for sg in self.segments:
+            for t in ([self._single] if self._single is not None else [sg.features_dc, sg.features_rest]):
+                if t is not None and not t.is_leaf:
+                    raise ValueError("FactoredGradReducer needs LEAF SH parameters (their .grad is replaced)")
+            if not sg.posed and sg.fourier_dim != 1:
+                raise ValueError("a static segment has one DC row (features_dc [n, 1, 3])")
+        self.M = 1 + (int(self.segments[0].features_rest.shape[1]) if self.segments[0].features_rest is not None else 0)
+        first = self.segments[0].features_dc
+        self.group, self.force = group, force
         self.k = int(views_per_rank)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._mask_fn, self._rebuild_fn = mask_fn, rebuild_fn
         self._pending = []
-        P = means3D.shape[0]
-        dev = means3D.device
-        # payload of one view: [campos (3) | dRGB (3P)]
-        self._mine = torch.zeros(self.k, 3 + 3 * P, dtype=torch.float32, device=dev)
-        self._all = torch.zeros(self.world * self.k, 3 + 3 * P, dtype=torch.float32, device=dev)
+        dev = first.device
+        # payload row of one view: [campos 3 | dRGB of every segment, statics first then posed | positions of the posed
+        # segments | Fourier mix (idft) of every posed segment]
+        self._static = [i for i, sg in enumerate(self.segments) if not sg.posed]
+        self._posed = [i for i, sg in enumerate(self.segments) if sg.posed]
+        off = 3
+        self._drgb_off = {}
+        for i in self._static + self._posed:
+            self._drgb_off[i] = off
+            off += 3 * self.segments[i].n
+        self._posed_drgb0 = self._drgb_off[self._posed[0]] if self._posed else off
+        self._n_posed = sum(self.segments[i].n for i in self._posed)
+        self._pos_off = {}
+        for i in self._posed:
+            self._pos_off[i] = off
+            off += 3 * self.segments[i].n
+        self._pos0 = self._pos_off[self._posed[0]] if self._posed else off
+        self._idft_off = {}
+        for i in self._posed:
+            self._idft_off[i] = off
+            off += self.segments[i].fourier_dim
+        self._row = off
+        self._bufs = [torch.zeros(self.k, self._row, dtype=torch.float32, device=dev) for _ in range(2)]
+        self._free_ev = [None, None]  # event on the side stream: "the all-gather that read buffer b is done"
+        self._cur = 0
+        self._mine = self._bufs[0]
+        self._all = torch.zeros(self.world * self.k, self._row, dtype=torch.float32, device=dev)
+        self._frame = (list(range(len(self.segments))), {})
         self._rast = _rast
         _rast.BACKWARD_OBSERVERS.append(self._observe)
 
+    # legacy attribute (bench.py, tests): the single static model's positions
+    @property
+    def means3D(self):
+        return self.segments[0].means
+
+    def set_frame(self, models: Sequence[int], idft: Optional[dict] = None) -> None:
+        """Declares the NEXT rasterizer backward's frame: the indices (into ``segments``) of the sub-models it renders,
+        in rasterization order (the reference's per-frame graph_obj_list, street_gaussian_model.py:230-250), and for
+        posed segments with fourier_dim > 1 their Fourier mix of this frame, ``idft[i]`` = [fourier_dim]
+        (gaussian_model_actor.py:71-80: features_dc is mixed over its fourier dimension by the frame's IDFT row)."""
+        self._frame = ([int(m) for m in models], dict(idft or {}))
+
     # -- rasterizer backward hook --
-    def _observe(self, grad_colors, geomBuffer, campos, sh_degree, num_points):
+    def _observe(self, grad_colors, geomBuffer, campos, sh_degree, num_points, means3D=None):
         # the hook list is process-wide: passes over another Gaussian set (the reference's training step also renders
         # single objects, street_gaussian_renderer.render_object) are not this reducer's business
-        if int(num_points) != int(self.means3D.shape[0]):
+        models, idft = self._frame
+        if int(num_points) != sum(self.segments[m].n for m in models):
             return
         if len(self._pending) >= self.k:
             raise RuntimeError(f"more than views_per_rank={self.k} rasterizer backward passes since the last exchange")
@@ -196,9 +289,35 @@ class FactoredGradReducer:
         else:
             from . import _C
             drgb = _C.masked_color_grad(geomBuffer, grad_colors, num_points)
-        slot = self._mine[len(self._pending)]
+        buf = self._bufs[self._cur]
+        ev = self._free_ev[self._cur]
+        if ev is not None and len(self._pending) == 0:
+            torch.cuda.current_stream(buf.device).wait_event(ev)  # the exchange that read this buffer has finished
+            self._free_ev[self._cur] = None
+        slot = buf[len(self._pending)]
+        whole = len(models) == len(self.segments) and models == self._static + self._posed and not self._posed
+        if not whole:
+            slot.zero_()  # segments this frame does not render contribute zeros
         slot[:3].copy_(campos.reshape(3))
-        slot[3:].copy_(drgb.reshape(-1))
+        src = 0
+        for m in models:
+            sg = self.segments[m]
+            n = sg.n
+            o = self._drgb_off[m]
+            slot[o:o + 3 * n].copy_(drgb[src:src + n].reshape(-1))
+            if sg.posed:
+                if means3D is None:
+                    raise RuntimeError("posed segments need the rasterizer's means3D (world positions of this frame)")
+                o = self._pos_off[m]
+                slot[o:o + 3 * n].copy_(means3D.detach()[src:src + n].reshape(-1))
+                o, C = self._idft_off[m], sg.fourier_dim
+                if C == 1 and m not in idft:
+                    slot[o:o + 1].fill_(1.0)
+                else:
+                    if m not in idft:
+                        raise RuntimeError(f"set_frame: segment {m} has fourier_dim {C} and needs its idft row")
+                    slot[o:o + C].copy_(torch.as_tensor(idft[m], dtype=torch.float32).reshape(C))
+            src += n
         self._pending.append(int(sh_degree))
 
     @property
@@ -219,58 +338,97 @@ class FactoredGradReducer:
 
     def begin(self) -> None:
         """Non-blocking start: the dense bucket's all-reduce and the all-gather of the per-view dRGB go to the side stream."""
+        if getattr(self, "_begun", False):
+            raise RuntimeError("begin() called twice without wait()")
         if len(self._pending) != self.k:
             raise RuntimeError(f"expected {self.k} rasterizer backward passes before the exchange, saw {len(self._pending)}")
         self._degree = self._pending[0]
         self._pending = []
         self._gather_works = []
         self._begun = True
+        mine = self._mine = self._bufs[self._cur]
+        sent = self._cur
+        self._cur ^= 1  # rasterizer backward passes from now on fill the other buffer
         if self.world == 1 and not self.force:
-            return  # shs.grad of the single view is already the sum
+            self._all.copy_(mine)  # one rank: its own views are all the views
+            return
         self.dense.begin()
         if self.world > 1 or dist.is_initialized():
             side = self.dense._side
             if side is not None:
-                side.wait_stream(torch.cuda.current_stream(self._mine.device))
+                side.wait_stream(torch.cuda.current_stream(mine.device))
                 with torch.cuda.stream(side):
-                    self._gather_works = [dist.all_gather_into_tensor(self._all, self._mine, group=self.group, async_op=True)]
+                    self._gather_works = [dist.all_gather_into_tensor(self._all, mine, group=self.group, async_op=True)]
+                    for w in self._gather_works:
+                        w.wait()  # stream order on RCCL, no host block
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    self._free_ev[sent] = ev
             else:
-                self._gather_works = [dist.all_gather_into_tensor(self._all, self._mine, group=self.group, async_op=True)]
+                self._gather_works = [dist.all_gather_into_tensor(self._all, mine, group=self.group, async_op=True)]
         else:
-            self._all.copy_(self._mine)
+            self._all.copy_(mine)
+
+    def _rebuild(self, n, means, means_stride, col0, V):
+        """sum_v Y(dir_v) (x) dRGB_v for the n Gaussians whose dRGB sits at column col0 of the gathered rows -> [n, M, 3]."""
+        A, row = self._all, self._row
+        if self._rebuild_fn is not None:  # test path (CPU tensors): contiguous copies, same arithmetic
+            drgb = A[:, col0:col0 + 3 * n].reshape(V, n, 3)
+            m = means.detach() if means_stride == 0 else A[:, means:means + 3 * n].reshape(V, n, 3)
+            return self._rebuild_fn(m, A[:, :3].contiguous(), drgb, self._degree, self.M).view(n, self.M, 3)
+        from . import _C
+        base = A.data_ptr()
+        if means_stride == 0:
+            mt = means.detach()
+            mt = mt if (mt.dtype == torch.float32 and mt.is_contiguous()) else mt.float().contiguous()
+            mp = mt.data_ptr()
+        else:
+            mp = base + 4 * means
+        return _C.sh_grad_from_rows(n, self._degree, self.M, V, mp, means_stride, base, row, base + 4 * col0, row, A.device)
 
     def wait(self) -> None:
         """Joins the exchange and rebuilds dL/dSH = sum over all views of Y(dir_v) (x) dRGB_v on the compute stream."""
         if not getattr(self, "_begun", False):
             return
         self._begun = False
-        if self.world == 1 and not self.force:
-            return
-        side = self.dense._side
-        if side is not None:
-            with torch.cuda.stream(side):
+        if self.world > 1 or self.force:
+            side = self.dense._side
+            if side is None:
                 for w in self._gather_works:
                     w.wait()
-        else:
-            for w in self._gather_works:
-                w.wait()
-        self._gather_works = []
-        self.dense.wait()  # also makes the compute stream wait for the side stream
+            self._gather_works = []
+            self.dense.wait()  # also makes the compute stream wait for the side stream
         V = self._all.shape[0]
-        P, M = self.means3D.shape[0], self.M
-        campos = self._all[:, :3].contiguous()
-        drgb = self._all[:, 3:].reshape(V, P, 3)
-        if self._rebuild_fn is not None:
-            grad = self._rebuild_fn(self.means3D.detach(), campos, drgb, self._degree, M)
-        else:
-            from . import _C
-            grad = _C.sh_grad_from_views(self.means3D.detach(), campos, drgb, self._degree, M)
-        grad = grad.view(P, M, 3)
-        off = 0
-        for t in self.shs_parts:  # one parameter, or the reference's (features_dc, features_rest) pair
-            m = int(t.shape[1])
-            t.grad = grad[:, off:off + m, :] if len(self.shs_parts) > 1 else grad.view_as(t)
-            off += m
+        M = self.M
+        # static models: one launch each (their positions are local leaves); every posed model in ONE launch over the
+        # concatenated posed block (positions per view from the payload)
+        grads = {}
+        for i in self._static:
+            sg = self.segments[i]
+            grads[i] = self._rebuild(sg.n, sg.means, 0, self._drgb_off[i], V)
+        if self._posed:
+            g_all = self._rebuild(self._n_posed, self._pos0, self._row, self._posed_drgb0, V)
+            o = 0
+            for i in self._posed:
+                grads[i] = g_all[o:o + self.segments[i].n]
+                o += self.segments[i].n
+        for i, sg in enumerate(self.segments):
+            g = grads[i]
+            if self._single is not None:
+                self._single.grad = g.view_as(self._single)
+                continue
+            if sg.features_rest is not None:
+                sg.features_rest.grad = g[:, 1:, :]
+            if not sg.posed:
+                sg.features_dc.grad = g[:, :1, :]
+                continue
+            # posed segment: features_dc is mixed over its fourier dimension by the frame's IDFT row, so
+            # dL/dfeatures_dc[:, f, :] = sum_v idft_v[f] * Y_0 * dRGB_v (fourier_dim 1 with idft = 1 is the plain DC row)
+            C = sg.fourier_dim
+            o, d0 = self._idft_off[i], self._drgb_off[i]
+            mix = self._all[:, o:o + C]                                   # [V, C]
+            drgb = self._all[:, d0:d0 + 3 * sg.n].reshape(V, sg.n, 3)      # [V, n, 3]
+            sg.features_dc.grad = 0.28209479177387814 * torch.einsum("vf,vnc->nfc", mix, drgb)
 
     def all_reduce(self) -> None:
         self.begin()

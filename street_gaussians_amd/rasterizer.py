@@ -25,6 +25,15 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, semantics, opaciti
                                      cov3Ds_precomp, raster_settings, stats)
 
 
+# extension (not in the reference): the number of tile instances R of this process' most recent forward -- the reference
+# keeps it inside the autograd context only (__init__.py:93); bench.py and the densify-loop test report it
+_LAST = {"num_rendered": 0}
+
+
+def last_num_rendered() -> int:
+    return int(_LAST["num_rendered"])
+
+
 # callables invoked at the end of every rasterizer backward with that view's dL/dcolour, geometry buffer and camera
 # centre; empty unless a multiview.FactoredGradReducer is alive (extension, not part of the reference API)
 BACKWARD_OBSERVERS = []
@@ -53,6 +62,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             (num_rendered, color, depth, alpha, semantic, radii, geomBuffer, binningBuffer,
              imgBuffer) = _C.rasterize_gaussians(*args)
 
+        _LAST["num_rendered"] = num_rendered
         ctx.raster_settings = raster_settings
         ctx.stats = stats  # extension: densification statistics updated by the backward (GaussianRasterizer.stats_sink)
         ctx.num_rendered = num_rendered
@@ -100,7 +110,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         for observer in list(BACKWARD_OBSERVERS):  # view-sharded training (multiview.FactoredGradReducer)
             observer(grad_colors=grad_colors_precomp, geomBuffer=geomBuffer, campos=raster_settings.campos,
-                     sh_degree=raster_settings.sh_degree, num_points=means3D.shape[0])
+                     sh_degree=raster_settings.sh_degree, num_points=means3D.shape[0], means3D=means3D)
 
         # same order as the reference (__init__.py:152-163); gradients of inputs that do not take part in
         # autograd (None / empty placeholders) are dropped instead of returned and ignored

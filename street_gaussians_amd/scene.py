@@ -220,7 +220,8 @@ class FlatStats:
     the reference's GaussianModel) kept as VIEWS of three flat tensors in concatenation order -- the layout the
     rasterizer's backward updates in place when ``GaussianRasterizer.stats_sink = stats.sink()`` is set
     (include/sgr.h: sgr_backward_ex), so that ``set_max_radii2D`` + ``add_densification_stats``
-    (street_gaussian_model.py:551-571) cost nothing extra.  After a densification step the point counts change:
+    (street_gaussian_model.py:551-571) cost nothing extra.  A frame that renders only some of the models passes ``sink(models=[...])``.  After a densification step the
+    point counts change:
     build a new FlatStats (the reference re-creates the three tensors as zeros there as well, gaussian_model.py:545-547).
     """
 
@@ -231,8 +232,23 @@ class FlatStats:
         self.denom = torch.zeros(n, 1, dtype=torch.float32, device=device)
         self.max_radii2D = torch.zeros(n, dtype=torch.float32, device=device)
 
-    def sink(self):
-        return self.xyz_gradient_accum, self.denom, self.max_radii2D
+    def sink(self, models: Optional[Sequence[int]] = None):
+        """The value for ``GaussianRasterizer.stats_sink``.  ``models`` = the indices (into ``counts``) of the sub-models
+        this frame renders, in rasterization order -- the reference rebuilds that list per frame
+        (street_gaussian_model.py:230-250: background + the actors visible at the timestamp), so the rasterized set is
+        in general a subset / re-ordering of the persistent models.  None = every model, in order (a static graph)."""
+        if models is None:
+            return self.xyz_gradient_accum, self.denom, self.max_radii2D
+        starts = [0]
+        for c in self.counts:
+            starts.append(starts[-1] + c)
+        segs, src = [], 0
+        for m in models:
+            c = self.counts[m]
+            if c:
+                segs.append((src, c, starts[m]))
+            src += c
+        return self.xyz_gradient_accum, self.denom, self.max_radii2D, segs
 
     def views(self) -> List[dict]:
         out, start = [], 0

@@ -147,3 +147,101 @@ def test_factored_grad_reducer_world2():
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok in res), res
+
+
+def _segments_worker(rank, world, port, q):
+    """A scene graph of one static model + two posed models (fourier_dim 2); the ranks render DIFFERENT frames: other
+    actor poses, other Fourier mixes, and rank 1's frame does not contain actor 2 at all."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import torch_ref
+    from street_gaussians_amd import multiview, rasterizer
+    M, deg, C = 16, 3, 2
+    n = [301, 57, 40]
+    g = torch.Generator().manual_seed(21)
+    bk_means = torch.randn(n[0], 3, generator=g) * 3 + torch.tensor([0.0, 0.0, 10.0])
+    local = [None, torch.randn(n[1], 3, generator=g), torch.randn(n[2], 3, generator=g)]
+    leaf = lambda *s: torch.zeros(*s, requires_grad=True)
+    segs = [multiview.SHSegment(leaf(n[0], 1, 3), leaf(n[0], M - 1, 3), bk_means),
+            multiview.SHSegment(leaf(n[1], C, 3), leaf(n[1], M - 1, 3), None),
+            multiview.SHSegment(leaf(n[2], C, 3), leaf(n[2], M - 1, 3), None)]
+    dense = [torch.zeros(sum(n), 3, requires_grad=True)]
+    # per rank (= per view): frame layout, actor translations, idft rows, camera, upstream colour gradients, clamp masks
+    frames = [[0, 1, 2], [0, 1]]
+    trans = torch.randn(world, 3, 3, generator=g) * 2 + torch.tensor([0.0, 0.0, 8.0])
+    idft = torch.randn(world, 3, C, generator=g)
+    campos = torch.randn(world, 3, generator=g)
+    ok = True
+    exp_rest = [torch.zeros(k, M - 1, 3, dtype=torch.float64) for k in n]
+    exp_dc = [torch.zeros(n[0], 1, 3, dtype=torch.float64), torch.zeros(n[1], C, 3, dtype=torch.float64),
+              torch.zeros(n[2], C, 3, dtype=torch.float64)]
+    views = []
+    for v in range(world):
+        Pf = sum(n[m] for m in frames[v])
+        colors = torch.randn(Pf, 3, generator=g)
+        clamp = torch.rand(Pf, 3, generator=g) < 0.2
+        pos = torch.cat([bk_means if m == 0 else local[m] + trans[v, m] for m in frames[v]])
+        views.append((colors, clamp, pos))
+        # float64 reference: d/d(leaves) of sum <SH->RGB(dir), dRGB> with the composed SH = cat over the frame's models,
+        # actors' DC mixed by the frame's idft row (gaussian_model_actor.py:71-80)
+        src = 0
+        for m in frames[v]:
+            dc = torch.zeros(n[m], exp_dc[m].shape[1], 3, dtype=torch.float64, requires_grad=True)
+            rest = torch.zeros(n[m], M - 1, 3, dtype=torch.float64, requires_grad=True)
+            dc_mixed = dc if m == 0 else (idft[v, m].double()[None, :, None] * dc).sum(1, keepdim=True)
+            shs = torch.cat([dc_mixed, rest], 1)
+            d = pos[src:src + n[m]].double() - campos[v].double()
+            d = d / d.norm(dim=1, keepdim=True)
+            drgb = (colors * (~clamp).float())[src:src + n[m]].double()
+            (torch_ref.sh_to_rgb(deg, shs, d) * drgb).sum().backward()
+            exp_dc[m] += dc.grad
+            exp_rest[m] += rest.grad
+            src += n[m]
+    with multiview.FactoredGradReducer(dense, segments=segs, mask_fn=lambda geom, gc, k: gc * (~geom).float(),
+                                       rebuild_fn=_rebuild_ref_pv) as red:
+        for rnd in range(2):  # twice: the payload is double-buffered
+            colors, clamp, pos = views[rank]
+            red.set_frame(frames[rank], idft={m: idft[rank, m] for m in frames[rank] if m != 0})
+            for obs in list(rasterizer.BACKWARD_OBSERVERS):
+                obs(grad_colors=colors, geomBuffer=clamp, campos=campos[rank], sh_degree=deg, num_points=colors.shape[0],
+                    means3D=pos)
+            dense[0].grad = torch.full_like(dense[0], float(rank + 1))
+            red.begin()
+            if rnd == 0:  # a backward between begin() and wait() (overlap schedule) fills the OTHER buffer
+                for obs in list(rasterizer.BACKWARD_OBSERVERS):
+                    obs(grad_colors=colors * 0 + 77.0, geomBuffer=clamp, campos=campos[rank], sh_degree=deg,
+                        num_points=colors.shape[0], means3D=pos)
+                red._pending = []  # (that pass is discarded by this test)
+            red.wait()
+            for m, sg in enumerate(segs):
+                ok &= torch.allclose(sg.features_rest.grad.double(), exp_rest[m], atol=2e-5)
+                ok &= torch.allclose(sg.features_dc.grad.double(), exp_dc[m], atol=2e-5)
+            ok &= bool((dense[0].grad == 3.0).all())
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def _rebuild_ref_pv(means3D, campos, drgb, degree, M):
+    """_rebuild_ref with per-view positions ([V, n, 3]) for posed models."""
+    if means3D.dim() == 2:
+        return _rebuild_ref(means3D, campos, drgb, degree, M)
+    out = 0
+    for v in range(campos.shape[0]):
+        out = out + _rebuild_ref(means3D[v], campos[v:v + 1], drgb[v:v + 1], degree, M)
+    return out
+
+
+def test_factored_grad_reducer_scene_segments_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_segments_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res

@@ -4,6 +4,7 @@ import struct
 from collections import OrderedDict
 
 import numpy as np
+import pytest
 
 from street_gaussians_amd import plyio
 
@@ -122,3 +123,42 @@ def test_checkpoint_layout_of_the_reference():
         assert torch.equal(again["obj_001"][k], st["obj_001"][k]), k
     final = checkpoint.state_from_models(models, is_final=True)
     assert "denom" not in final["background"]
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/lib/models/gaussian_model.py"), reason="reference checkout not present")
+def test_saved_checkpoint_is_loadable_by_the_reference_load_state_dict(tmp_path):
+    """checkpoint.save writes nn.Parameter entries (requires_grad) like the reference's state_dict does: the reference's
+    OWN GaussianModel.load_state_dict (gaussian_model.py:157-180), cut out of its source and executed on a stub in train
+    mode, assigns them as the model's parameters and builds an optimiser over them."""
+    import re
+    import types
+    import torch
+    from street_gaussians_amd import checkpoint
+    models = checkpoint.load(os.path.join(GOLD, "scene_ref_state.pth"))
+    out = str(tmp_path / "ours.pth")
+    checkpoint.save(out, models, is_final=True, iteration=12)
+    st = torch.load(out, weights_only=False)  # as train.py / render.py read it: no map_location
+    src = open("/root/reference/lib/models/gaussian_model.py").read()
+    m = re.search(r"^    def load_state_dict\(self.*?(?=^    def |\Z)", src, re.S | re.M).group(0)
+    body = "\n".join(ln[4:] if ln.startswith("    ") else ln for ln in m.split("\n"))
+    ns = {"cfg": types.SimpleNamespace(mode="train"), "torch": torch}
+    exec(body, ns)
+
+    class Stub:
+        def training_setup(self):  # gaussian_model.py:258-286: an Adam over the seven parameters
+            self.optimizer = torch.optim.Adam([{"params": [p], "name": n} for n, p in (
+                ("xyz", self._xyz), ("f_dc", self._features_dc), ("f_rest", self._features_rest), ("opacity", self._opacity),
+                ("scaling", self._scaling), ("rotation", self._rotation), ("semantic", self._semantic))], lr=1e-3)
+
+    for name in ("background", "obj_001"):
+        stub = Stub()
+        ns["load_state_dict"](stub, st[name])
+        for attr, ours in (("_xyz", "xyz"), ("_features_dc", "features_dc"), ("_features_rest", "features_rest"),
+                           ("_scaling", "scaling"), ("_rotation", "rotation"), ("_opacity", "opacity"), ("_semantic", "semantic")):
+            p = getattr(stub, attr)
+            assert isinstance(p, torch.nn.Parameter) and p.requires_grad and p.is_leaf
+            assert torch.equal(p.detach(), models[name][ours].float())
+        # the optimiser training_setup builds can take a step on them
+        (stub._xyz.sum() + stub._opacity.sum()).backward()
+        stub.optimizer.step()
+    assert st["iter"] == 12
