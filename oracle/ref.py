@@ -23,14 +23,30 @@ INTERNAL = {"depths": (0, torch.float32, 1), "clamped": (1, torch.uint8, 3), "me
             "tiles_touched": (6, torch.int32, 1), "point_offsets": (7, torch.int32, 1)}
 
 
-def available() -> bool:
-    return os.path.exists(LIB_PATH)
+FMAD_LIB_PATH = os.path.join(_HERE, "_ref", "libref_rasterizer_fmad.so")
+_libs = {}
+_variant = "strict"
+
+
+def available(variant: str = "strict") -> bool:
+    return os.path.exists(LIB_PATH if variant == "strict" else FMAD_LIB_PATH)
+
+
+def use(variant: str) -> None:
+    """Selects which build of the reference's kernels the functions below call: "strict" = compiled with
+    -ffp-contract=off (bit-comparable with the C oracle), "fmad" = the compiler's default contraction, as the reference's
+    own toolchain builds it (nvcc --fmad=true): another valid rounding of the same sources (oracle/ref_build.sh)."""
+    global _variant, _lib
+    assert variant in ("strict", "fmad")
+    _variant = variant
+    _lib = _libs.get(variant)
 
 
 def lib():
     global _lib
     if _lib is None:
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(LIB_PATH if _variant == "strict" else FMAD_LIB_PATH)
+        _libs[_variant] = L
         L.ref_forward.restype = C.c_void_p
         L.ref_internal.restype = C.c_void_p
         L.ref_internal.argtypes = [C.c_void_p, C.c_int]

@@ -312,7 +312,7 @@ def distCUDA2(points):
 
 
 _EXPORT = {"depths": (0, torch.float32, lambda P, R, N, T: (P,)), "clamped": (1, torch.uint8, lambda P, R, N, T: (P, 3)),
-           "means2D": (2, torch.float32, lambda P, R, N, T: (P, 2)), "cov3D": (3, torch.float32, lambda P, R, N, T: (P, 6)),
+           "means2D": (2, torch.float32, lambda P, R, N, T: (P, 2)),
            "conic_opacity": (4, torch.float32, lambda P, R, N, T: (P, 4)), "rgb": (5, torch.float32, lambda P, R, N, T: (P, 3)),
            "tiles_touched": (6, torch.int32, lambda P, R, N, T: (P,)), "point_offsets": (7, torch.int32, lambda P, R, N, T: (P,)),
            "point_list": (8, torch.int32, lambda P, R, N, T: (R,)), "keys": (9, torch.int64, lambda P, R, N, T: (R,)),

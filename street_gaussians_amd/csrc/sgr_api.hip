@@ -18,11 +18,10 @@ void sgr_launch_mark_visible(int P, const float* means3D, const float* viewmatri
 void sgr_launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, const float* rotations,
                            const float* opacities, const float* shs, const float* cov3D_precomp,
                            const float* colors_precomp, const SgrCam* cam, const SgrGeomView& gv, int* radii,
-                           int prefiltered, hipStream_t s);
+                           int prefiltered, bool stage_sh, hipStream_t s);
 void sgr_launch_filter(int P, const float* means3D, const float* scales, const float* rotations,
                        const float* cov3D_precomp, const SgrCamArgs& ca, const SgrGeomView& gv, int* radii,
                        float* means2D, int prefiltered, hipStream_t s);
-void sgr_launch_gather_tiles(int P, const uint32_t* order, const uint32_t* tiles_touched, uint32_t* tt_sorted, hipStream_t s);
 void sgr_launch_duplicate(int P, const SgrGeomView& gv, const uint32_t* order, const uint32_t* offs_incl, uint32_t* keys,
                           uint32_t* vals, int gx, hipStream_t s);
 void sgr_launch_tile_ranges(int L, const uint32_t* keys, uint2* ranges, uint8_t* touched, hipStream_t s);
@@ -34,7 +33,7 @@ void sgr_launch_blend_fwd(bool cull, int gx, int gy, const uint2* ranges, const 
                           hipStream_t s);
 int sgr_partial_row_stride(int S);
 void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, bool v2, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
-                          int H, int S, const float* bg, const float4* rec, const float* semantics, const float* alphas,
+                          int H, int S, const float* bg, const float4* rec, const uint32_t* u0, const float* semantics, const float* alphas,
                           const uint32_t* n_contrib, const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth,
                           const float* dL_dalpha, const float* dL_dsem, float* partials, uint8_t* touched, hipStream_t s);
 void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const int* radii, const float* shs,
@@ -69,7 +68,8 @@ static int switches() {
     int v = g_switches.load(std::memory_order_relaxed);
     if (v < 0) {
         v = (env_flag("SGR_NO_CULL") ? 1 : 0) | (env_flag("SGR_NO_DPP") ? 2 : 0) | (env_flag("SGR_NO_DET") ? 4 : 0) |
-            (env_flag("SGR_NO_HITS") ? 8 : 0) | (env_flag("SGR_V2") ? 16 : 0);
+            (env_flag("SGR_NO_HITS") ? 8 : 0) | (env_flag("SGR_V2") ? 16 : 0) | (env_flag("SGR_PRE_STAGE") ? 64 : 0) |
+            (env_flag("SGR_SW7") ? 128 : 0) | (env_flag("SGR_SW8") ? 256 : 0) | (env_flag("SGR_SW9") ? 512 : 0);
         g_switches.store(v, std::memory_order_relaxed);
     }
     return v;
@@ -283,7 +283,7 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     SGR_STAGE("pack_camera");
 
     sgr_launch_preprocess(P, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
-                          cam_slot(gv), gv, radii_ptr, prefiltered, stream);
+                          cam_slot(gv), gv, radii_ptr, prefiltered, (switches() & 64) != 0, stream);
     SGR_STAGE("preprocess");
     prof_end(stream);
 
@@ -301,10 +301,14 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     // Depth pre-sort of the P Gaussians (32-bit keys, 4 passes over P elements), then K4: scan of tiles_touched in
     // that order.
     prof_begin(1, stream);
-    const int dcur = sgr_launch_sort_pairs32(gv.dkeys, gv.dvals, (uint32_t)P, 32, gv.dhist, gv.scan_tmp, stream);
+    // (the ids are not materialised before the sort: its first pass takes the element index as the value; its last
+    // pass also carries every Gaussian's {tiles_touched, tile rect} into depth order -- ONE fused 8-byte gather instead
+    // of three per-stage gathers through `order`: at 5 M Gaussians those read 0.6 GB each, rocprofv3 FETCH_SIZE)
+    const int dcur = sgr_launch_sort_pairs32(gv.dkeys, gv.dvals, (uint32_t)P, 32, gv.dhist, gv.scan_tmp, stream, true, gv.aux,
+                                             gv.aux_sorted);
     const uint32_t* order = gv.dvals[dcur];
-    // tiles_touched is read through `order` inside the scan (no gathered copy, one launch less)
-    sgr_launch_scan(gv.tiles_touched, gv.tt_sorted, (size_t)P, gv.scan_tmp, true, stream, nullptr, order);
+    sgr_launch_scan(reinterpret_cast<const uint32_t*>(gv.aux_sorted), gv.tt_sorted, (size_t)P, gv.scan_tmp, true, stream,
+                    nullptr, nullptr, 2);
     SGR_STAGE("depth_sort+scan");
     prof_end(stream);
     // The window between "R is known" and "the GPU runs out of queued work" is only the ~0.12 ms of sort + scan
@@ -465,7 +469,7 @@ int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, 
         // the forward's record of which (quadrant, instance) pairs blended at all; switch 8: the kernel redoes the
         // geometric cull instead (A/B and tests: the two walks must give bit-identical gradients)
         const uint8_t* hits = (sw & 8) ? nullptr : bv.hit4;
-        sgr_launch_blend_bwd(cull, dpp, det, (sw & 16) != 0, gx, gy, iv.ranges, bv.vals[cur], W, H, S, background, gv.rec, semantics,
+        sgr_launch_blend_bwd(cull, dpp, det, (sw & 16) != 0, gx, gy, iv.ranges, bv.vals[cur], W, H, S, background, gv.rec, gv.u0, semantics,
                              alphas, iv.n_contrib, hits, dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, partials,
                              touched, stream);
         SGR_STAGE("blend_bwd");
@@ -522,7 +526,7 @@ int sgr_sh_grad_from_views_ex(int P, int D, int M, int V, const float* means3D, 
 int sgr_test_switches(int mask) {
     const int prev = switches() | (sgr_sort_get_one_sweep() ? 32 : 0);
     if (mask >= 0) {
-        g_switches.store(mask & 31, std::memory_order_relaxed);
+        g_switches.store(mask & ~32, std::memory_order_relaxed);
         sgr_sort_set_one_sweep((mask >> 5) & 1);
     }
     return prev;
@@ -651,10 +655,9 @@ __global__ void sgr_export_kernel(int which, int P, SgrGeomView gv, void* dst) {
             ((uint8_t*)dst)[3 * i] = c & 1u; ((uint8_t*)dst)[3 * i + 1] = (c >> 1) & 1u; ((uint8_t*)dst)[3 * i + 2] = (c >> 2) & 1u;
         } break;
         case 2: { const float4 a = gv.rec[4 * (size_t)i]; ((float*)dst)[2 * i] = a.x; ((float*)dst)[2 * i + 1] = a.y; } break;
-        case 3: for (int k = 0; k < 6; k++) ((float*)dst)[6 * i + k] = gv.cov3D[6 * (size_t)i + k]; break;
         case 4: ((float4*)dst)[i] = gv.rec[4 * (size_t)i + 1]; break;
         case 5: { const float4 c = gv.rec[4 * (size_t)i + 2]; ((float*)dst)[3 * i] = c.x; ((float*)dst)[3 * i + 1] = c.y; ((float*)dst)[3 * i + 2] = c.z; } break;
-        case 6: ((uint32_t*)dst)[i] = gv.tiles_touched[i]; break;
+        case 6: ((uint32_t*)dst)[i] = gv.aux[i].x; break;
         case 7: ((uint32_t*)dst)[i] = gv.point_offsets[i]; break;
         case 14: { const float4 a = gv.rec[4 * (size_t)i]; ((float*)dst)[2 * i] = a.z; ((float*)dst)[2 * i + 1] = a.w; } break;
     }
@@ -669,8 +672,10 @@ int sgr_export_internal(int which, int P, int R, int width, int height, char* ge
     if (which <= 7 || which == 14) {
         if (P <= 0) return 0;
         const SgrGeomView gv = sgr_geom_carve(geom_buffer, (size_t)P);
+        if (which == 3) return fail(SGR_E_INVALID, "cov3D is not materialised (the backward recomputes it)");
         if (which == 7)  // the reference's index-order inclusive scan is not needed by the pipeline: made on demand
-            sgr_launch_scan(gv.tiles_touched, gv.point_offsets, (size_t)P, gv.scan_tmp, true, stream);
+            sgr_launch_scan(reinterpret_cast<const uint32_t*>(gv.aux), gv.point_offsets, (size_t)P, gv.scan_tmp, true, stream,
+                            nullptr, nullptr, 2);
         sgr_export_kernel<<<(P + 255) / 256, 256, 0, stream>>>(which, P, gv, dst);
         SGR_STAGE("export");
         return 0;

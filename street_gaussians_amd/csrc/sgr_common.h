@@ -8,10 +8,12 @@
 //     rec[4g+0] = {pix.x, pix.y, hx, hy}      2D mean + conservative half extents of the alpha>=1/255 ellipse
 //     rec[4g+1] = {conic.x, conic.y, conic.z, opacity}
 //     rec[4g+2] = {r, g, b, view depth}
-//     rec[4g+3] = {bits: exclusive tile offset, bits: packed tile rect, -, -}   (backward only)
+//     rec[4g+3] = {-, bits: packed tile rect, -, -}   (backward only)
 //     -> ONE 64-byte, 64-byte-aligned record per Gaussian: a tile kernel's gather of an instance touches
 //        a single cache line (three separate arrays cost three lines per instance: measured 2-4x over-fetch)
-//     cov3D[6g..], tiles_touched[g], point_offsets[g] (inclusive), clamped[g] (3-bit mask), radii (if not given)
+//     aux[g] = {tiles_touched, packed tile rect} (8 bytes; gathered into depth order by the depth sort's last pass),
+//     clamped[g] (3-bit mask), radii (if not given); cov3D is NOT stored: the backward recomputes it from scale and
+//     rotation with the same function (24 B/Gaussian less to write and to read back)
 //   binning buffer: 32-bit tile keys and 32-bit Gaussian ids, ping-pong for the stable LSD radix sort by
 //     tile (the instances are emitted in (depth, id) order, so the reference's 64-bit (tile|depth) key
 //     order falls out of a stable sort on the tile bits alone), plus the per-block digit histograms and one
@@ -34,12 +36,15 @@
 
 struct SgrGeomView {
     float4* rec;  // [4P]
-    float* cov3D;
-    uint32_t* tiles_touched;
+    uint2* aux;               // per Gaussian {tiles_touched, packed tile rect}; {0, 0} when culled
+    uint2* aux_sorted;        // the same in (depth, id) order (written by the last pass of the depth sort)
+    uint32_t* u0;             // per Gaussian: its first slot in depth order = its first partial-gradient row (written by
+                              // duplicate: 4-byte scatter into this compact array instead of into the 64-byte records)
     uint32_t* point_offsets;  // inclusive scan in index order: only materialised by sgr_export_internal (parity)
     uint32_t* dkeys[2];       // depth bits per Gaussian (0xffffffff = culled), ping-pong for the depth sort
-    uint32_t* dvals[2];       // Gaussian ids; after the sort dvals[cur] = ids in (depth, id) order
-    uint32_t* tt_sorted;      // tiles_touched in depth order, inclusive-scanned in place
+    uint32_t* dvals[2];       // Gaussian ids; after the sort dvals[cur] = ids in (depth, id) order (dvals[0] is never
+                              // written by the preprocess: the first pass takes the element index as the value)
+    uint32_t* tt_sorted;      // inclusive scan of tiles_touched in depth order
     uint32_t* dhist;          // digit histogram of the depth sort
     uint32_t* clamped;  // 3-bit mask per Gaussian, one u32 each (keeps stores simple and aligned)
     int* internal_radii;
@@ -108,8 +113,9 @@ static inline SgrGeomView sgr_geom_carve(char* base, size_t P, char** end = null
     size_t Pn = P ? P : 1;
     sgr_carve(p, v.header, 64);
     sgr_carve(p, v.rec, Pn * 4);
-    sgr_carve(p, v.cov3D, Pn * 6);
-    sgr_carve(p, v.tiles_touched, Pn);
+    sgr_carve(p, v.aux, Pn);
+    sgr_carve(p, v.aux_sorted, Pn);
+    sgr_carve(p, v.u0, Pn);
     sgr_carve(p, v.point_offsets, Pn);
     sgr_carve(p, v.clamped, Pn);
     sgr_carve(p, v.internal_radii, Pn);
@@ -178,15 +184,20 @@ SgrFlagBlock sgr_acquire_flag_block();
 // signature cannot leave a stale copy behind in another file --------------------------------------------------------
 // device-wide scan: out may alias in; tmp needs sgr_scan_tmp_count(n) words; tmp[nblocks] (and *total_out) receive the
 // grand total; gather != nullptr scans in[gather[i]] instead of in[i]
+// in_stride: element i is in[i * in_stride] (scan of one field of an array of records)
 void sgr_launch_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, bool inclusive, hipStream_t s,
-                     uint32_t* total_out = nullptr, const uint32_t* gather = nullptr);
+                     uint32_t* total_out = nullptr, const uint32_t* gather = nullptr, int in_stride = 1);
 // stable LSD radix sorts on key bits [0, end_bit); return the index (0/1) of the buffer pair holding the result
 int sgr_sort_get_one_sweep();
 void sgr_sort_set_one_sweep(int on);  // A/B: 1 = the one-sweep form instead of histogram + row scan + scatter per pass
 int sgr_launch_sort_pairs(uint64_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
                           uint32_t* scan_tmp, hipStream_t s);
+// iota: vals[0] is not read (value of element i = i); aux_in / aux_out: the last pass also gathers an 8-byte per-id record
+// into sorted order, aux_out[sorted position] = aux_in[value]
 int sgr_launch_sort_pairs32(uint32_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
-                            uint32_t* scan_tmp, hipStream_t s);
+                            uint32_t* scan_tmp, hipStream_t s, bool iota = false, const uint2* aux_in = nullptr,
+                            uint2* aux_out = nullptr);
+int sgr_sort_pass_count(int end_bit);  // passes (= buffer flips) of a sort on key bits [0, end_bit)
 
 // XCD-aware workgroup -> tile map.  The dispatcher places workgroup b on XCD b % 8 (observed, used for speed only),
 // and each XCD has a private 4 MiB L2.  A splat's instances live in neighbouring tiles, so neighbouring tiles

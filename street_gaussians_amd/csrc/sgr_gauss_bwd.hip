@@ -37,8 +37,8 @@ sgr_row_sum_kernel(int P, int S, const int* __restrict__ radii, SgrGeomView gv, 
     for (int k = 0; k < 4 * NV; k++) acc[k] = 0.f;
     const bool live = idx < P;  // P need not be a multiple of 16: keep whole quads alive for the DPP steps
     if (live && radii[idx] > 0) {
-        const uint32_t u0 = __float_as_uint(gv.rec[4 * (size_t)idx + 3].x);
-        const uint32_t n = gv.tiles_touched[idx];
+        const uint32_t u0 = gv.u0[idx];
+        const uint32_t n = gv.aux[idx].x;  // tiles_touched
         const uint8_t* flag = touched + u0;
         const float* rows = partials + (size_t)u0 * row_stride;
         auto add_row = [&](const float4 (&t)[NV]) __attribute__((always_inline)) {
@@ -178,18 +178,24 @@ sgr_gauss_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, con
     if (visible) {
         // K12: conic -> cov3D and the covariance part of dL/dmean (assigned)
         float cov3D[6];
-        const float* csrc = cov3D_precomp ? cov3D_precomp + 6 * (size_t)idx : gv.cov3D + 6 * (size_t)idx;
+        float sc[3] = {0.f, 0.f, 0.f}, rot[4] = {0.f, 0.f, 0.f, 0.f};
+        if (scales != nullptr) {
+            sc[0] = scales[3 * idx]; sc[1] = scales[3 * idx + 1]; sc[2] = scales[3 * idx + 2];
+            const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)idx);
+            rot[0] = q.x; rot[1] = q.y; rot[2] = q.z; rot[3] = q.w;
+        }
+        if (cov3D_precomp) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) cov3D[i] = csrc[i];
+            for (int i = 0; i < 6; i++) cov3D[i] = cov3D_precomp[6 * (size_t)idx + i];
+        } else {
+            // the forward does not store cov3D (24 B/Gaussian written there and read here): same function, same
+            // inputs, FP contraction off inside it -> the forward's value bit for bit (forward.cu:115-150)
+            sgr_cov3d(sc, cam.scale_modifier, rot, cov3D);
+        }
         sgr_cov2d_backward(p, cov3D, cam, acc[3], acc[4], acc[5], dcov, dmean);
         // K13: projection + depth paths (added)
         sgr_proj_depth_backward(p, cam, acc[0], acc[1], acc[10], dmean);
-        if (scales != nullptr) {
-            const float sc[3] = {scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]};
-            const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)idx);
-            const float rot[4] = {q.x, q.y, q.z, q.w};
-            sgr_cov3d_backward(sc, cam.scale_modifier, rot, dcov, dscale, drot);
-        }
+        if (scales != nullptr) sgr_cov3d_backward(sc, cam.scale_modifier, rot, dcov, dscale, drot);
         if (shs != nullptr) {
             const uint32_t cl = gv.clamped[idx];
             dRGB[0] = (cl & 1u) ? 0.f : acc[7];

@@ -28,16 +28,11 @@ sgr_mark_visible_kernel(int P, const float* __restrict__ means3D, const float* _
 }
 
 // ---- K2 / K3 ----------------------------------------------------------------------------------
-// One Gaussian; returns its tiles_touched (0 when culled).
-template <bool FILTER>
-__device__ __forceinline__ uint32_t
-sgr_preprocess_one(const int idx, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
-                   const float* __restrict__ rotations, const float* __restrict__ opacities,
-                   const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
-                   const float* __restrict__ colors_precomp, const SgrCam& cam, const SgrGeomView& gv,
-                   int* __restrict__ radii, float* __restrict__ filter_means2D, int prefiltered) {
-
-    const float p[3] = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+// Geometry of one Gaussian (cull, covariance, EWA projection): the part K2 and K3 share.
+__device__ __forceinline__ SgrProj
+sgr_preprocess_geom(const int idx, const float (&p)[3], const float* __restrict__ scales, const float* __restrict__ rotations,
+                    const float* __restrict__ cov3D_precomp, const SgrCam& cam, uint32_t* __restrict__ header,
+                    int prefiltered) {
     float tz;
     {
 #pragma clang fp contract(off)
@@ -55,131 +50,154 @@ sgr_preprocess_one(const int idx, int D, int M, const float* __restrict__ means3
             const float sc[3] = {scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]};
             const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)idx);
             const float rot[4] = {q.x, q.y, q.z, q.w};
-            sgr_cov3d(sc, cam.scale_modifier, rot, cov3D);
-            if (!FILTER) {
-#pragma unroll
-                for (int i = 0; i < 6; i++) gv.cov3D[6 * (size_t)idx + i] = cov3D[i];
-            }
+            sgr_cov3d(sc, cam.scale_modifier, rot, cov3D);  // not stored: the backward recomputes it (same function)
         }
         pr = sgr_project(p, cov3D, cam);
     } else if (prefiltered) {
-        if (gv.header) atomicOr(&gv.header[0], 1u);  // reference: printf + __trap() (auxiliary.h:156-161); we raise on the host
+        if (header) atomicOr(&header[0], 1u);  // reference: printf + __trap() (auxiliary.h:156-161); we raise on the host
     }
-
-    if (!FILTER) gv.dvals[0][idx] = (uint32_t)idx;
-    if (!pr.ok) {
-        radii[idx] = 0;
-        if (!FILTER) {
-            gv.tiles_touched[idx] = 0;
-            gv.dkeys[0][idx] = 0xffffffffu;  // sorts behind every real depth (> 0.2 => sign bit clear)
-        }
-        return 0;
-    }
-    if (FILTER) {
-        radii[idx] = pr.radius;
-        filter_means2D[2 * idx] = pr.px;
-        filter_means2D[2 * idx + 1] = pr.py;
-        return 0;
-    }
-
-    // colour: precomputed, or SH -> RGB (forward.cu:20-71)
-    float rgb[3];
-    uint32_t clamped = 0;
-    if (colors_precomp != nullptr) {
-        rgb[0] = colors_precomp[3 * idx];
-        rgb[1] = colors_precomp[3 * idx + 1];
-        rgb[2] = colors_precomp[3 * idx + 2];
-    } else {
-#pragma clang fp contract(off)
-        float dx = p[0] - cam.campos[0], dy = p[1] - cam.campos[1], dz = p[2] - cam.campos[2];
-        const float t0 = dx * dx, t1 = dy * dy, t2 = dz * dz;
-        const float len = sqrtf(t0 + t1 + t2);
-        dx = dx / len; dy = dy / len; dz = dz / len;
-        float Y[16];
-        sgr_sh_basis(D, dx, dy, dz, Y);
-        const int ncoef = (D + 1) * (D + 1);
-        const float* sh = shs + (size_t)idx * M * 3;
-        float r = 0.f, g = 0.f, b = 0.f;
-        if (((M * 3) & 3) == 0) {
-            // row stride is a multiple of 16 B: stream the row as float4 (12 loads at SH degree 3)
-            const float4* sh4 = reinterpret_cast<const float4*>(sh);
-            const int n4 = (ncoef * 3 + 3) >> 2;
-            float buf[48];
-#pragma unroll
-            for (int i = 0; i < 12; i++) {
-                if (i < n4) {
-                    const float4 t = sh4[i];
-                    buf[4 * i] = t.x; buf[4 * i + 1] = t.y; buf[4 * i + 2] = t.z; buf[4 * i + 3] = t.w;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                if (k < ncoef) {
-                    if (k == 0) { r = Y[0] * buf[0]; g = Y[0] * buf[1]; b = Y[0] * buf[2]; }
-                    else { r = r + Y[k] * buf[3 * k]; g = g + Y[k] * buf[3 * k + 1]; b = b + Y[k] * buf[3 * k + 2]; }
-                }
-            }
-        } else {
-            for (int k = 0; k < ncoef; k++) {
-                if (k == 0) { r = Y[0] * sh[0]; g = Y[0] * sh[1]; b = Y[0] * sh[2]; }
-                else { r = r + Y[k] * sh[3 * k]; g = g + Y[k] * sh[3 * k + 1]; b = b + Y[k] * sh[3 * k + 2]; }
-            }
-        }
-        r += 0.5f; g += 0.5f; b += 0.5f;
-        clamped = (r < 0 ? 1u : 0u) | (g < 0 ? 2u : 0u) | (b < 0 ? 4u : 0u);
-        rgb[0] = fmaxf(r, 0.0f); rgb[1] = fmaxf(g, 0.0f); rgb[2] = fmaxf(b, 0.0f);
-    }
-
-    const float opacity = opacities[idx];
-    float hx, hy;
-    sgr_extent(opacity, pr.cov_a, pr.cov_c, pr.con_x, pr.con_y, pr.con_z, hx, hy);
-    const uint32_t w = pr.rx1 - pr.rx0, h = pr.ry1 - pr.ry0;
-    float4* rec = gv.rec + 4 * (size_t)idx;
-    rec[0] = make_float4(pr.px, pr.py, hx, hy);
-    rec[1] = make_float4(pr.con_x, pr.con_y, pr.con_z, opacity);
-    rec[2] = make_float4(rgb[0], rgb[1], rgb[2], pr.depth);
-    rec[3] = make_float4(0.f, __uint_as_float(sgr_pack_rect(pr.rx0, pr.ry0, w)), 0.f, 0.f);
-    gv.clamped[idx] = clamped;
-    gv.tiles_touched[idx] = w * h;
-    gv.dkeys[0][idx] = __float_as_uint(pr.depth);
-    radii[idx] = pr.radius;
-    return w * h;
+    return pr;
 }
 
+// K3 (visible_filter): radii + means2D only.  The matrices are read from the caller's device arrays (wave-uniform
+// addresses: scalar loads), the scalars travel as kernel arguments -- no allocation, no sync.
+__global__ void __launch_bounds__(SGR_PRE_THREADS)
+sgr_filter_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ scales,
+                  const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, uint32_t* __restrict__ header,
+                  int* __restrict__ radii, float* __restrict__ filter_means2D, int prefiltered, SgrCamArgs ca) {
+    const int idx = blockIdx.x * SGR_PRE_THREADS + threadIdx.x;
+    SgrCam cam;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { cam.view[i] = ca.view[i]; cam.proj[i] = ca.proj[i]; }
+    cam.campos[0] = cam.campos[1] = cam.campos[2] = 0.f;
+    cam.tan_fovx = ca.tan_fovx; cam.tan_fovy = ca.tan_fovy; cam.focal_x = ca.focal_x; cam.focal_y = ca.focal_y;
+    cam.W = ca.W; cam.H = ca.H; cam.gx = ca.gx; cam.gy = ca.gy; cam.scale_modifier = ca.scale_modifier;
+    if (idx >= P) return;
+    const float p[3] = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+    const SgrProj pr = sgr_preprocess_geom(idx, p, scales, rotations, cov3D_precomp, cam, header, prefiltered);
+    if (!pr.ok) { radii[idx] = 0; return; }
+    radii[idx] = pr.radius;
+    filter_means2D[2 * idx] = pr.px;
+    filter_means2D[2 * idx + 1] = pr.py;
+}
+
+// K2.  One Gaussian per lane.  The SH rows of a wave's 64 Gaussians are one contiguous 12 KB block (M = 16): per-lane
+// float4 loads at a 192-byte stride touch 64 cache lines per instruction, so -- once the geometry has decided which
+// Gaussians survive the cull -- the wave copies the rows of the survivors into LDS with coalesced 1 KB transfers
+// (rows of culled Gaussians are skipped float4 by float4) and every lane reads its own row from there.
 // num_rendered = sum of tiles_touched does not depend on the depth order, so it is accumulated here (one atomic per
 // workgroup into header[1]) and the host can read it back while the depth sort and the offset scan are still running.
-template <bool FILTER>
 __global__ void __launch_bounds__(SGR_PRE_THREADS)
 sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
                       const float* __restrict__ rotations, const float* __restrict__ opacities,
                       const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
                       const float* __restrict__ colors_precomp, const SgrCam* __restrict__ camp, SgrGeomView gv,
-                      int* __restrict__ radii, float* __restrict__ filter_means2D, int prefiltered, SgrCamArgs ca) {
-    const int idx = blockIdx.x * SGR_PRE_THREADS + threadIdx.x;
-    uint32_t n = 0;
-    if (FILTER) {
-        // K3 has no geometry buffer to keep a packed camera in: the matrices are read from the caller's device arrays
-        // (wave-uniform addresses: scalar loads), the scalars travel as kernel arguments -- no allocation, no sync
-        SgrCam cam;
+                      int* __restrict__ radii, int prefiltered, int stage_sh) {
+    // rows padded to 13 float4 (52 dwords): the per-lane float4 reads of 16 consecutive rows then fall on 16 disjoint
+    // 4-bank groups (a 48-dword stride puts them on 4).  Dynamic LDS: none when the rows are read directly.
+    extern __shared__ float4 sSHdyn[];
+    float4 (*sSH)[64 * 13] = reinterpret_cast<float4 (*)[64 * 13]>(sSHdyn);
+    __shared__ uint32_t wave_sum[SGR_PRE_THREADS / 64];
+    const SgrCam& cam = *camp;
+    const int gidx = blockIdx.x * SGR_PRE_THREADS + threadIdx.x;
+    const bool live = gidx < P;
+    const int idx = live ? gidx : P - 1;  // lanes past P help with the cooperative copy; their stores are masked
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float p[3] = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+    SgrProj pr = sgr_preprocess_geom(idx, p, scales, rotations, cov3D_precomp, cam, live ? gv.header : nullptr, prefiltered);
+    const bool ok = live && pr.ok;
+
+    const bool stage = stage_sh && shs != nullptr && M == 16;
+    if (stage) {
+        const uint64_t vis = __ballot(ok);
+        const int g0 = blockIdx.x * SGR_PRE_THREADS + wave * 64;
+        const int nrow4 = max(0, min(64, P - g0)) * 12;  // float4s of this wave's rows
+        const float4* src = reinterpret_cast<const float4*>(shs) + (size_t)g0 * 12;
 #pragma unroll
-        for (int i = 0; i < 16; i++) { cam.view[i] = ca.view[i]; cam.proj[i] = ca.proj[i]; }
-        cam.campos[0] = cam.campos[1] = cam.campos[2] = 0.f;
-        cam.tan_fovx = ca.tan_fovx; cam.tan_fovy = ca.tan_fovy; cam.focal_x = ca.focal_x; cam.focal_y = ca.focal_y;
-        cam.W = ca.W; cam.H = ca.H; cam.gx = ca.gx; cam.gy = ca.gy; cam.scale_modifier = ca.scale_modifier;
-        if (idx < P)
-            sgr_preprocess_one<true>(idx, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
-                                     cam, gv, radii, filter_means2D, prefiltered);
-        return;
+        for (int it = 0; it < 12; it++) {
+            const int f = it * 64 + lane;
+            const int row = f / 12;
+            if (f < nrow4 && ((vis >> row) & 1ull)) sSH[wave][f + row] = src[f];
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    if (idx < P)
-        n = sgr_preprocess_one<FILTER>(idx, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
-                                       *camp, gv, radii, filter_means2D, prefiltered);
+
+    uint32_t n = 0;
+    if (live && !ok) {
+        radii[idx] = 0;
+        gv.aux[idx] = make_uint2(0u, 0u);
+        gv.dkeys[0][idx] = 0xffffffffu;  // sorts behind every real depth (> 0.2 => sign bit clear)
+    }
+    if (ok) {
+        // colour: precomputed, or SH -> RGB (forward.cu:20-71)
+        float rgb[3];
+        uint32_t clamped = 0;
+        if (colors_precomp != nullptr) {
+            rgb[0] = colors_precomp[3 * idx];
+            rgb[1] = colors_precomp[3 * idx + 1];
+            rgb[2] = colors_precomp[3 * idx + 2];
+        } else {
+#pragma clang fp contract(off)
+            float dx = p[0] - cam.campos[0], dy = p[1] - cam.campos[1], dz = p[2] - cam.campos[2];
+            const float t0 = dx * dx, t1 = dy * dy, t2 = dz * dz;
+            const float len = sqrtf(t0 + t1 + t2);
+            dx = dx / len; dy = dy / len; dz = dz / len;
+            float Y[16];
+            sgr_sh_basis(D, dx, dy, dz, Y);
+            const int ncoef = (D + 1) * (D + 1);
+            const float* sh = shs + (size_t)idx * M * 3;
+            float r = 0.f, g = 0.f, b = 0.f;
+            if (((M * 3) & 3) == 0 && M <= 16) {
+                // row stride is a multiple of 16 B: the row as float4 (12 at SH degree 3), from LDS when staged
+                const float4* sh4 = stage ? &sSH[wave][lane * 13] : reinterpret_cast<const float4*>(sh);
+                const int n4 = (ncoef * 3 + 3) >> 2;
+                float buf[48];
+#pragma unroll
+                for (int i = 0; i < 12; i++) {
+                    if (i < n4) {
+                        const float4 t = sh4[i];
+                        buf[4 * i] = t.x; buf[4 * i + 1] = t.y; buf[4 * i + 2] = t.z; buf[4 * i + 3] = t.w;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    if (k < ncoef) {
+                        if (k == 0) { r = Y[0] * buf[0]; g = Y[0] * buf[1]; b = Y[0] * buf[2]; }
+                        else { r = r + Y[k] * buf[3 * k]; g = g + Y[k] * buf[3 * k + 1]; b = b + Y[k] * buf[3 * k + 2]; }
+                    }
+                }
+            } else {
+                for (int k = 0; k < ncoef; k++) {
+                    if (k == 0) { r = Y[0] * sh[0]; g = Y[0] * sh[1]; b = Y[0] * sh[2]; }
+                    else { r = r + Y[k] * sh[3 * k]; g = g + Y[k] * sh[3 * k + 1]; b = b + Y[k] * sh[3 * k + 2]; }
+                }
+            }
+            r += 0.5f; g += 0.5f; b += 0.5f;
+            clamped = (r < 0 ? 1u : 0u) | (g < 0 ? 2u : 0u) | (b < 0 ? 4u : 0u);
+            rgb[0] = fmaxf(r, 0.0f); rgb[1] = fmaxf(g, 0.0f); rgb[2] = fmaxf(b, 0.0f);
+        }
+
+        const float opacity = opacities[idx];
+        float hx, hy;
+        sgr_extent(opacity, pr.cov_a, pr.cov_c, pr.con_x, pr.con_y, pr.con_z, hx, hy);
+        const uint32_t w = pr.rx1 - pr.rx0, h = pr.ry1 - pr.ry0;
+        const uint32_t rect = sgr_pack_rect(pr.rx0, pr.ry0, w);
+        float4* rec = gv.rec + 4 * (size_t)idx;
+        rec[0] = make_float4(pr.px, pr.py, hx, hy);
+        rec[1] = make_float4(pr.con_x, pr.con_y, pr.con_z, opacity);
+        rec[2] = make_float4(rgb[0], rgb[1], rgb[2], pr.depth);
+        rec[3] = make_float4(0.f, __uint_as_float(rect), 0.f, 0.f);
+        gv.clamped[idx] = clamped;
+        gv.aux[idx] = make_uint2(w * h, rect);
+        gv.dkeys[0][idx] = __float_as_uint(pr.depth);
+        radii[idx] = pr.radius;
+        n = w * h;
+    }
     // device-scope atomics on one address are resolved beyond the per-XCD L2s (~6 ns each, serialised): one per
     // workgroup, not one per wave (16k of them cost 0.1 ms at P = 1M)
-    __shared__ uint32_t wave_sum[SGR_PRE_THREADS / 64];
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) n += __shfl_xor(n, m, 64);
-    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = n;
+    if (lane == 0) wave_sum[wave] = n;
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t t = 0;
@@ -187,15 +205,6 @@ sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         for (int i = 0; i < SGR_PRE_THREADS / 64; i++) t += wave_sum[i];
         if (t) atomicAdd(&gv.header[1], t);
     }
-}
-
-// ---- tiles_touched gathered in (depth, id) order, ready for the scan that gives every Gaussian its slot ----
-__global__ void __launch_bounds__(SGR_PRE_THREADS)
-sgr_gather_tiles_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles_touched,
-                        uint32_t* __restrict__ tt_sorted) {
-    const int i = blockIdx.x * SGR_PRE_THREADS + threadIdx.x;
-    if (i >= P) return;
-    tt_sorted[i] = tiles_touched[order[i]];
 }
 
 // ---- K6: one (tile key, Gaussian id) per overlapped tile (rasterizer_impl.cu:70-111).  Lane i handles the i-th
@@ -216,15 +225,17 @@ sgr_duplicate_kernel(int P, SgrGeomView gv, const uint32_t* __restrict__ order, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t off = 0xffffffffu, incl = 0, idx = 0, rect = 0;
     if (i < P) {
+        // everything in depth order and coalesced: the id, the scanned offsets, and the tile rect the depth sort's last
+        // pass carried along (aux_sorted) -- no gather of the Gaussian's record
         idx = order[i];
         off = (i == 0) ? 0u : offs_incl[i - 1];
         incl = offs_incl[i];
         if (incl != off) {  // tiles_touched > 0
-            float4* rec = gv.rec + 4 * (size_t)idx;
-            float4 d4 = rec[3];
-            rect = __float_as_uint(d4.y);
-            d4.x = __uint_as_float(off);
-            rec[3] = d4;
+            rect = gv.aux_sorted[i].y;
+            // first slot = first partial-gradient row of the backward: a 4-byte scatter into the compact u0 array (20 MB
+            // at 5 M Gaussians: its lines collect 16 stores each in L2; the same store into the 64-byte records touched
+            // 320 MB of lines once each and was what this kernel spent its time on)
+            gv.u0[idx] = off;
         }
     }
     sOff[wave][lane] = off;  // lanes past P: 0xffffffff, never <= a slot
@@ -296,27 +307,21 @@ void sgr_launch_mark_visible(int P, const float* means3D, const float* viewmatri
 void sgr_launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, const float* rotations,
                            const float* opacities, const float* shs, const float* cov3D_precomp,
                            const float* colors_precomp, const SgrCam* cam, const SgrGeomView& gv, int* radii,
-                           int prefiltered, hipStream_t s) {
+                           int prefiltered, bool stage_sh, hipStream_t s) {
     if (P <= 0) return;
-    sgr_preprocess_kernel<false><<<(P + SGR_PRE_THREADS - 1) / SGR_PRE_THREADS, SGR_PRE_THREADS, 0, s>>>(
-        P, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, cam, gv, radii, nullptr,
-        prefiltered, SgrCamArgs{});
+    const bool stage = stage_sh && shs != nullptr && M == 16;
+    const size_t lds = stage ? (size_t)(SGR_PRE_THREADS / 64) * 64 * 13 * sizeof(float4) : 0;
+    sgr_preprocess_kernel<<<(P + SGR_PRE_THREADS - 1) / SGR_PRE_THREADS, SGR_PRE_THREADS, lds, s>>>(
+        P, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, cam, gv, radii, prefiltered,
+        stage ? 1 : 0);
 }
 
 void sgr_launch_filter(int P, const float* means3D, const float* scales, const float* rotations,
                        const float* cov3D_precomp, const SgrCamArgs& ca, const SgrGeomView& gv, int* radii,
                        float* means2D, int prefiltered, hipStream_t s) {
     if (P <= 0) return;
-    sgr_preprocess_kernel<true><<<(P + SGR_PRE_THREADS - 1) / SGR_PRE_THREADS, SGR_PRE_THREADS, 0, s>>>(
-        P, 0, 0, means3D, scales, rotations, nullptr, nullptr, cov3D_precomp, nullptr, nullptr, gv, radii, means2D,
-        prefiltered, ca);
-}
-
-void sgr_launch_gather_tiles(int P, const uint32_t* order, const uint32_t* tiles_touched, uint32_t* tt_sorted,
-                             hipStream_t s) {
-    if (P <= 0) return;
-    sgr_gather_tiles_kernel<<<(P + SGR_PRE_THREADS - 1) / SGR_PRE_THREADS, SGR_PRE_THREADS, 0, s>>>(P, order, tiles_touched,
-                                                                                                tt_sorted);
+    sgr_filter_kernel<<<(P + SGR_PRE_THREADS - 1) / SGR_PRE_THREADS, SGR_PRE_THREADS, 0, s>>>(
+        P, means3D, scales, rotations, cov3D_precomp, gv.header, radii, means2D, prefiltered, ca);
 }
 
 void sgr_launch_duplicate(int P, const SgrGeomView& gv, const uint32_t* order, const uint32_t* offs_incl, uint32_t* keys,

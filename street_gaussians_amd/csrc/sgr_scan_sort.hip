@@ -54,13 +54,13 @@ __device__ __forceinline__ uint32_t sgr_block_excl_scan256(uint32_t v, uint32_t*
 // order without materialising the permuted array)
 __global__ void __launch_bounds__(256) sgr_scan_reduce_kernel(const uint32_t* __restrict__ in, size_t n,
                                                               uint32_t* __restrict__ block_sums,
-                                                              const uint32_t* __restrict__ gather) {
+                                                              const uint32_t* __restrict__ gather, int stride) {
     __shared__ uint32_t lds4[4];
     const size_t base = (size_t)blockIdx.x * SGR_SCAN_ITEMS + (size_t)threadIdx.x * 8;
     uint32_t s = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++)
-        if (base + i < n) s += gather ? in[gather[base + i]] : in[base + i];
+        if (base + i < n) s += gather ? in[(size_t)gather[base + i] * stride] : in[(base + i) * stride];
     uint32_t total;
     sgr_block_excl_scan256(s, lds4, total);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
@@ -88,14 +88,14 @@ __global__ void __launch_bounds__(256) sgr_scan_spine_kernel(uint32_t* __restric
 template <bool INCLUSIVE>
 __global__ void __launch_bounds__(256) sgr_scan_final_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                              size_t n, const uint32_t* __restrict__ block_sums,
-                                                             const uint32_t* __restrict__ gather) {
+                                                             const uint32_t* __restrict__ gather, int stride) {
     __shared__ uint32_t lds4[4];
     const size_t base = (size_t)blockIdx.x * SGR_SCAN_ITEMS + (size_t)threadIdx.x * 8;
     uint32_t v[8];
     uint32_t s = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        v[i] = (base + i < n) ? (gather ? in[gather[base + i]] : in[base + i]) : 0;
+        v[i] = (base + i < n) ? (gather ? in[(size_t)gather[base + i] * stride] : in[(base + i) * stride]) : 0;
         s += v[i];
     }
     uint32_t total;
@@ -111,35 +111,40 @@ __global__ void __launch_bounds__(256) sgr_scan_final_kernel(const uint32_t* __r
 // out may alias in.  tmp needs sgr_scan_tmp_count(n) words; tmp[nblocks] receives the grand total, and so does
 // *total_out when given.
 void sgr_launch_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, bool inclusive, hipStream_t s,
-                     uint32_t* total_out, const uint32_t* gather) {
+                     uint32_t* total_out, const uint32_t* gather, int in_stride) {
     if (n == 0) return;
     const size_t nb = (n + SGR_SCAN_ITEMS - 1) / SGR_SCAN_ITEMS;
 
-    sgr_scan_reduce_kernel<<<(unsigned)nb, 256, 0, s>>>(in, n, tmp, gather);
+    sgr_scan_reduce_kernel<<<(unsigned)nb, 256, 0, s>>>(in, n, tmp, gather, in_stride);
     sgr_scan_spine_kernel<<<1, 256, 0, s>>>(tmp, nb, total_out);
-    if (inclusive) sgr_scan_final_kernel<true><<<(unsigned)nb, 256, 0, s>>>(in, out, n, tmp, gather);
-    else sgr_scan_final_kernel<false><<<(unsigned)nb, 256, 0, s>>>(in, out, n, tmp, gather);
+    if (inclusive) sgr_scan_final_kernel<true><<<(unsigned)nb, 256, 0, s>>>(in, out, n, tmp, gather, in_stride);
+    else sgr_scan_final_kernel<false><<<(unsigned)nb, 256, 0, s>>>(in, out, n, tmp, gather, in_stride);
 }
 
 // ------------------------------------------------------------------------------------------------
 // radix sort
 // block b owns keys [b*ITEMS, (b+1)*ITEMS); wave w of the block owns ITEMS/4 consecutive keys, read in IPT
 // steps of 64 (lane l <-> key base + w*512 + step*64 + l), so memory order == (wave, step, lane).
-template <typename K>
+template <typename K, int IPT>
 __global__ void __launch_bounds__(256)
-sgr_sort_hist_kernel(const K* __restrict__ keys, uint32_t n, int shift, uint32_t nblocks,
+sgr_sort_hist_kernel(const K* __restrict__ keys, uint32_t n, int shift, uint32_t mask, uint32_t nblocks,
                      uint32_t* __restrict__ hist) {
-    __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t base = blockIdx.x * SGR_SORT_ITEMS;
+    // one private histogram per wave (a quarter of the same-address LDS atomics), merged at the end
+    __shared__ uint32_t h[4][256];
 #pragma unroll
-    for (int s = 0; s < SGR_SORT_IPT; s++) {
+    for (int w = 0; w < 4; w++) h[w][threadIdx.x] = 0;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6;
+    const uint32_t base = blockIdx.x * (256u * IPT);
+#pragma unroll
+    for (int s = 0; s < IPT; s++) {
         const uint32_t i = base + s * 256 + threadIdx.x;
-        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+        if (i < n) atomicAdd(&h[wave][(uint32_t)(keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
-    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];  // [digit][block]
+    if (threadIdx.x <= mask)
+        hist[(size_t)threadIdx.x * nblocks + blockIdx.x] =
+            h[0][threadIdx.x] + h[1][threadIdx.x] + h[2][threadIdx.x] + h[3][threadIdx.x];  // [digit][block]
 }
 
 // workgroup d: exclusive scan of row d of the [digit][block] table in place; totals[d] = row sum
@@ -179,40 +184,50 @@ sgr_sort_rowscan_kernel(uint32_t* __restrict__ hist, uint32_t nblocks, uint32_t*
 #define SGR_OS_AGG (1ull << 48)
 #define SGR_OS_PREFIX (2ull << 48)
 #define SGR_OS_VALUE ((1ull << 48) - 1ull)
-template <typename K, bool ONE>
+// BITS = digit width (NB = 2^BITS bins), IPT = keys per thread (block = 256 * IPT keys).  Fewer bins and larger blocks
+// make every digit's run of a block longer (256 * IPT / NB keys on average: 8 at 8 bits x 2048 keys = a 32-byte store
+// run, 32 at 7 bits x 4096 keys = 128 bytes), which is what the scatter's write efficiency depends on.
+// vin == nullptr: the value of key i is i itself (first pass of a sort whose values are the element ids).
+// aux_in != nullptr (last pass): aux_out[pos] = aux_in[value] as well -- a fused gather of an 8-byte per-id record into
+// sorted order (the depth sort hands tiles_touched + tile rect of every Gaussian to the scan / duplicate stage this way).
+template <typename K, int BITS, int IPT, bool ONE>
 __global__ void __launch_bounds__(256)
 sgr_sort_scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* __restrict__ kout,
                         uint32_t* __restrict__ vout, uint32_t n, int shift, uint32_t nblocks,
                         const uint32_t* __restrict__ hist_scanned, const uint32_t* __restrict__ totals,
                         unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket, uint32_t* __restrict__ err,
-                        uint32_t pass_tag) {
-    __shared__ uint32_t cnt[4][256];    // per wave: count of each digit, then its block-local start for that wave
-    __shared__ uint32_t lstart[256];    // block-local start of each digit
-    __shared__ uint32_t gbase[256];     // global position of the digit's first key of this block
+                        uint32_t pass_tag, const uint2* __restrict__ aux_in, uint2* __restrict__ aux_out) {
+    constexpr int NB = 1 << BITS;
+    constexpr uint32_t ITEMS = 256u * IPT;
+    __shared__ uint32_t cnt[4][NB];    // per wave: count of each digit, then its block-local start for that wave
+    __shared__ uint32_t lstart[NB];    // block-local start of each digit
+    __shared__ uint32_t gbase[NB];     // global position of the digit's first key of this block
     __shared__ uint32_t lds4[4];
-    __shared__ K sK[SGR_SORT_ITEMS];
-    __shared__ uint32_t sV[SGR_SORT_ITEMS];
+    __shared__ K sK[ITEMS];
+    __shared__ uint32_t sV[ITEMS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (ONE && tid == 0) lds4[0] = atomicAdd(ticket, 1u);  // block id in start order: every lower id is already running
+    if (tid < NB) {
 #pragma unroll
-    for (int w = 0; w < 4; w++) cnt[w][tid] = 0;
+        for (int w = 0; w < 4; w++) cnt[w][tid] = 0;
+    }
     __syncthreads();
     const uint32_t block = ONE ? lds4[0] : blockIdx.x;
 
-    const uint32_t base = block * SGR_SORT_ITEMS + wave * (64 * SGR_SORT_IPT);
+    const uint32_t base = block * ITEMS + wave * (64 * IPT);
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    K key[SGR_SORT_IPT];
-    uint32_t val[SGR_SORT_IPT], rnk[SGR_SORT_IPT];
+    K key[IPT];
+    uint32_t val[IPT], rnk[IPT];
 #pragma unroll
-    for (int s = 0; s < SGR_SORT_IPT; s++) {
+    for (int s = 0; s < IPT; s++) {
         const uint32_t i = base + s * 64 + lane;
         const bool valid = i < n;
         key[s] = valid ? kin[i] : (K)0;
-        val[s] = valid ? vin[i] : 0u;
-        const uint32_t d = (uint32_t)(key[s] >> shift) & 255u;
+        val[s] = valid ? (vin ? vin[i] : i) : 0u;
+        const uint32_t d = (uint32_t)(key[s] >> shift) & (uint32_t)(NB - 1);
         uint64_t m = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < 8; b++) {
+        for (int b = 0; b < BITS; b++) {
             const bool bit = (d >> b) & 1u;
             const uint64_t bal = __ballot(valid && bit);
             m &= bit ? bal : ~bal;
@@ -231,10 +246,12 @@ sgr_sort_scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ 
     }
     __syncthreads();
     {
-        const uint32_t c0 = cnt[0][tid], c1 = cnt[1][tid], c2 = cnt[2][tid], c3 = cnt[3][tid];
+        const bool bin = tid < NB;
+        const uint32_t c0 = bin ? cnt[0][tid] : 0u, c1 = bin ? cnt[1][tid] : 0u, c2 = bin ? cnt[2][tid] : 0u,
+                       c3 = bin ? cnt[3][tid] : 0u;
         uint32_t all;
         // digit base over the whole array (contains a barrier), then the block-local digit starts (another scan)
-        uint32_t before;  // keys of digit `tid` in the blocks before this one
+        uint32_t before = 0;  // keys of digit `tid` in the blocks before this one
         if (ONE) {
             const unsigned long long tag = (unsigned long long)pass_tag << 56;
             const uint32_t c = c0 + c1 + c2 + c3;
@@ -258,41 +275,45 @@ sgr_sort_scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ 
             if (block > 0)
                 __hip_atomic_store(mine, tag | SGR_OS_PREFIX | (sum + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             before = (uint32_t)sum;
-        } else {
+        } else if (bin) {
             before = hist_scanned[(size_t)tid * nblocks + block];
         }
-        const uint32_t g = before + sgr_block_excl_scan256(totals[tid], lds4, all);
+        const uint32_t g = before + sgr_block_excl_scan256(bin ? totals[tid] : 0u, lds4, all);
         const uint32_t ls = sgr_block_excl_scan256(c0 + c1 + c2 + c3, lds4, all);
-        gbase[tid] = g;
-        lstart[tid] = ls;
-        cnt[0][tid] = ls;
-        cnt[1][tid] = ls + c0;
-        cnt[2][tid] = ls + c0 + c1;
-        cnt[3][tid] = ls + c0 + c1 + c2;
+        if (bin) {
+            gbase[tid] = g;
+            lstart[tid] = ls;
+            cnt[0][tid] = ls;
+            cnt[1][tid] = ls + c0;
+            cnt[2][tid] = ls + c0 + c1;
+            cnt[3][tid] = ls + c0 + c1 + c2;
+        }
     }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < SGR_SORT_IPT; s++) {
+    for (int s = 0; s < IPT; s++) {
         const uint32_t i = base + s * 64 + lane;
         if (i < n) {
-            const uint32_t d = (uint32_t)(key[s] >> shift) & 255u;
+            const uint32_t d = (uint32_t)(key[s] >> shift) & (uint32_t)(NB - 1);
             const uint32_t lp = cnt[wave][d] + rnk[s];
             sK[lp] = key[s];
             sV[lp] = val[s];
         }
     }
     __syncthreads();
-    const uint32_t first = block * SGR_SORT_ITEMS;
-    const uint32_t nloc = min((uint32_t)SGR_SORT_ITEMS, n - first);
+    const uint32_t first = block * ITEMS;
+    const uint32_t nloc = min(ITEMS, n - first);
 #pragma unroll
-    for (int s = 0; s < SGR_SORT_IPT; s++) {
+    for (int s = 0; s < IPT; s++) {
         const uint32_t li = s * 256 + tid;
         if (li < nloc) {
             const K k = sK[li];
-            const uint32_t d = (uint32_t)(k >> shift) & 255u;
+            const uint32_t d = (uint32_t)(k >> shift) & (uint32_t)(NB - 1);
             const uint32_t pos = gbase[d] + (li - lstart[d]);
+            const uint32_t v = sV[li];
             kout[pos] = k;
-            vout[pos] = sV[li];
+            vout[pos] = v;
+            if (aux_in != nullptr) aux_out[pos] = aux_in[v];
         }
     }
 }
@@ -342,14 +363,55 @@ int sgr_sort_get_one_sweep() {
 // three launches -- the [digit][block] table + 256 totals, recomputed before every scatter pass (the per-block digit
 // histogram depends on where the previous pass left the keys);
 // one sweep -- [control: 8 x 256 digit counts, 8 tickets, error flag | status table, 256 x 64 bit per block].
+// Digit schedule of a sort on key bits [0, end_bit): npass = ceil(end_bit / 8) passes of ceil(end_bit / npass) bits each
+// (14 tile bits -> 2 x 7 instead of 8 + 6: half the bins, twice the run length in the first pass).
+static inline int sort_pass_bits(int end_bit) {
+    static const int forced = [] { const char* e = getenv("SGR_SORT_BITS"); return e ? atoi(e) : 0; }();  // A/B only
+    const int npass = (end_bit + 7) / 8;
+    if (forced == 8) return 8;
+    return npass ? (end_bit + npass - 1) / npass : 8;
+}
+// Keys per thread: large inputs use 4096-key blocks (longer store runs); small ones keep 2048 so that the launch
+// still has a few hundred workgroups.
+static inline int sort_ipt(uint32_t n) {
+    static const int forced = [] { const char* e = getenv("SGR_SORT_IPT"); return e ? atoi(e) : 0; }();  // A/B only
+    if (forced == 8 || forced == 16) return forced;
+    // measured on MI355X (rocprofv3, tile sort of 7.8 M / 38.9 M pairs, 7-bit digits): 2048-key blocks 40.7 / 221.6 us per
+    // pass, 4096-key blocks 42.3 / 242.9 us -- the longer store runs of the larger block do not pay for its occupancy
+    // (115 vs 67 VGPRs, 38 vs 19 KB of LDS); the 16-key template stays for the A/B
+    (void)n;
+    return 8;
+}
+
+int sgr_sort_pass_count(int end_bit) { return (end_bit + 7) / 8; }
+
+template <typename K, int BITS, int IPT>
+static void sort_pass(const K* kin, const uint32_t* vin, K* kout, uint32_t* vout, uint32_t n, int shift, uint32_t* hist,
+                      const uint2* aux_in, uint2* aux_out, hipStream_t s) {
+    const uint32_t nblocks = (n + 256u * IPT - 1) / (256u * IPT);
+    constexpr int NB = 1 << BITS;
+    sgr_sort_hist_kernel<K, IPT><<<nblocks, 256, 0, s>>>(kin, n, shift, (uint32_t)(NB - 1), nblocks, hist);
+    uint32_t* totals = hist + (size_t)NB * nblocks;
+    sgr_sort_rowscan_kernel<<<NB, 256, 0, s>>>(hist, nblocks, totals);
+    sgr_sort_scatter_kernel<K, BITS, IPT, false><<<nblocks, 256, 0, s>>>(kin, vin, kout, vout, n, shift, nblocks, hist, totals,
+                                                                         nullptr, nullptr, nullptr, 0u, aux_in, aux_out);
+}
+
+// Sorts n pairs on key bits [0, end_bit).  keys[0]/vals[0] hold the input; returns the index (0/1)
+// of the pair of buffers that holds the sorted output.  hist: sgr_sort_hist_words(n) dwords (scan_tmp is unused):
+// three launches -- the [digit][block] table + the digit totals, recomputed before every scatter pass (the per-block digit
+// histogram depends on where the previous pass left the keys);
+// one sweep -- [control: 8 x 256 digit counts, 8 tickets, error flag | status table, 256 x 64 bit per block].
+// iota: vals[0] is not read, the value of input element i is i.  aux_in / aux_out: see the scatter kernel (last pass).
 template <typename K>
 static int sort_pairs_impl(K* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
-                           uint32_t* scan_tmp, hipStream_t s) {
+                           uint32_t* scan_tmp, hipStream_t s, bool iota = false, const uint2* aux_in = nullptr,
+                           uint2* aux_out = nullptr) {
     if (n == 0) return 0;
     const int npass = (end_bit + 7) / 8;
-    const uint32_t nblocks = (n + SGR_SORT_ITEMS - 1) / SGR_SORT_ITEMS;
     int cur = 0;
-    if (sgr_sort_get_one_sweep() && npass <= SGR_SORT_MAX_PASS) {
+    if (sgr_sort_get_one_sweep() && npass <= SGR_SORT_MAX_PASS && !iota && !aux_in) {
+        const uint32_t nblocks = (n + SGR_SORT_ITEMS - 1) / SGR_SORT_ITEMS;
         uint32_t* ghist = hist;
         uint32_t* tickets = hist + SGR_SORT_MAX_PASS * 256;
         uint32_t* err = tickets + SGR_SORT_MAX_PASS;
@@ -359,19 +421,29 @@ static int sort_pairs_impl(K* const keys[2], uint32_t* const vals[2], uint32_t n
         sgr_sort_hist_all_kernel<K><<<chunks < 1024u ? chunks : 1024u, 256, 0, s>>>(keys[0], n, npass, ghist, status,
                                                                                    (size_t)nblocks * 256);
         for (int p = 0; p < npass; p++) {
-            sgr_sort_scatter_kernel<K, true><<<nblocks, 256, 0, s>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n,
-                                                                     8 * p, nblocks, nullptr, ghist + p * 256, status,
-                                                                     tickets + p, err, (uint32_t)p + 1u);
+            sgr_sort_scatter_kernel<K, 8, SGR_SORT_IPT, true><<<nblocks, 256, 0, s>>>(
+                keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, 8 * p, nblocks, nullptr, ghist + p * 256, status,
+                tickets + p, err, (uint32_t)p + 1u, nullptr, nullptr);
             cur ^= 1;
         }
         return cur;
     }
+    const int bits = sizeof(K) == 8 ? 8 : sort_pass_bits(end_bit);
+    const int ipt = sizeof(K) == 8 ? 8 : sort_ipt(n);
     for (int p = 0; p < npass; p++) {
-        sgr_sort_hist_kernel<K><<<nblocks, 256, 0, s>>>(keys[cur], n, 8 * p, nblocks, hist);
-        uint32_t* totals = hist + (size_t)256 * nblocks;
-        sgr_sort_rowscan_kernel<<<256, 256, 0, s>>>(hist, nblocks, totals);
-        sgr_sort_scatter_kernel<K, false><<<nblocks, 256, 0, s>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n,
-                                                                  8 * p, nblocks, hist, totals, nullptr, nullptr, nullptr, 0u);
+        const uint32_t* vin = (iota && p == 0) ? nullptr : vals[cur];
+        const bool last = p == npass - 1;
+        const uint2* ai = last ? aux_in : nullptr;
+        uint2* ao = last ? aux_out : nullptr;
+        const int shift = bits * p;
+#define SGR_PASS(B, I) sort_pass<K, B, I>(keys[cur], vin, keys[cur ^ 1], vals[cur ^ 1], n, shift, hist, ai, ao, s)
+        if constexpr (sizeof(K) == 8) { SGR_PASS(8, 8); }
+        else if (ipt == 16) {
+            if (bits <= 5) SGR_PASS(5, 16); else if (bits == 6) SGR_PASS(6, 16); else if (bits == 7) SGR_PASS(7, 16); else SGR_PASS(8, 16);
+        } else {
+            if (bits <= 5) SGR_PASS(5, 8); else if (bits == 6) SGR_PASS(6, 8); else if (bits == 7) SGR_PASS(7, 8); else SGR_PASS(8, 8);
+        }
+#undef SGR_PASS
         cur ^= 1;
     }
     return cur;
@@ -381,6 +453,6 @@ int sgr_launch_sort_pairs(uint64_t* const keys[2], uint32_t* const vals[2], uint
     return sort_pairs_impl<uint64_t>(keys, vals, n, end_bit, hist, scan_tmp, s);
 }
 int sgr_launch_sort_pairs32(uint32_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
-                            uint32_t* scan_tmp, hipStream_t s) {
-    return sort_pairs_impl<uint32_t>(keys, vals, n, end_bit, hist, scan_tmp, s);
+                            uint32_t* scan_tmp, hipStream_t s, bool iota, const uint2* aux_in, uint2* aux_out) {
+    return sort_pairs_impl<uint32_t>(keys, vals, n, end_bit, hist, scan_tmp, s, iota, aux_in, aux_out);
 }
