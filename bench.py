@@ -545,7 +545,7 @@ def main():
         sb = stage_bytes(args.gaussians, wl.V_in, V, R, N, T_tiles, S)
         achieved = algo_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms else None
         fwd_ms = stage_ms["blend_fwd"]
-        traffic, valu, traffic_note = None, None, None
+        traffic, valu, traffic_note, pmc_derived = None, None, None, None
         tfile = os.path.join(ROOT, "profiles", "pmc_blend_bwd.json")
         kernel_name = "sgr_blend_bwd_kernel_s0" if S == 0 else "sgr_blend_bwd_kernel"
         if os.path.exists(tfile):
@@ -562,6 +562,7 @@ def main():
                                     f"this build is {sha}: re-run tools/gpu_evidence.sh + tools/pmc_summary.py")
                 else:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    pmc_derived = tj.get("derived")
                     traffic_note = "rocprofv3 PMC, 2*FETCH_SIZE + WRITE_SIZE per launch, " + str(tj.get("source", ""))[:120]
                     if tj.get("sq_insts_valu") and bwd_ms:
                         # what actually bounds the kernel: VALU wave-instructions (rocprofv3 SQ_INSTS_VALU) against
@@ -602,7 +603,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernel_name,
                          "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": traffic,
-                         "traffic_note": traffic_note, "valu": valu,
+                         "traffic_note": traffic_note, "valu": valu, "pmc": pmc_derived,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "kernel_ms": round(bwd_ms, 4) if bwd_ms else None,
                          "kernel_ms_source": f"HIP events around the kernel on its launch stream, mean over "

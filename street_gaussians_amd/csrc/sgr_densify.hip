@@ -10,6 +10,8 @@
 //     S  is split                  (rank among S = the child's row in the repeat(N,1) layout)
 //     C  leaves surviving children = split && !pruned(child)
 // exclusive scans of the masks give every result row its position, in the reference's order.
+#include <algorithm>
+#include <cstdint>
 #include <string>
 
 #include "../../include/sgr_densify.h"
@@ -73,13 +75,22 @@ sgr_densify_flags_kernel(int N, sgr_densify_params p, const float* __restrict__ 
     w.offC[i] = (split && !prune_child) ? 1u : 0u;
 }
 
-__global__ void sgr_densify_count_kernel(int N, DnWork w) {
-    // one wave: clone count (not a scan total) in a fixed order
+// number of cloned points (not a scan total: clones that are pruned again still count, gaussian_model.py:500-502).  An
+// integer count -- order-independent, so a ballot per wave and one atomic per workgroup; the single-wave loop it replaces
+// took 10 ms at 5 M points (rocprofv3), 80 % of the whole densify_and_prune.
+__global__ void __launch_bounds__(256)
+sgr_densify_count_kernel(int N, DnWork w) {
+    __shared__ uint32_t part[4];
     uint32_t c = 0;
-    for (int i = threadIdx.x; i < N; i += 64) c += (w.flags[i] & DN_CLONE) ? 1u : 0u;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) c += (w.flags[i] & DN_CLONE) ? 1u : 0u;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
-    if (threadIdx.x == 0) w.totals[4] = c;
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = part[0] + part[1] + part[2] + part[3];
+        if (t) atomicAdd(&w.totals[4], t);
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -109,6 +120,9 @@ sgr_densify_map_kernel(int N, int n_split, DnWork w, int32_t* __restrict__ src, 
 // One workgroup builds 128 consecutive result rows: their source rows / kinds are staged in LDS once, then one lane per
 // float walks the 128 * width outputs (coalesced stores, row-wise contiguous loads, 32-bit index arithmetic).
 #define SGR_DN_ROWS 128
+// WT > 0: the row width as a compile-time constant (the per-element row / column split is a multiply-shift instead of a
+// 32-bit division, which was most of the kernel's instructions: 1 TB/s with the runtime width); WT == 0: any width.
+template <int WT>
 __global__ void __launch_bounds__(256)
 sgr_densify_gather_kernel(int n_out, int width, const float* __restrict__ in, const int32_t* __restrict__ src,
                           const uint8_t* __restrict__ kind, int zero_new, float* __restrict__ out) {
@@ -121,8 +135,20 @@ sgr_densify_gather_kernel(int n_out, int width, const float* __restrict__ in, co
         sKind[threadIdx.x] = kind[r0 + threadIdx.x];
     }
     __syncthreads();
-    float* o = out + (size_t)r0 * width;
-    const uint32_t total = (uint32_t)rows * (uint32_t)width, w = (uint32_t)width;
+    const uint32_t w = WT > 0 ? (uint32_t)WT : (uint32_t)width;
+    float* o = out + (size_t)r0 * w;
+    const uint32_t total = (uint32_t)rows * w;
+    if (WT > 0 && (WT & 3) == 0) {
+        // rows are whole float4s (and 16-byte aligned: hipMalloc'ed tensors, width a multiple of 4): 16-byte copies
+        constexpr uint32_t W4 = WT > 0 ? (uint32_t)WT / 4u : 1u;
+        const float4* in4 = reinterpret_cast<const float4*>(in);
+        float4* o4 = reinterpret_cast<float4*>(o);
+        for (uint32_t e = threadIdx.x; e < (uint32_t)rows * W4; e += 256) {
+            const uint32_t r = e / W4, j = e - r * W4;
+            o4[e] = (zero_new && sKind[r] != SGR_KIND_KEEP) ? make_float4(0.f, 0.f, 0.f, 0.f) : in4[(size_t)sSrc[r] * W4 + j];
+        }
+        return;
+    }
     for (uint32_t e = threadIdx.x; e < total; e += 256) {
         const uint32_t r = e / w, j = e - r * w;
         o[e] = (zero_new && sKind[r] != SGR_KIND_KEEP) ? 0.0f : in[(size_t)sSrc[r] * w + j];
@@ -162,9 +188,10 @@ sgr_densify_prune_kernel(int n, sgr_densify_params p, int variant, const float* 
                          const float* __restrict__ opacity, DnSphere sph, DnBox box,
                          const float* __restrict__ box_normals, uint8_t* __restrict__ prune, uint32_t* __restrict__ cnt) {
 #pragma clang fp contract(off)
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     bool low = false, big = false, outside = false;
-    if (i < n) {
+    {
         const float op = 1.0f / (1.0f + expf(-opacity[i]));
         low = op < p.min_opacity;
         const float s[3] = {expf(scaling[3 * i]), expf(scaling[3 * i + 1]), expf(scaling[3 * i + 2])};
@@ -199,13 +226,23 @@ sgr_densify_prune_kernel(int n, sgr_densify_params p, int variant, const float* 
         }
         prune[i] = (low || big || outside) ? 1 : 0;
     }
-    // four counters, one atomic each per wave (integers: order-independent)
-    const uint64_t b0 = __ballot(low), b1 = __ballot(big), b2 = __ballot(outside), b3 = __ballot(low || big || outside);
+    c0 += low; c1 += big; c2 += outside; c3 += (low || big || outside);
+    }
+    // four counters (integers: order-independent): per-thread over the grid-stride loop, then one atomic each per
+    // WORKGROUP -- one per wave were 440 k device-scope atomics on four words at 7 M candidates, 3.7 ms (rocprofv3)
+    __shared__ uint32_t part[4][4];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        c0 += __shfl_xor(c0, m, 64); c1 += __shfl_xor(c1, m, 64); c2 += __shfl_xor(c2, m, 64); c3 += __shfl_xor(c3, m, 64);
+    }
     if ((threadIdx.x & 63) == 0) {
-        if (b0) atomicAdd(&cnt[0], (uint32_t)__popcll(b0));
-        if (b1) atomicAdd(&cnt[1], (uint32_t)__popcll(b1));
-        if (b2) atomicAdd(&cnt[2], (uint32_t)__popcll(b2));
-        if (b3) atomicAdd(&cnt[3], (uint32_t)__popcll(b3));
+        const int wv = threadIdx.x >> 6;
+        part[wv][0] = c0; part[wv][1] = c1; part[wv][2] = c2; part[wv][3] = c3;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const uint32_t t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        if (t) atomicAdd(&cnt[threadIdx.x], t);
     }
 }
 
@@ -260,7 +297,7 @@ int sgr_densify_prune_mask(int n, const sgr_densify_params* p, int variant, cons
     if (!fb.ptr) return sgr_set_error(SGR_E_HIP, "counter block allocation failed");
     uint32_t* cnt = fb.ptr + 16;  // words 16..19: the first words belong to sgr_visible_filter's flag
     DN_HIP(hipMemsetAsync(cnt, 0, 16, stream));
-    sgr_densify_prune_kernel<<<(n + 255) / 256, 256, 0, stream>>>(n, *p, variant, xyz, scaling, rotation, opacity, sph, bx,
+    sgr_densify_prune_kernel<<<std::min((n + 255) / 256, 2048), 256, 0, stream>>>(n, *p, variant, xyz, scaling, rotation, opacity, sph, bx,
                                                                  box_normals, prune, cnt);
     uint32_t h[4];
     DN_HIP(hipMemcpyAsync(h, cnt, 16, hipMemcpyDeviceToHost, stream));
@@ -316,7 +353,8 @@ int sgr_densify_plan(int N, const sgr_densify_params* p, const float* xyz_gradie
     sgr_launch_scan(w.offB, w.offB, (size_t)N, w.tmp, false, stream, w.totals + 1);
     sgr_launch_scan(w.offS, w.offS, (size_t)N, w.tmp, false, stream, w.totals + 2);
     sgr_launch_scan(w.offC, w.offC, (size_t)N, w.tmp, false, stream, w.totals + 3);
-    sgr_densify_count_kernel<<<1, 64, 0, stream>>>(N, w);
+    DN_HIP(hipMemsetAsync(w.totals + 4, 0, sizeof(uint32_t), stream));
+    sgr_densify_count_kernel<<<std::min((N + 255) / 256, 1024), 256, 0, stream>>>(N, w);
     uint32_t t[8];
     DN_HIP(hipMemcpyAsync(t, w.totals, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     DN_HIP(hipStreamSynchronize(stream));
@@ -345,8 +383,28 @@ int sgr_densify_gather(int n_out, int width, const float* in, const int32_t* src
     hipStream_t stream = (hipStream_t)stream_;
     if (n_out <= 0 || width <= 0) return 0;
     if (!in || !src || !kind || !out) return sgr_set_error(SGR_E_INVALID, "in, src, kind and out are required");
-    sgr_densify_gather_kernel<<<(unsigned)((n_out + SGR_DN_ROWS - 1) / SGR_DN_ROWS), 256, 0, stream>>>(n_out, width, in, src,
-                                                                                                   kind, zero_new, out);
+    const unsigned nb = (unsigned)((n_out + SGR_DN_ROWS - 1) / SGR_DN_ROWS);
+    const bool al16 = (((uintptr_t)in | (uintptr_t)out) & 15u) == 0;
+#define DN_G(W) sgr_densify_gather_kernel<W><<<nb, 256, 0, stream>>>(n_out, width, in, src, kind, zero_new, out)
+    // the widths of the reference's parameter groups: xyz / scaling / f_dc 3, opacity 1, rotation 4, f_rest 45 (SH degree 3;
+    // 9 / 24 at degrees 1 / 2), semantic logits (16, 19, 20 classes), actor f_dc (fourier_dim x 3: 6, 9, 12, 15)
+    switch (width) {
+        case 1: DN_G(1); break;
+        case 3: DN_G(3); break;
+        case 4: if (al16) DN_G(4); else DN_G(0); break;
+        case 6: DN_G(6); break;
+        case 9: DN_G(9); break;
+        case 12: if (al16) DN_G(12); else DN_G(0); break;
+        case 15: DN_G(15); break;
+        case 16: if (al16) DN_G(16); else DN_G(0); break;
+        case 19: DN_G(19); break;
+        case 20: if (al16) DN_G(20); else DN_G(0); break;
+        case 24: if (al16) DN_G(24); else DN_G(0); break;
+        case 45: DN_G(45); break;
+        case 48: if (al16) DN_G(48); else DN_G(0); break;
+        default: DN_G(0); break;
+    }
+#undef DN_G
     DN_HIP(hipGetLastError());
     return 0;
 }

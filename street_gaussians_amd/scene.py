@@ -191,6 +191,180 @@ def compose(segments: List[Segment], max_sh_coeffs: int, num_classes: int):
     return _Compose.apply(list(segments), int(max_sh_coeffs), int(num_classes), *flat)
 
 
+# ---- flat-parameter mode ---------------------------------------------------------------------------------------------
+# `compose` takes one leaf tensor per (sub-model, attribute): a street scene with 20 actors crosses the autograd boundary
+# with 167 leaves, and the engine's per-leaf work (an AccumulateGrad node each) costs more than the kernels (1.56 ms wall
+# for 0.71 ms of kernels at 2 M Gaussians).  In flat mode the scene's parameters live in ONE leaf tensor per attribute
+# (all sub-models concatenated, the per-model tensors are views of it) and every actor's pose in one [n_actors, 7] leaf: 8
+# leaves whatever the number of actors.  The kernels are the same -- they take per-segment pointers, which here point into
+# the flat storages.
+_FLAT = ("xyz", "rotation", "scaling", "opacity", "features_dc", "features_rest", "semantic")
+
+
+class FlatScene:
+    """The raw parameters of a scene graph as one leaf tensor per attribute.
+
+    ``FlatScene.from_segments(segments)`` concatenates the segments' tensors (rows of features_dc are [fourier_dim * 3]
+    wide per Gaussian and of semantic [S] for the background / [1] for an actor, so those two are flattened to 1-D); the
+    result's ``xyz, rotation, scaling, opacity, features_dc, features_rest, semantic`` and ``poses`` [n_actors, 7] require
+    grad and are what an optimiser holds; ``views()`` gives the per-model tensors (views: densification, I/O).
+    ``compose(M, S, flip_masks=None, idfts=None)`` is ``scene.compose`` for the current values."""
+
+    def __init__(self, meta, tensors, poses):
+        self.meta = meta              # per segment: dict(count, kind, fourier_dim, sem_width, class_label, semantic_mode, flip_*)
+        self.tensors = tensors        # attr -> flat leaf
+        self.poses = poses            # [n_actors, 7] leaf or None
+        for k in _FLAT:
+            setattr(self, k, tensors[k])
+
+    @classmethod
+    def from_segments(cls, segments: Sequence[Segment], requires_grad: bool = True) -> "FlatScene":
+        meta, parts = [], {k: [] for k in _FLAT}
+        poses = []
+        dev = segments[0].xyz.device
+        for s in segments:
+            n = int(s.xyz.shape[0])
+            C = int(s.features_dc.shape[1]) if s.features_dc.dim() == 3 else 1
+            sw = 0 if s.semantic is None or s.semantic.numel() == 0 else int(s.semantic.shape[1])
+            meta.append(dict(count=n, kind=s.kind, fourier_dim=C, sem_width=sw, class_label=int(s.class_label),
+                             semantic_mode=s.semantic_mode, flip_axis=int(s.flip_axis), flip_quat=tuple(s.flip_quat),
+                             idft=None if s.idft is None else s.idft.detach().float().to(dev)))
+            for k in _FLAT:
+                t = getattr(s, k)
+                if t is None:
+                    continue
+                t = t.detach().float()
+                parts[k].append(t.reshape(-1) if k in ("features_dc", "semantic") else t.reshape(n, -1))
+            if s.pose is not None:
+                poses.append(s.pose.detach().float().reshape(7))
+        tensors = {}
+        for k in _FLAT:
+            t = torch.cat(parts[k], 0).contiguous() if parts[k] else torch.zeros(0, device=dev)
+            tensors[k] = t.requires_grad_(requires_grad)
+        P = torch.stack(poses).contiguous().requires_grad_(requires_grad) if poses else None
+        return cls(meta, tensors, P)
+
+    def _offsets(self):
+        """Per segment: element offsets of its block inside each flat tensor."""
+        offs, row, dc, sem = [], 0, 0, 0
+        for m in self.meta:
+            offs.append(dict(row=row, dc=dc, sem=sem))
+            row += m["count"]
+            dc += m["count"] * m["fourier_dim"] * 3
+            sem += m["count"] * m["sem_width"]
+        return offs
+
+    def views(self) -> List[dict]:
+        out, a = [], 0
+        for m, o in zip(self.meta, self._offsets()):
+            n = m["count"]
+            d = {k: self.tensors[k][o["row"]:o["row"] + n] for k in ("xyz", "rotation", "scaling", "opacity", "features_rest")}
+            d["features_rest"] = d["features_rest"].view(n, -1, 3)
+            d["features_dc"] = self.tensors["features_dc"][o["dc"]:o["dc"] + n * m["fourier_dim"] * 3].view(n, m["fourier_dim"], 3)
+            d["semantic"] = self.tensors["semantic"][o["sem"]:o["sem"] + n * m["sem_width"]].view(n, m["sem_width"])
+            if m["kind"] == SEG_ACTOR:
+                d["pose"] = self.poses[a]
+                a += 1
+            out.append(d)
+        return out
+
+    def compose(self, max_sh_coeffs: int, num_classes: int, flip_masks: Optional[Sequence] = None):
+        """Same result as ``scene.compose(segments, M, S)``; gradients arrive in the 7 flat leaves + ``poses``."""
+        fm = list(flip_masks) if flip_masks is not None else [None] * len(self.meta)
+        args = [self.tensors[k] for k in _FLAT] + [self.poses]
+        return _ComposeFlat.apply(self, fm, int(max_sh_coeffs), int(num_classes), *args)
+
+
+def _pack_flat(fs: FlatScene, tensors, flip_masks, grads=None):
+    """_CSeg array (and, with `grads`, the _CSegGrads array) whose pointers address the segments' blocks of the flat tensors."""
+    arr = (_CSeg * len(fs.meta))()
+    garr = (_CSegGrads * len(fs.meta))() if grads is not None else None
+    keep = []
+    base = {k: (t.data_ptr() if t is not None and t.numel() else 0) for k, t in zip(_FLAT + ("poses",), tensors)}
+    gbase = None
+    if grads is not None:
+        gbase = {k: (t.data_ptr() if t is not None and t.numel() else 0) for k, t in zip(_FLAT + ("poses",), grads)}
+    width = {"xyz": 3, "rotation": 4, "scaling": 3, "opacity": 1}
+    rest_w = tensors[5].shape[1] if tensors[5] is not None and tensors[5].dim() == 2 else 0
+    a = 0
+    for i, (m, o) in enumerate(zip(fs.meta, fs._offsets())):
+        c = arr[i]
+        c.count, c.kind, c.fourier_dim = m["count"], m["kind"], m["fourier_dim"]
+        c.class_label, c.sem_mode, c.flip_axis = m["class_label"], _SEM[m["semantic_mode"]], m["flip_axis"]
+        c.flip_quat = (C.c_float * 4)(*[float(v) for v in m["flip_quat"]])
+
+        def addr(b, name):
+            if not b[name] or not m["count"]:
+                return None
+            if name in width:
+                return b[name] + 4 * o["row"] * width[name]
+            if name == "features_rest":
+                return b[name] + 4 * o["row"] * rest_w if rest_w else None
+            if name == "features_dc":
+                return b[name] + 4 * o["dc"]
+            return b[name] + 4 * o["sem"] if m["sem_width"] else None  # semantic
+        for name in _FLAT:
+            setattr(c, name, addr(base, name))
+            if garr is not None:
+                setattr(garr[i], name, addr(gbase, name))
+        if m["kind"] == SEG_ACTOR:
+            c.pose = base["poses"] + 4 * 7 * a
+            if garr is not None and gbase["poses"]:
+                garr[i].pose = gbase["poses"] + 4 * 7 * a
+            a += 1
+        fmk = flip_masks[i]
+        if fmk is not None:
+            fmk = fmk.view(torch.uint8) if fmk.dtype == torch.bool and fmk.is_contiguous() else fmk.to(torch.uint8).contiguous()
+            keep.append(fmk)
+            c.flip_mask = fmk.data_ptr() if fmk.numel() else None
+        if m["idft"] is not None:
+            c.idft = m["idft"].data_ptr()
+    return arr, garr, keep
+
+
+class _ComposeFlat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fs, flip_masks, M, S, *tensors):
+        dev = tensors[0].device
+        for t in tensors:
+            if t is not None and (not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous()):
+                raise SgrError("flat scene parameters must be contiguous float32 HIP tensors")
+        arr, _, keep = _pack_flat(fs, tensors, flip_masks)
+        N = sum(m["count"] for m in fs.meta)
+        f = dict(dtype=torch.float32, device=dev)
+        outs = [torch.empty(N, 3, **f), torch.empty(N, 4, **f), torch.empty(N, 3, **f), torch.empty(N, 1, **f),
+                torch.empty(N, M, 3, **f), torch.empty(N, S, **f)]
+        grow = _Grow(dev)
+        with torch.cuda.device(dev):
+            check(_native.lib().sgr_scene_compose_forward(
+                len(fs.meta), arr, int(M), int(S), *[_ptr(o) if o.numel() else None for o in outs], grow.cb, None,
+                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        ctx.fs, ctx.flip_masks, ctx.M, ctx.S = fs, flip_masks, int(M), int(S)
+        ctx.save_for_backward(*[t for t in tensors if t is not None])
+        ctx.present = [t is not None for t in tensors]
+        ctx.keep = keep
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, d_means, d_rot, d_scale, d_opac, d_shs, d_sem):
+        saved = iter(ctx.saved_tensors)
+        tensors = [next(saved) if p else None for p in ctx.present]
+        fs, M, S = ctx.fs, ctx.M, ctx.S
+        dev = tensors[0].device
+        need = ctx.needs_input_grad[4:]
+        grads = [torch.empty_like(t) if (t is not None and need[i]) else None for i, t in enumerate(tensors)]
+        arr, garr, keep = _pack_flat(fs, tensors, ctx.flip_masks, grads)
+        dz = lambda t: None if t is None else _f32c(t, "grad")
+        ins = [dz(d_means), dz(d_rot), dz(d_scale), dz(d_opac), dz(d_shs), dz(d_sem) if S else None]
+        grow = _Grow(dev)
+        with torch.cuda.device(dev):
+            check(_native.lib().sgr_scene_compose_backward(
+                len(fs.meta), arr, garr, M, S, *[_ptr(t) if t is not None and t.numel() else None for t in ins], grow.cb,
+                None, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        del keep
+        return (None, None, None, None) + tuple(grads)
+
+
 def densification_stats(models: Sequence[dict], dL_dmeans2D: torch.Tensor, radii: torch.Tensor) -> None:
     """In-place update of every model's ``xyz_gradient_accum`` [n,2], ``denom`` [n,1] and ``max_radii2D`` [n] from one
     view's screen-space gradient [N,3] and radii [N] (models in concatenation order; dict keys as the attribute

@@ -217,3 +217,38 @@ def test_scene_file_in_the_reference_layout_renders_like_the_oracle(source):
     image_close(npy(alpha), fw.alpha, rel=2e-3, name="scene alpha", max_outliers=50)
     image_close(npy(semo), fw.semantic, rel=2e-3, name="scene semantic", max_outliers=200)
     fw.free()
+
+
+@pytest.mark.parametrize("counts,M,S,seed", [((700, 300, 257), 16, 5, 2), ((5, 1, 3, 513), 4, 19, 3), ((1000,), 16, 0, 1)])
+def test_flat_parameter_mode_equals_per_model_compose(counts, M, S, seed):
+    """scene.FlatScene: the same kernels fed from ONE leaf tensor per attribute (8 autograd leaves instead of 8 per
+    sub-model) -- outputs and every gradient bit-identical to scene.compose on the per-model leaves."""
+    segs = _make(counts, M, S, seed)
+    gsegs, gleaves = _to_gpu(segs)
+    outs = scene.compose(gsegs, M, S)
+    flat = scene.FlatScene.from_segments(gsegs)
+    fouts = flat.compose(M, S, flip_masks=[s.flip_mask for s in gsegs])
+    for a, b in zip(outs, fouts):
+        assert torch.equal(a, b)
+    g = torch.Generator().manual_seed(100 + seed)
+    ups = [torch.randn(o.shape, generator=g).cuda() for o in outs]
+    sel = [i for i, o in enumerate(outs) if o.requires_grad]
+    torch.autograd.backward([outs[i] for i in sel], [ups[i] for i in sel])
+    torch.autograd.backward([fouts[i] for i in sel], [ups[i] for i in sel])
+    views = flat.views()
+    fgrads = {k: flat.tensors[k].grad for k in scene._FLAT}
+    offs = flat._offsets()
+    for k, (seg, m, o) in enumerate(zip(gsegs, flat.meta, offs)):
+        n = m["count"]
+        for name in ("xyz", "rotation", "scaling", "opacity"):
+            assert torch.equal(getattr(seg, name).grad, fgrads[name][o["row"]:o["row"] + n]), (k, name)
+        assert torch.equal(seg.features_rest.grad.reshape(n, -1), fgrads["features_rest"][o["row"]:o["row"] + n]), k
+        assert torch.equal(seg.features_dc.grad.reshape(-1), fgrads["features_dc"][o["dc"]:o["dc"] + n * m["fourier_dim"] * 3]), k
+        if S and seg.semantic is not None:
+            assert torch.equal(seg.semantic.grad.reshape(-1), fgrads["semantic"][o["sem"]:o["sem"] + n * m["sem_width"]]), k
+    a = 0
+    for seg in gsegs:
+        if seg.pose is not None:
+            assert torch.equal(seg.pose.grad, flat.poses.grad[a])
+            a += 1
+    assert len(views) == len(counts) and views[0]["xyz"].shape[0] == counts[0]

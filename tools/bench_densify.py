@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch_ref_densify as ref  # noqa: E402
 from street_gaussians_amd import densify  # noqa: E402
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
+N = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 5_000_000
 dev = torch.device("cuda")
 g = torch.Generator(device="cuda").manual_seed(0)
 r = lambda *s: torch.randn(*s, generator=g, device=dev)
@@ -48,7 +48,19 @@ def timeit(fn, n=3):
     return 1e3 * (time.perf_counter() - t0) / n, out
 
 
+def fused_bkgd():
+    return densify.densify_and_prune(params, accum, denom, prune_big=True, states=states, normals=None, variant="bkgd",
+                                     sphere_center=torch.zeros(3), sphere_radius=20.0, **kw)[2]
+
+
 tf, sf = timeit(fused)
-tt, st = timeit(torch_ops)
+tb, sb = timeit(fused_bkgd)
+if "--no-torch" in sys.argv:
+    tt, st = float("nan"), None
+else:
+    tt, st = timeit(torch_ops)
+moved = sum(v.numel() * 4 * 3 * 2 for v in params.values())  # parameters + two Adam moments, read + written once
 print(json.dumps({"what": "densify_and_prune (SURVEY 8f n2)", "gaussians": N, "fused_ms": round(tf, 2), "torch_ops_ms": round(tt, 2),
-                  "speedup": round(tt / tf, 1), "scalars_fused": sf, "scalars_torch_ops": st}))
+                  "speedup": round(tt / tf, 1), "fused_bkgd_variant_ms": round(tb, 2),
+                  "row_bytes_moved_gb": round(moved / 1e9, 2), "fused_effective_tb_s": round(moved / 1e12 / (tf * 1e-3), 2),
+                  "scalars_fused": sf, "scalars_bkgd": sb, "scalars_torch_ops": st}))

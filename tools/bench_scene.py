@@ -72,6 +72,14 @@ def timeit(fn):
 
 
 fused = timeit(lambda: scene.compose(segs, M, S))
+# flat-parameter mode: the same kernels, 8 autograd leaves instead of 8 per sub-model
+flat = scene.FlatScene.from_segments(segs)
+masks = [s.flip_mask for s in segs]
+per_model_leaves = leaves
+leaves = [t for t in flat.tensors.values()] + [flat.poses]
+ups = None
+flat_ms = timeit(lambda: flat.compose(M, S, flip_masks=masks))
+leaves, ups = per_model_leaves, None
 torch_ops = timeit(lambda: ref.compose(dicts, M, S))
 per_g = 3 + 4 + 3 + 1 + 3 * M + S      # output floats per Gaussian
 raw_bk = 3 + 4 + 3 + 1 + 3 * M + S      # raw floats per background Gaussian
@@ -80,7 +88,8 @@ n_ac = N - counts[0]
 fwd = 4 * (counts[0] * raw_bk + n_ac * raw_ac + N * per_g)
 bwd = 4 * (N * per_g + counts[0] * 2 * raw_bk + n_ac * 2 * raw_ac)
 print(json.dumps({"what": "scene compose forward+backward (SURVEY 8f n1)", "gaussians": N, "actors": args.actors,
-                  "fused_ms": round(fused, 3), "torch_ops_ms": round(torch_ops, 3),
+                  "fused_ms": round(fused, 3), "fused_flat_parameters_ms": round(flat_ms, 3), "autograd_leaves": len(per_model_leaves),
+                  "autograd_leaves_flat": 8, "torch_ops_ms": round(torch_ops, 3),
                   "speedup": round(torch_ops / fused, 2), "algorithmic_bytes": fwd + bwd,
                   "fused_GBps": round((fwd + bwd) / fused / 1e6, 1), "hbm_peak_GBps": 8000.0,
                   "frac": round((fwd + bwd) / fused / 1e6 / 8000.0, 3)}))
