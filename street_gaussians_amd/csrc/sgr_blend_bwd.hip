@@ -13,7 +13,7 @@
 //     inside its rect).  Rows of one Gaussian are therefore contiguous, and the per-Gaussian kernel
 //     (sgr_gauss_bwd.hip) reduces them in a fixed order: gradients are bit-reproducible run to run,
 //     unlike the reference's unordered atomics.
-// Row layout (stride = 16, 32 or 48 floats, 64-B aligned): [0..2] dL/dmean2D (x, y, |x|+|y|),
+// Row layout (stride = the instantiation's 12 + SMAX floats rounded up to float4s, 16-B aligned): [0..2] dL/dmean2D (x, y, |x|+|y|),
 // [3..5] dL/dconic (x, y, w), [6] dL/dopacity, [7..9] dL/drgb, [10] dL/ddepth, [11..11+S) dL/dsemantic.
 #include "sgr_math.h"
 
@@ -727,7 +727,7 @@ sgr_blend_bwd_kernel_v2(SGR_BWD_ARGS) {
     __shared__ __attribute__((aligned(16))) float2 sW[4][CH][64];  // [wave][visit][pixel ^ swizzle] = {Gd, wm}
     __shared__ float4 sDL[4][64];                                    // [wave][pixel] = dL/d{r, g, b, depth}
     __shared__ int sVis[4][CH];                                      // slot of each visit of the chunk
-    (void)S; (void)semantics; (void)dL_dpixel_semantics; (void)row_stride;
+    (void)S; (void)semantics; (void)dL_dpixel_semantics;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t tx, ty;
@@ -940,7 +940,7 @@ sgr_blend_bwd_kernel_v2(SGR_BWD_ARGS) {
         if (flags) {
             const uint32_t u = sU[tid];
             touched[u] = 1;
-            float4* row = reinterpret_cast<float4*>(partials + (size_t)u * 16);
+            float4* row = reinterpret_cast<float4*>(partials + (size_t)u * row_stride);
             const float4* src = reinterpret_cast<const float4*>(&sAcc[tid * ACCW]);
             float4 r0 = src[0], r1 = src[1], r2 = src[2];
             if (DET) {
@@ -1006,7 +1006,12 @@ static void launch_bwd(bool cull, bool dpp, bool det, bool v2, unsigned tiles, h
 }
 
 // floats per partial row for S semantic channels: the kernel's SMAX bucket writes ceil((11+SMAX)/4) float4
-int sgr_partial_row_stride(int S) { return S <= 4 ? 16 : (S <= 20 ? 32 : 48); }
+// = NVAL of the instantiation that serves S (12 floats = 48 bytes at S = 0: the rows are only 16-byte aligned; padding
+// them to 64 bytes cost 25 % more row traffic in this kernel's stores and in the per-Gaussian row sum's loads)
+int sgr_partial_row_stride(int S) {
+    const int smax = S == 0 ? 0 : (S <= 4 ? 4 : (S <= 8 ? 8 : (S <= 12 ? 12 : (S <= 16 ? 16 : (S <= 20 ? 20 : (S <= 24 ? 24 : 32))))));
+    return (SGR_ROW_BASE + smax + 3) / 4 * 4;
+}
 
 void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, bool v2, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
                           int H, int S, const float* bg, const float4* rec, const uint32_t* u0, const float* semantics, const float* alphas, const uint32_t* n_contrib,

@@ -137,3 +137,69 @@ def _async_body():
     for p, gr in zip(params, grads):
         assert torch.equal(p.grad, gr)
     assert torch.isfinite(junk).all()
+
+
+def test_scene_graph_segments_keep_the_factored_exchange():
+    """Background + two posed actors with Fourier DC features: the rasterizer's SH input is scene.compose's NON-leaf cat
+    over sub-models (street_gaussian_model.py:287-449).  With `segments=` the reducer rebuilds every sub-model's
+    features_dc / features_rest gradient from the view's dRGB (+ the posed models' world positions and IDFT rows carried
+    in the payload) -- equal to what autograd sends through compose's backward when the SH tensor is NOT detached."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from street_gaussians_amd import scene
+    cam = _views(1)[0]
+    g = torch.Generator().manual_seed(31)
+    r = lambda *s: torch.randn(*s, generator=g)
+    M, C = 16, 3
+    base = syn.make_scene(9000, cam, S=0, seed=13)
+
+    def seg(lo, hi, actor):
+        n = hi - lo
+        op = base.opacities[lo:hi].clamp(1e-4, 1 - 1e-4)
+        kw = dict(xyz=base.means3D[lo:hi].clone(), rotation=base.rotations[lo:hi].clone(), scaling=torch.log(base.scales[lo:hi]),
+                  opacity=torch.log(op / (1 - op)), features_rest=base.shs[lo:hi, 1:, :].clone())
+        if actor:
+            kw.update(features_dc=base.shs[lo:hi, :1, :].repeat(1, C, 1) + 0.1 * r(n, C, 3), idft=torch.tensor([0.6, 0.3, 0.1]) + 0.05 * r(C),
+                      pose=torch.tensor([1.0, 0.02 * actor, -0.01, 0.03, 0.1 * actor, -0.05, 0.2]))
+            kw["xyz"] = kw["xyz"] - kw["pose"][4:]  # keep the posed model inside the view
+        else:
+            kw.update(features_dc=base.shs[lo:hi, :1, :].clone())
+        t = {k: (v.float().cuda().requires_grad_(k != "idft") if torch.is_tensor(v) else v) for k, v in kw.items()}
+        return scene.Segment(**t)
+
+    segs = [seg(0, 6000, 0), seg(6000, 7800, 1), seg(7800, 9000, 2)]
+    w = {k: dev(v) for k, v in syn.loss_weights(cam, seed=4).items()}
+
+    def run(detach):
+        for s in segs:
+            for name in ("xyz", "rotation", "scaling", "opacity", "features_dc", "features_rest", "pose"):
+                t = getattr(s, name)
+                if t is not None:
+                    t.grad = None
+        means, rot, scl, opa, shs, _ = scene.compose(segs, M, 0)
+        color, radii, depth, alpha, _ = GaussianRasterizer(settings(cam))(means, None, opa, shs=shs.detach() if detach else shs,
+                                                                          scales=scl, rotations=rot)
+        torch.autograd.backward([color, depth, alpha], [w["color"], w["depth"], w["alpha"]])
+
+    run(detach=False)
+    want = [(s.features_dc.grad.clone(), s.features_rest.grad.clone(), s.xyz.grad.clone()) for s in segs]
+    port = socket.socket()
+    port.bind(("127.0.0.1", 0))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port.getsockname()[1])
+    port.close()
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        sh_segments = [multiview.SHSegment(s.features_dc, s.features_rest, s.xyz if s.pose is None else None) for s in segs]
+        with multiview.FactoredGradReducer([segs[0].xyz], segments=sh_segments, force=True) as red:
+            for rnd in range(2):  # twice: the payload buffers alternate
+                red.set_frame([0, 1, 2], idft={1: segs[1].idft, 2: segs[2].idft})
+                run(detach=True)
+                assert not segs[1].features_dc.grad.any()  # nothing of dL/dSH went down the graph (compose wrote zeros)
+                red.all_reduce()
+                for s, (gdc, grest, gxyz) in zip(segs, want):
+                    for got, ref in ((s.features_dc.grad, gdc), (s.features_rest.grad, grest)):
+                        scale = float(ref.abs().max())
+                        assert float((got - ref).abs().max()) <= 3e-6 * scale, float((got - ref).abs().max()) / scale
+                assert torch.equal(segs[0].xyz.grad, want[0][2])  # the dense path: untouched by the factoring
+            assert red.nbytes == 4 * (segs[0].xyz.numel() + 3 + 3 * 9000 + 3 * 3000 + 2 * C)
+    finally:
+        dist.destroy_process_group()
