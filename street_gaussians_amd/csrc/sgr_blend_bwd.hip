@@ -400,6 +400,20 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
     const bool fold_leader = (lane & 3) == 0;
     const int acc_fold_off = (DET ? (wave >> 1) : 0) * BATCH * ACCW + 4 * fold_t0 + (lane >> 4);
 
+    // The staging of a round is a dependent pair of gathers (list entry -> record).  The first half is taken out of the
+    // round: the entry (and its hit byte) of round n + 1 is loaded while round n walks -- 2 VGPRs held across the walk --
+    // so that a round opens with the record gather itself (SGR_BWD_PREFETCH, A/B in DESIGN.md section 10).
+#ifndef SGR_BWD_PREFETCH
+#define SGR_BWD_PREFETCH 1
+#endif
+    uint32_t g_pre = 0, h_pre = 0;
+    if (SGR_BWD_PREFETCH) {
+        const int pos0 = (tid < BATCH) ? (maxc - 1) - tid : -1;
+        if (pos0 >= 0) {
+            g_pre = point_list[range.x + (uint32_t)pos0];
+            if (CULL && hit4 != nullptr) h_pre = hit4[range.x + (uint32_t)pos0];
+        }
+    }
     for (int hi = maxc - 1; hi >= 0; hi -= BATCH) {
         // slot t of this batch holds list position hi - t (descending: back to front)
         sgr_lds_barrier();  // previous batch fully consumed (rows written) before LDS is overwritten
@@ -413,7 +427,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
             for (int k4 = 0; k4 < ACCW / 4; k4++) z[k4] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (pos >= 0) {
-            const uint32_t g = point_list[range.x + (uint32_t)pos];
+            const uint32_t g = SGR_BWD_PREFETCH ? g_pre : point_list[range.x + (uint32_t)pos];
             const float4* r = rec + 4 * (size_t)g;  // one 64-byte line
             const float4 a = r[0];
             const float4 b = r[1];
@@ -430,8 +444,16 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
             }
             // which quadrants to walk: the forward's record of the quadrants it blended this instance into (exactly the
             // visits that can contribute; nothing to compute), else the geometric cull the forward uses
-            mask4 = CULL ? (hit4 != nullptr ? (uint32_t)hit4[range.x + (uint32_t)pos] : sgr_quadrant_mask(a, b, tx0, ty0))
+            mask4 = CULL ? (hit4 != nullptr ? (SGR_BWD_PREFETCH ? h_pre : (uint32_t)hit4[range.x + (uint32_t)pos])
+                                            : sgr_quadrant_mask(a, b, tx0, ty0))
                          : 0xFu;
+        }
+        if (SGR_BWD_PREFETCH) {  // next round's list entries: in flight under this round's walk
+            const int posn = stager ? (hi - BATCH) - tid : -1;
+            if (posn >= 0) {
+                g_pre = point_list[range.x + (uint32_t)posn];
+                if (CULL && hit4 != nullptr) h_pre = hit4[range.x + (uint32_t)posn];
+            }
         }
         if (stager) {
 #pragma unroll

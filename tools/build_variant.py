@@ -1,0 +1,33 @@
+#!/usr/bin/env python
+"""Builds a VARIANT of libsgr_hip.so with extra compiler flags (A/B of -D switches) into
+street_gaussians_amd/variants/libsgr_hip_<name>.so; select it with SGR_LIB=<path> SGR_BINDING=ctypes.
+
+    python tools/build_variant.py <name> <flags...>        e.g.  python tools/build_variant.py nopf -DSGR_BWD_PREFETCH=0
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from street_gaussians_amd import build as b  # noqa: E402
+
+name, flags = sys.argv[1], sys.argv[2:]
+out_dir = os.path.join(b.HERE, "variants")
+obj_dir = os.path.join(b.OBJ, "variant_" + name)
+os.makedirs(out_dir, exist_ok=True)
+os.makedirs(obj_dir, exist_ok=True)
+
+
+def one(src):
+    o = os.path.join(obj_dir, src.replace(".hip", ".o"))
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + b.FLAGS + flags + ["-c", os.path.join(b.CSRC, src), "-o", o])
+    return o
+
+
+with ThreadPoolExecutor(max_workers=8) as ex:
+    objs = list(ex.map(one, b.SOURCES))
+lib = os.path.join(out_dir, f"libsgr_hip_{name}.so")
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+print(lib)
