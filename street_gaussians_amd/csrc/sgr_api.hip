@@ -27,12 +27,12 @@ void sgr_launch_duplicate(int P, const SgrGeomView& gv, const uint32_t* order, c
 void sgr_launch_tile_ranges(int L, const uint32_t* keys, uint2* ranges, uint8_t* touched, hipStream_t s);
 void sgr_launch_compose_keys(int L, const uint32_t* tile_keys, const uint32_t* point_list, const float4* rec, uint64_t* out,
                              hipStream_t s);
-void sgr_launch_blend_fwd(bool cull, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W, int H,
+void sgr_launch_blend_fwd(bool cull, bool exact, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W, int H,
                           int S, const float4* rec, const float* semantics, const float* bg, float* out_color,
                           float* out_depth, float* out_alpha, float* out_semantic, uint32_t* n_contrib, uint8_t* hit4,
                           hipStream_t s);
 int sgr_partial_row_stride(int S);
-void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, bool v2, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
+void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, bool v2, bool exact, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
                           int H, int S, const float* bg, const float4* rec, const uint32_t* u0, const float* semantics, const float* alphas,
                           const uint32_t* n_contrib, const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth,
                           const float* dL_dalpha, const float* dL_dsem, float* partials, uint8_t* touched, hipStream_t s);
@@ -57,6 +57,8 @@ static bool env_flag(const char* name) {
     return v && v[0] && v[0] != '0';
 }
 
+// (bit 6: the preprocess stages its SH rows through LDS -- an A/B that measured slower; bit 7: EXACT parity mode of the
+// blend kernels, sgr_math.h sgr_power_ref: the reference's power expression + accurate expf + true division)
 // A/B switches of the blend kernels (tests and tools/gpu_ab.sh): bit 0 no quadrant cull, 1 no DPP reduction,
 // 2 no deterministic LDS combine, 3 backward ignores the forward's hit record, 4 the S = 0 backward runs the
 // transposed-accumulation kernel (an A/B design that measured slower than the cross-lane reduction), 5 the
@@ -69,7 +71,7 @@ static int switches() {
     if (v < 0) {
         v = (env_flag("SGR_NO_CULL") ? 1 : 0) | (env_flag("SGR_NO_DPP") ? 2 : 0) | (env_flag("SGR_NO_DET") ? 4 : 0) |
             (env_flag("SGR_NO_HITS") ? 8 : 0) | (env_flag("SGR_V2") ? 16 : 0) | (env_flag("SGR_PRE_STAGE") ? 64 : 0) |
-            (env_flag("SGR_SW7") ? 128 : 0) | (env_flag("SGR_SW8") ? 256 : 0) | (env_flag("SGR_SW9") ? 512 : 0);
+            (env_flag("SGR_EXACT") ? 128 : 0) | (env_flag("SGR_SW8") ? 256 : 0) | (env_flag("SGR_SW9") ? 512 : 0);
         g_switches.store(v, std::memory_order_relaxed);
     }
     return v;
@@ -356,7 +358,7 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     }
     prof_begin(5, stream);
     const bool cull = !(switches() & 1);
-    sgr_launch_blend_fwd(cull, gx, gy, iv.ranges, bv.vals[cur], W, H, S, gv.rec, semantics,
+    sgr_launch_blend_fwd(cull, (switches() & 128) != 0, gx, gy, iv.ranges, bv.vals[cur], W, H, S, gv.rec, semantics,
                          background, out_color, out_depth, out_alpha, out_semantic, iv.n_contrib, bv.hit4, stream);
     SGR_STAGE("blend_fwd");
     prof_end(stream);
@@ -469,7 +471,7 @@ int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, 
         // the forward's record of which (quadrant, instance) pairs blended at all; switch 8: the kernel redoes the
         // geometric cull instead (A/B and tests: the two walks must give bit-identical gradients)
         const uint8_t* hits = (sw & 8) ? nullptr : bv.hit4;
-        sgr_launch_blend_bwd(cull, dpp, det, (sw & 16) != 0, gx, gy, iv.ranges, bv.vals[cur], W, H, S, background, gv.rec, gv.u0, semantics,
+        sgr_launch_blend_bwd(cull, dpp, det, (sw & 16) != 0, (sw & 128) != 0, gx, gy, iv.ranges, bv.vals[cur], W, H, S, background, gv.rec, gv.u0, semantics,
                              alphas, iv.n_contrib, hits, dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, partials,
                              touched, stream);
         SGR_STAGE("blend_bwd");

@@ -295,7 +295,7 @@ __device__ __forceinline__ void sgr_lds_barrier() {
     __syncthreads();
 }
 
-template <int SMAX, bool CULL, bool DPP, bool DET, int BATCH>
+template <int SMAX, bool CULL, bool DPP, bool DET, int BATCH, bool EXACT = false>
 __device__ __forceinline__ void
 sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int S,
                      int gx, int gy, const float* __restrict__ bg_color, const float4* __restrict__ rec,
@@ -364,7 +364,10 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
     }
     const float bgdot = bg_color[0] * dLdC0 + bg_color[1] * dLdC1 + bg_color[2] * dLdC2;
     // d(pixel)/d(ndc) (backward.cu:501-502) with the 1/log2(e) of the pre-scaled conic folded in
-    const float kx = (0.5f * (float)W) / SGR_LOG2E, ky = (0.5f * (float)H) / SGR_LOG2E;
+    // EXACT (parity mode): the conic is staged with exact power-of-two scalings only (scale constant 1 instead of log2 e),
+    // G comes from the reference's own power expression + the accurate expf, T is recovered by a true division
+    constexpr float LSC = EXACT ? 1.0f : SGR_LOG2E;
+    const float kx = (0.5f * (float)W) / LSC, ky = (0.5f * (float)H) / LSC;
 
     // colour / depth recurrences as register pairs {C0, C1} and {C2, D}: the four channels follow the same recurrence,
     // and the float4 {r, g, b, depth} read from LDS is already laid out that way, so they run on v_pk_mul / v_pk_fma
@@ -433,7 +436,8 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
             const float4 b = r[1];
             const float4 d4 = r[3];
             sA[tid] = a;
-            sB[tid] = make_float4(-0.5f * SGR_LOG2E * b.x, -SGR_LOG2E * b.y, -0.5f * SGR_LOG2E * b.z, b.w);
+            sB[tid] = EXACT ? make_float4(-0.5f * b.x, -b.y, -0.5f * b.z, b.w)
+                            : make_float4(-0.5f * SGR_LOG2E * b.x, -SGR_LOG2E * b.y, -0.5f * SGR_LOG2E * b.z, b.w);
             sC[tid] = r[2];
             const uint32_t dy_ = __float_as_uint(d4.y);
             const uint32_t rx0 = dy_ & 1023u, ry0 = (dy_ >> 10) & 1023u, rw = dy_ >> 20;
@@ -487,7 +491,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                     const float oma = 1.0f - alpha;
                     float inv1ma = __builtin_amdgcn_rcpf(oma);
                     inv1ma = fmaf(fmaf(-oma, inv1ma, 1.0f), inv1ma, inv1ma);  // Newton step: T recovery compounds per layer
-                    T = T * inv1ma;  // T = T / (1 - alpha)
+                    T = EXACT ? T / oma : T * inv1ma;  // T = T / (1 - alpha) (backward.cu:547)
                     wm = alpha * T;
                     const float one_m_la = 1.0f - last_alpha;
                     float d;
@@ -539,7 +543,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                     }
                     last_alpha = alpha;
                     d *= T;
-                    Gd = G * fmaf(-T_final * inv1ma, bgdot, d);  // backward.cu:611-614
+                    Gd = EXACT ? G * (d + (-T_final / oma) * bgdot) : G * fmaf(-T_final * inv1ma, bgdot, d);  // backward.cu:611-614
                 }
                 if (SMAX > 0 && !(DPP && SGR_FOLD)) {
 #pragma unroll
@@ -626,8 +630,8 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                 const int j0 = chunk * 64 + sgr_pop_lowest(m);
                 const float4 a0 = sA[j0], q0 = sB[j0];
                 const float dx0 = a0.x - pxf, dy0 = a0.y - pyf;
-                const float pw0 = sgr_power2(q0.x, q0.y, q0.z, dx0, dy0);
-                const float G0 = __builtin_amdgcn_exp2f(pw0);
+                const float pw0 = EXACT ? sgr_power_ref(-2.0f * q0.x, -q0.y, -2.0f * q0.z, dx0, dy0) : sgr_power2(q0.x, q0.y, q0.z, dx0, dy0);
+                const float G0 = EXACT ? expf(pw0) : __builtin_amdgcn_exp2f(pw0);
                 process(j0, q0, dx0, dy0, pw0, G0, fminf(0.99f, q0.w * G0), true);
             }
             while (m) {
@@ -638,9 +642,9 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                 const float4 a0 = sA[j0], q0 = sB[j0];
                 const float4 a1 = sA[j1], q1 = sB[j1];
                 const float dx0 = a0.x - pxf, dy0 = a0.y - pyf, dx1 = a1.x - pxf, dy1 = a1.y - pyf;
-                const float pw0 = sgr_power2(q0.x, q0.y, q0.z, dx0, dy0);
-                const float pw1 = sgr_power2(q1.x, q1.y, q1.z, dx1, dy1);
-                const float G0 = __builtin_amdgcn_exp2f(pw0), G1 = __builtin_amdgcn_exp2f(pw1);
+                const float pw0 = EXACT ? sgr_power_ref(-2.0f * q0.x, -q0.y, -2.0f * q0.z, dx0, dy0) : sgr_power2(q0.x, q0.y, q0.z, dx0, dy0);
+                const float pw1 = EXACT ? sgr_power_ref(-2.0f * q1.x, -q1.y, -2.0f * q1.z, dx1, dy1) : sgr_power2(q1.x, q1.y, q1.z, dx1, dy1);
+                const float G0 = EXACT ? expf(pw0) : __builtin_amdgcn_exp2f(pw0), G1 = EXACT ? expf(pw1) : __builtin_amdgcn_exp2f(pw1);
                 const float al0 = fminf(0.99f, q0.w * G0), al1 = fminf(0.99f, q1.w * G1);
                 process(j0, q0, dx0, dy0, pw0, G0, al0, true);
                 process(j1, q1, dx1, dy1, pw1, G1, al1, true);
@@ -712,6 +716,12 @@ template <bool CULL, bool DPP, bool DET>
 __global__ void __launch_bounds__(SGR_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
 sgr_blend_bwd_kernel_s0(SGR_BWD_ARGS) {
     sgr_blend_bwd_body<0, CULL, DPP, DET, SgrBwdBatch<0>::value>(SGR_BWD_PASS);
+}
+// parity mode (sgr_math.h: sgr_power_ref): the shipped configuration only (cull / hit record, DPP, deterministic)
+template <int SMAX>
+__global__ void __launch_bounds__(SGR_TILE_THREADS)
+sgr_blend_bwd_kernel_exact(SGR_BWD_ARGS) {
+    sgr_blend_bwd_body<SMAX, true, true, true, SgrBwdBatch<SMAX>::value, true>(SGR_BWD_PASS);
 }
 
 // =====================================================================================================================
@@ -980,12 +990,18 @@ sgr_blend_bwd_kernel_v2(SGR_BWD_ARGS) {
 }
 
 template <int SMAX>
-static void launch_bwd(bool cull, bool dpp, bool det, bool v2, unsigned tiles, hipStream_t s, const uint2* ranges, const uint32_t* point_list,
+static void launch_bwd(bool cull, bool dpp, bool det, bool v2, bool exact, unsigned tiles, hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                        int W, int H, int S, int gx, int gy, const float* bg, const float4* rec, const uint32_t* u0, const float* semantics,
                        const float* alphas,
                        const uint32_t* n_contrib, const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth,
                        const float* dL_dalpha, const float* dL_dsem, float* partials, int row_stride, uint8_t* touched) {
     constexpr bool kDet = true;  // every instantiation has the two-row deterministic combine (see SgrBwdBatch)
+    if (exact) {
+        sgr_blend_bwd_kernel_exact<SMAX><<<tiles, SGR_TILE_THREADS, 0, s>>>(
+            ranges, point_list, W, H, S, gx, gy, bg, rec, u0, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth, dL_dalpha,
+            dL_dsem, partials, row_stride, touched);
+        return;
+    }
     if constexpr (SMAX == 0) {
         if (v2 && dpp) {  // transposed accumulation (S = 0)
 #define SGR_V2(C, D) sgr_blend_bwd_kernel_v2<C, D><<<tiles, SGR_TILE_THREADS, 0, s>>>(                                    \
@@ -1035,14 +1051,14 @@ int sgr_partial_row_stride(int S) {
     return (SGR_ROW_BASE + smax + 3) / 4 * 4;
 }
 
-void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, bool v2, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
+void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, bool v2, bool exact, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
                           int H, int S, const float* bg, const float4* rec, const uint32_t* u0, const float* semantics, const float* alphas, const uint32_t* n_contrib,
                           const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha,
                           const float* dL_dsem, float* partials, uint8_t* touched, hipStream_t s) {
     if (gx <= 0 || gy <= 0) return;
     const unsigned tiles = sgr_xcd_grid_blocks(gx, gy);  // supertile-ordered grid incl. padding blocks
     const int stride = sgr_partial_row_stride(S);
-#define SGR_BWD(N) launch_bwd<N>(cull, dpp, det, v2, tiles, s, ranges, point_list, W, H, S, gx, gy, bg, rec, u0, semantics, alphas, \
+#define SGR_BWD(N) launch_bwd<N>(cull, dpp, det, v2, exact, tiles, s, ranges, point_list, W, H, S, gx, gy, bg, rec, u0, semantics, alphas, \
                                  n_contrib, hit4, dL_dpix, dL_ddepth, dL_dalpha, dL_dsem, partials, stride, touched)
     if (S == 0) SGR_BWD(0);
     else if (S <= 4) SGR_BWD(4);

@@ -15,7 +15,7 @@
 
 #define SGR_TILE_THREADS 256
 
-template <int SMAX, bool CULL>
+template <int SMAX, bool CULL, bool EXACT>
 __global__ void __launch_bounds__(SGR_TILE_THREADS)
 sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int S,
                      int gx, int gy, const float4* __restrict__ rec, const float* __restrict__ semantics,
@@ -88,7 +88,8 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
             const float4 a = r[0];
             const float4 b = r[1];
             sA[tid] = a;
-            sB[tid] = make_float4(-0.5f * SGR_LOG2E * b.x, -SGR_LOG2E * b.y, -0.5f * SGR_LOG2E * b.z, b.w);
+            // EXACT (parity mode): the conic as it is -- the walk evaluates the reference's own power expression
+            sB[tid] = EXACT ? b : make_float4(-0.5f * SGR_LOG2E * b.x, -SGR_LOG2E * b.y, -0.5f * SGR_LOG2E * b.z, b.w);
             sC[tid] = r[2];
             if (SMAX > 0) {  // channels S..SMAX-1 are staged as zeros so the walk needs no per-channel test
 #pragma unroll
@@ -127,20 +128,37 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                     const bool blend = k1 && k2 && !k3;
                     const float4 c = sC[j];
                     const float w = blend ? alpha * T : 0.0f;
-                    C0 = fmaf(c.x, w, C0);
-                    C1 = fmaf(c.y, w, C1);
-                    C2 = fmaf(c.z, w, C2);
-                    Dp = fmaf(c.w, w, Dp);
+                    if (EXACT) {
+                        // the reference's association, unfused: C[ch] += features[ch] * alpha * T (forward.cu:438-441)
+                        const float ae = blend ? alpha : 0.0f;
+                        C0 = C0 + (c.x * ae) * T;
+                        C1 = C1 + (c.y * ae) * T;
+                        C2 = C2 + (c.z * ae) * T;
+                        Dp = Dp + (c.w * ae) * T;
+                    } else {
+                        C0 = fmaf(c.x, w, C0);
+                        C1 = fmaf(c.y, w, C1);
+                        C2 = fmaf(c.z, w, C2);
+                        Dp = fmaf(c.w, w, Dp);
+                    }
                     Wt += w;
                     if (SMAX > 0) {
                         const float4* sj = reinterpret_cast<const float4*>(&sSem[j * SMAX]);
+                        const float ae = blend ? alpha : 0.0f;
 #pragma unroll
                         for (int c4 = 0; c4 < SMAX / 4; c4++) {
                             const float4 sv = sj[c4];
-                            sem[4 * c4] = fmaf(sv.x, w, sem[4 * c4]);
-                            sem[4 * c4 + 1] = fmaf(sv.y, w, sem[4 * c4 + 1]);
-                            sem[4 * c4 + 2] = fmaf(sv.z, w, sem[4 * c4 + 2]);
-                            sem[4 * c4 + 3] = fmaf(sv.w, w, sem[4 * c4 + 3]);
+                            if (EXACT) {
+                                sem[4 * c4] = sem[4 * c4] + (sv.x * ae) * T;
+                                sem[4 * c4 + 1] = sem[4 * c4 + 1] + (sv.y * ae) * T;
+                                sem[4 * c4 + 2] = sem[4 * c4 + 2] + (sv.z * ae) * T;
+                                sem[4 * c4 + 3] = sem[4 * c4 + 3] + (sv.w * ae) * T;
+                            } else {
+                                sem[4 * c4] = fmaf(sv.x, w, sem[4 * c4]);
+                                sem[4 * c4 + 1] = fmaf(sv.y, w, sem[4 * c4 + 1]);
+                                sem[4 * c4 + 2] = fmaf(sv.z, w, sem[4 * c4 + 2]);
+                                sem[4 * c4 + 3] = fmaf(sv.w, w, sem[4 * c4 + 3]);
+                            }
                         }
                     }
                     T = blend ? test_T : T;
@@ -160,8 +178,9 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                     const int b0 = sgr_pop_lowest(m);
                     const int j0 = chunk * 64 + b0;
                     const float4 a0 = sA[j0], q0 = sB[j0];
-                    const float pw0 = sgr_power2(q0.x, q0.y, q0.z, a0.x - pxf, a0.y - pyf);
-                    blend_one(j0, b0, pw0, fminf(0.99f, q0.w * __builtin_amdgcn_exp2f(pw0)));
+                    const float pw0 = EXACT ? sgr_power_ref(q0.x, q0.y, q0.z, a0.x - pxf, a0.y - pyf)
+                                            : sgr_power2(q0.x, q0.y, q0.z, a0.x - pxf, a0.y - pyf);
+                    blend_one(j0, b0, pw0, fminf(0.99f, q0.w * (EXACT ? expf(pw0) : __builtin_amdgcn_exp2f(pw0))));
                 }
                 while (m) {
                     // two survivors per trip: their LDS reads and exp() are independent, only the blend is ordered
@@ -170,10 +189,12 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                     const int j0 = chunk * 64 + b0, j1 = chunk * 64 + b1;
                     const float4 a0 = sA[j0], q0 = sB[j0];
                     const float4 a1 = sA[j1], q1 = sB[j1];
-                    const float pw0 = sgr_power2(q0.x, q0.y, q0.z, a0.x - pxf, a0.y - pyf);
-                    const float pw1 = sgr_power2(q1.x, q1.y, q1.z, a1.x - pxf, a1.y - pyf);
-                    const float al0 = fminf(0.99f, q0.w * __builtin_amdgcn_exp2f(pw0));
-                    const float al1 = fminf(0.99f, q1.w * __builtin_amdgcn_exp2f(pw1));
+                    const float pw0 = EXACT ? sgr_power_ref(q0.x, q0.y, q0.z, a0.x - pxf, a0.y - pyf)
+                                            : sgr_power2(q0.x, q0.y, q0.z, a0.x - pxf, a0.y - pyf);
+                    const float pw1 = EXACT ? sgr_power_ref(q1.x, q1.y, q1.z, a1.x - pxf, a1.y - pyf)
+                                            : sgr_power2(q1.x, q1.y, q1.z, a1.x - pxf, a1.y - pyf);
+                    const float al0 = fminf(0.99f, q0.w * (EXACT ? expf(pw0) : __builtin_amdgcn_exp2f(pw0)));
+                    const float al1 = fminf(0.99f, q1.w * (EXACT ? expf(pw1) : __builtin_amdgcn_exp2f(pw1)));
                     blend_one(j0, b0, pw0, al0);
                     blend_one(j1, b1, pw1, al1);  // if the wave finished on j0 every lane's threshold is +inf: a no-op
                 }
@@ -204,27 +225,27 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
 }
 
 template <int SMAX>
-static void launch_fwd(bool cull, unsigned tiles, hipStream_t s, const uint2* ranges, const uint32_t* point_list, int W,
+static void launch_fwd(bool cull, bool exact, unsigned tiles, hipStream_t s, const uint2* ranges, const uint32_t* point_list, int W,
                        int H, int S, int gx, int gy, const float4* rec, const float* semantics, const float* bg, float* out_color, float* out_depth, float* out_alpha,
                        float* out_semantic, uint32_t* n_contrib, uint8_t* hit4) {
-    if (cull)
-        sgr_blend_fwd_kernel<SMAX, true><<<tiles, SGR_TILE_THREADS, 0, s>>>(ranges, point_list, W, H, S, gx, gy, rec, semantics,
-                                                                           bg, out_color, out_depth, out_alpha,
-                                                                           out_semantic, n_contrib, hit4);
-    else
-        sgr_blend_fwd_kernel<SMAX, false><<<tiles, SGR_TILE_THREADS, 0, s>>>(ranges, point_list, W, H, S, gx, gy, rec, semantics,
-                                                                            bg, out_color, out_depth, out_alpha,
-                                                                            out_semantic, n_contrib, hit4);
+#define SGR_FWD_GO(C, E)                                                                                              \
+    sgr_blend_fwd_kernel<SMAX, C, E><<<tiles, SGR_TILE_THREADS, 0, s>>>(ranges, point_list, W, H, S, gx, gy, rec, semantics, \
+                                                                        bg, out_color, out_depth, out_alpha, out_semantic,   \
+                                                                        n_contrib, hit4)
+    if (exact) SGR_FWD_GO(true, true);  // parity mode: with the cull (it is invisible in the results)
+    else if (cull) SGR_FWD_GO(true, false);
+    else SGR_FWD_GO(false, false);
+#undef SGR_FWD_GO
 }
 
 // S must be <= SGR_SEM_MAX (checked by the caller).
-void sgr_launch_blend_fwd(bool cull, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W, int H,
+void sgr_launch_blend_fwd(bool cull, bool exact, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W, int H,
                           int S, const float4* rec, const float* semantics,
                           const float* bg, float* out_color, float* out_depth, float* out_alpha, float* out_semantic,
                           uint32_t* n_contrib, uint8_t* hit4, hipStream_t s) {
     if (gx <= 0 || gy <= 0) return;
     const unsigned tiles = sgr_xcd_grid_blocks(gx, gy);  // supertile-ordered grid incl. padding blocks
-#define SGR_FWD(N) launch_fwd<N>(cull, tiles, s, ranges, point_list, W, H, S, gx, gy, rec, semantics, bg, \
+#define SGR_FWD(N) launch_fwd<N>(cull, exact, tiles, s, ranges, point_list, W, H, S, gx, gy, rec, semantics, bg, \
                                  out_color, out_depth, out_alpha, out_semantic, n_contrib, hit4)
     if (S == 0) SGR_FWD(0);
     else if (S <= 4) SGR_FWD(4);

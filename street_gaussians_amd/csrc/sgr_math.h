@@ -272,6 +272,16 @@ SGR_HD float sgr_power2(float qa, float qb, float qc, float dx, float dy) {
     return fmaf(qc * dy, dy, u * dx);
 }
 
+// "Exact" (parity) mode of the blend kernels: the reference's own expression, operation by operation and without
+// contraction (forward.cu:420, backward.cu:536), followed by the library's accurate expf -- the arithmetic of oracle/_ref's
+// strict build and of the C oracle, so that alpha_out (and with it T_final = 1 - alpha_out, the amplifier of every
+// end-to-end gradient difference) is reproduced bit for bit.  ~13 VALU instructions more per pixel
+// and visit than sgr_power2 + v_exp_f32: opt-in (sgr_test_switches bit 7 / SGR_EXACT=1), not the default.
+SGR_HD float sgr_power_ref(float cx, float cy, float cz, float dx, float dy) {
+#pragma clang fp contract(off)
+    return -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Per-Gaussian backward maths (float tolerance only, so contraction is left to the compiler).
 

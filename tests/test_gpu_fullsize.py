@@ -222,6 +222,17 @@ def test_threeway_against_reference_kernels_at_baseline_size(name, P, S):
 
     fw = oracle.forward(**kw)
     gor = oracle.backward(fw, wts["color"], wts["depth"], wts["alpha"], gsem, parallel="exact")
+    # the HIP path in its parity mode (sgr_math.h sgr_power_ref: the reference's power expression, accurate expf, true
+    # division): the forward must then reproduce the strict build's alpha image bit for bit
+    from gpu_utils import switches
+    from street_gaussians_amd import _C
+    with switches(_C.EXACT):
+        res_x, _ = raw_forward(kw)
+        g_x = raw_backward(kw, res_x, wts)
+        torch.cuda.synchronize()
+        img_x = {k: npy(res_x[k]) for k in ["color", "depth", "alpha", "semantic"]}
+        g_x = {k: npy(v) for k, v in g_x.items()}
+        del res_x
     res, internal = raw_forward(kw)
     g = raw_backward(kw, res, wts)
     torch.cuda.synchronize()
@@ -243,6 +254,8 @@ def test_threeway_against_reference_kernels_at_baseline_size(name, P, S):
                             "oracle_vs_ref": _image_stats(getattr(fw, k), ref_img[k].reshape(getattr(fw, k).shape))}
         if img_fmad is not None:
             rec["images"][k]["fmad_vs_ref"] = _image_stats(img_fmad[k], ref_img[k])
+        rec["images"][k]["hip_exact_vs_ref"] = _image_stats(img_x[k], ref_img[k])
+        rec["images"][k]["hip_exact_bit_identical"] = bool((img_x[k].reshape(-1) == ref_img[k].reshape(-1)).all())
     for k in GRADS:
         if k == "semantics" and not S:
             continue
@@ -257,6 +270,9 @@ def test_threeway_against_reference_kernels_at_baseline_size(name, P, S):
             rec["grads"][k]["fmad_vs_ref"] = _outside(f, r, 1e-4, 2e-6)
             rec["grads"][k]["fmad_vs_ref_1e-5"] = _outside(f, r, 1e-4, 1e-5)
             rec["grads"][k]["hip_vs_fmad"] = _outside(h, f, 1e-4, 2e-6)
+        hx = g_x[k].reshape(gor[k].shape)
+        rec["grads"][k]["hip_exact_vs_ref"] = _outside(hx, r, 1e-4, 2e-6)
+        rec["grads"][k]["hip_exact_vs_ref_1e-5"] = _outside(hx, r, 1e-4, 1e-5)
     try:
         cur = {}
         if os.path.exists(THREEWAY_REPORT):
@@ -274,6 +290,10 @@ def test_threeway_against_reference_kernels_at_baseline_size(name, P, S):
     for k, st in rec["images"].items():
         assert st["hip_vs_ref"]["outside_frac"] <= IMG_FLIP_FRAC, (k, st)
         assert st["hip_vs_ref"]["worst_abs_over_scale"] <= IMG_FLIP_CAP, (k, st)
+    # parity mode: alpha_out (hence T_final) is the strict build's, bit for bit; its gradients sit next to the C oracle's
+    assert rec["images"]["alpha"]["hip_exact_bit_identical"], rec["images"]["alpha"]
+    for k, st in rec["grads"].items():
+        assert st["hip_exact_vs_ref"]["outside"] <= 1.5 * st["oracle_vs_ref"]["outside"] + 2e-5 * st["hip_vs_ref"]["n"] + 8, (k, st)
     for k, st in rec["grads"].items():
         n = st["hip_vs_ref"]["n"]
         # yardstick: how far two VALID builds of the reference's own sources are from each other (contraction off vs the

@@ -702,3 +702,39 @@ def test_degenerate_inputs():
     big = settings(cam)._replace(image_width=16400, image_height=8)
     with pytest.raises(SgrError, match="not supported"):
         GaussianRasterizer(big)(t["means3D"], None, t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+
+
+@pytest.mark.parametrize("S", [0, 3, 19])
+def test_exact_parity_mode_is_bit_faithful_to_the_reference_kernels(S):
+    """sgr_test_switches bit 7 / SGR_EXACT=1: the blend kernels evaluate the reference's own power expression without
+    contraction, the library's accurate expf and a true division for the T recovery.  Against oracle/_ref's strict build
+    (the reference's untouched kernels, -ffp-contract=off, the same device expf) alpha_out, depth and the semantic image
+    are then BIT-IDENTICAL, n_contrib is identical, and -- T_final = 1 - alpha_out carrying no forward rounding into the
+    backward -- the gradients meet the north-star gate (rel 1e-4) END TO END, each side on its own forward.  (The C oracle
+    uses the host's libm expf, which differs from the device's in rare last bits: it is compared with a few-ulp gate.)"""
+    ref = _ref()
+    cam = syn.make_camera(320, 208, fx=340.0, yaw_deg=2.0)
+    sc = syn.make_scene(15000, cam, S=S, seed=21, scale_px=0.004)
+    kw = oracle_kwargs(cam, sc, bg=torch.tensor([0.3, 0.1, 0.2]))
+    wts = syn.loss_weights(cam, S=S)
+    rf = ref.forward(**kw)
+    gref = ref.backward(rf, wts["color"], wts["depth"], wts["alpha"], wts["semantic"] if S else None)
+    fw = oracle.forward(**kw)
+    with switches(_C.EXACT):
+        res, internal = raw_forward(kw)
+        g = raw_backward(kw, res, wts)
+        torch.cuda.synchronize()
+    for k in ["alpha", "depth"] + (["semantic"] if S else []):
+        assert torch.equal(res[k], getattr(rf, k)), k
+    assert torch.equal(internal("n_contrib").view(torch.int32).reshape(-1), rf.internal("n_contrib").reshape(-1))
+    image_close(npy(res["color"]), npy(rf.color), rel=1e-6, name="exact color vs ref", max_outliers=0)
+    image_close(npy(res["alpha"]), fw.alpha, rel=2e-6, name="exact alpha vs oracle", max_outliers=0)
+    names = {"means2D": "means2D", "colors": "colors", "opacity": "opacity", "means3D": "means3D", "cov3D": "cov3D", "sh": "sh",
+             "scales": "scales", "rotations": "rotations", "semantics": "semantics"}
+    for k in GRAD_KEYS:
+        if k == "semantics" and not S:
+            continue
+        grad_close(npy(g[k]).reshape(-1), npy(gref[names[k]]).reshape(-1), name=f"exact end-to-end {k} vs ref", rel=1e-4,
+                   abs_frac=2e-6, max_outlier_frac=1e-4)  # dL/drot, dL/dscale: the per-Gaussian stage is compiled with contraction
+    rf.free()
+    fw.free()
