@@ -52,8 +52,15 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
 
 /* CudaRasterizer::Rasterizer::backward  (cuda_rasterizer/rasterizer.h:64-102, rasterizer_impl.cu:396-506).
  * geom/binning/image buffers and R are the ones forward produced.  `scratch` provides temporary device
- * memory (one float4 per Gaussian + R partial rows of row_stride floats + R flag bytes) that may be released when
- * the call returns.  All gradient outputs are
+ * memory (one float4 per Gaussian + R partial rows of sgr_partial_row_floats(S) floats) that may be released when
+ * the call returns.
+ * Binning-buffer contract: the backward WRITES into the forward's binning buffer -- one "row written" byte per sorted
+ * instance, cleared by the forward's tile-ranges launch.  The set of rows a backward writes is a pure function of the
+ * forward's hit record and n_contrib (never of the upstream gradients), so any number of backward calls over ONE forward
+ * re-mark the same bytes (tests: two backward passes with retain_graph, incl. all-zero upstream gradients).  Do not hand
+ * the backward a binning buffer copied from, or shared with, another forward, even one with the same R: rows would be
+ * summed that this backward never wrote.
+ * All gradient outputs are
  * fully written (no zero-initialisation needed, cf. rasterize_points.cu:166-176):
  * dL_dmean2D[P,3] (z = sum |gx|+|gy|), dL_dopacity[P], dL_dcolor[P,3], dL_dmean3D[P,3], dL_dcov3D[P,6],
  * dL_dsh[P,M,3] (NULL if shs NULL), dL_dscale[P,3], dL_drot[P,4], dL_dsemantic[P,S].

@@ -268,15 +268,31 @@ class FlatScene:
             out.append(d)
         return out
 
-    def compose(self, max_sh_coeffs: int, num_classes: int, flip_masks: Optional[Sequence] = None):
-        """Same result as ``scene.compose(segments, M, S)``; gradients arrive in the 7 flat leaves + ``poses``."""
+    def compose(self, max_sh_coeffs: int, num_classes: int, flip_masks: Optional[Sequence] = None,
+                poses: Optional[torch.Tensor] = None, idfts: Optional[Sequence] = None):
+        """Same result as ``scene.compose(segments, M, S)``; gradients arrive in the 7 flat leaves and in the poses.
+
+        Per frame (street_gaussian_model.py:230-330): ``poses`` [n_actors, 7] (obj_rot wxyz + obj_trans in world space) is
+        usually a NON-leaf the caller derives from its tracking-pose refinements and the ego pose -- pass it here and
+        the gradient flows on to those; default: the ``poses`` leaf held by this object.  ``idfts`` = one IDFT row
+        [fourier_dim] per segment (None for the background): it depends on the frame's timestamp
+        (gaussian_model_actor.py:71-80); default: the rows the segments carried at construction.  ``flip_masks`` = one
+        bool [n] mask per segment or None (training-time symmetry flips, :270-283)."""
         fm = list(flip_masks) if flip_masks is not None else [None] * len(self.meta)
-        args = [self.tensors[k] for k in _FLAT] + [self.poses]
-        return _ComposeFlat.apply(self, fm, int(max_sh_coeffs), int(num_classes), *args)
+        P = self.poses if poses is None else poses
+        if P is not None and (P.dtype != torch.float32 or not P.is_contiguous()):
+            P = P.float().contiguous()
+        ids = None
+        if idfts is not None:
+            ids = [None if t is None else torch.as_tensor(t, dtype=torch.float32, device=self.xyz.device).contiguous() for t in idfts]
+        args = [self.tensors[k] for k in _FLAT] + [P]
+        return _ComposeFlat.apply(self, (fm, ids), int(max_sh_coeffs), int(num_classes), *args)
 
 
-def _pack_flat(fs: FlatScene, tensors, flip_masks, grads=None):
-    """_CSeg array (and, with `grads`, the _CSegGrads array) whose pointers address the segments' blocks of the flat tensors."""
+def _pack_flat(fs: FlatScene, tensors, frame, grads=None):
+    """_CSeg array (and, with `grads`, the _CSegGrads array) whose pointers address the segments' blocks of the flat tensors.
+    frame = (flip masks, IDFT rows or None) of this call."""
+    flip_masks, idfts = frame
     arr = (_CSeg * len(fs.meta))()
     garr = (_CSegGrads * len(fs.meta))() if grads is not None else None
     keep = []
@@ -317,8 +333,10 @@ def _pack_flat(fs: FlatScene, tensors, flip_masks, grads=None):
             fmk = fmk.view(torch.uint8) if fmk.dtype == torch.bool and fmk.is_contiguous() else fmk.to(torch.uint8).contiguous()
             keep.append(fmk)
             c.flip_mask = fmk.data_ptr() if fmk.numel() else None
-        if m["idft"] is not None:
-            c.idft = m["idft"].data_ptr()
+        idft = m["idft"] if idfts is None else idfts[i]
+        if idft is not None:
+            keep.append(idft)
+            c.idft = idft.data_ptr()
     return arr, garr, keep
 
 

@@ -252,3 +252,14 @@ def test_flat_parameter_mode_equals_per_model_compose(counts, M, S, seed):
             assert torch.equal(seg.pose.grad, flat.poses.grad[a])
             a += 1
     assert len(views) == len(counts) and views[0]["xyz"].shape[0] == counts[0]
+    # per-frame inputs: a NON-leaf pose tensor (the caller derives it from its tracking refinements) and explicit IDFT rows
+    if flat.poses is not None:
+        want_pose = flat.poses.grad.clone()
+        for t in list(flat.tensors.values()) + [flat.poses]:
+            t.grad = None
+        raw = flat.poses.detach().clone().requires_grad_(True)
+        fouts2 = flat.compose(M, S, flip_masks=[s.flip_mask for s in gsegs], poses=raw * 1.0, idfts=[s.idft for s in gsegs])
+        for a, b in zip(fouts, fouts2):
+            assert torch.equal(a, b)
+        torch.autograd.backward([fouts2[i] for i in sel], [ups[i] for i in sel])
+        assert torch.equal(raw.grad, want_pose) and flat.poses.grad is None
