@@ -322,7 +322,17 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     size_t have_bytes = 0;
     char* bbase = nullptr;
     if (r_hint > 0) {
-        have_bytes = sgr_binning_bytes((int)std::min<size_t>(r_hint, 0x7fffffffu));
+        // the hint decays a little every call; request sizes on a coarse ladder (steps of 1/16 of the next lower power of
+        // two) so that consecutive calls ask the caller's caching allocator for the SAME block size instead of a new,
+        // slightly smaller one each time (every new size is a device allocation: tens of ms on some hosts)
+        size_t hq = r_hint;
+        {
+            size_t step = 1;
+            while ((step << 1) <= hq) step <<= 1;
+            step = std::max<size_t>(step >> 4, 1024);
+            hq = (hq + step - 1) / step * step;
+        }
+        have_bytes = sgr_binning_bytes((int)std::min<size_t>(hq, 0x7fffffffu));
         bbase = binning_buffer(have_bytes, binning_user);
         if (!bbase) return fail(SGR_E_ALLOC, "binning buffer allocation failed");
     }

@@ -105,6 +105,8 @@ def test_bench_runs_the_rccl_exchange_on_one_rank():
         line = json.loads(out.stdout.strip().split("\n")[-1])
         assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["exchange_bytes_per_rank"] > 0
         assert (mode == "overlap") == ("overlapped" in line["config"]["exchange_schedule"])
+        # the reported value is the blocking schedule; the overlapped one rides along as an extra when blocking is reported
+        assert (mode == "blocking") == ("exchange_overlap" in line)
 
 
 def test_async_exchange_matches_blocking_exchange():
