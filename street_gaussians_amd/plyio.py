@@ -109,3 +109,32 @@ def read_scene_ply(path: str) -> "OrderedDict[str, Dict[str, np.ndarray]]":
             "semantic": _group(rec, n, "semantic"),
         }
     return out
+
+
+def write_viewer_ply(path: str, means3D, shs, opacities, scales, rotations) -> None:
+    """The single-element ``vertex`` PLY the reference's ``make_ply.py`` writes for a composed frame (the vanilla 3D-GS
+    viewer layout; /root/reference/make_ply.py:37-79): inputs are the FLATTENED, post-activation rasterizer inputs of one
+    frame (``scene.compose`` / the model's getters: means3D [n,3], shs [n,M,3], opacities [n,1] in (0,1), scales [n,3] > 0,
+    rotations [n,4]); the file holds x y z, zero normals, f_dc_* / f_rest_* channel-major, opacity as logit of the value
+    clipped to [1e-6, 1 - 1e-6], log scales, rotations -- float32, in that column order."""
+    xyz = np.asarray(means3D, np.float32)
+    n = xyz.shape[0]
+    f = np.ascontiguousarray(np.asarray(shs, np.float32).transpose(0, 2, 1))       # [n, 3, M]   (:40)
+    f_dc = f[..., :1].reshape(n, -1)                                                # (:41)
+    f_rest = f[..., 1:].reshape(n, -1)                                              # (:42)
+    op = np.clip(np.asarray(opacities, np.float32).reshape(n, 1), 1e-6, 1. - 1e-6)  # (:43-44)
+    op = np.log(op / (1 - op))                                                      # (:45)
+    sc = np.log(np.asarray(scales, np.float32))                                     # (:47-48)
+    rot = np.asarray(rotations, np.float32)
+    names = ["x", "y", "z", "nx", "ny", "nz"] + [f"f_dc_{i}" for i in range(f_dc.shape[1])] + \
+            [f"f_rest_{i}" for i in range(f_rest.shape[1])] + ["opacity"] + [f"scale_{i}" for i in range(sc.shape[1])] + \
+            [f"rot_{i}" for i in range(rot.shape[1])]
+    attributes = np.concatenate((xyz, np.zeros_like(xyz), f_dc, f_rest, op, sc, rot), axis=1).astype(np.float32)
+    rec = np.empty(n, dtype=[(c, "<f4") for c in names])
+    for i, c in enumerate(names):
+        rec[c] = attributes[:, i]
+    header = ["ply", "format binary_little_endian 1.0", f"element vertex {n}"] + [f"property float {c}" for c in names] + \
+             ["end_header"]
+    with open(path, "wb") as fh:
+        fh.write(("\n".join(header) + "\n").encode("ascii"))
+        fh.write(rec.tobytes())

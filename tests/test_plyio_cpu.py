@@ -162,3 +162,40 @@ def test_saved_checkpoint_is_loadable_by_the_reference_load_state_dict(tmp_path)
         (stub._xyz.sum() + stub._opacity.sum()).backward()
         stub.optimizer.step()
     assert st["iter"] == 12
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/make_ply.py"), reason="reference checkout not present")
+def test_viewer_ply_matches_the_reference_make_ply_script(tmp_path):
+    """plyio.write_viewer_ply against the reference's make_ply.py:37-72 (the block that turns a composed frame into the
+    structured array of the single `vertex` element), cut out of the script by line content and executed on a stub model."""
+    import re
+    import textwrap
+    import types
+    import torch
+    src = open("/root/reference/make_ply.py").read()
+    a = src.index("    xyz = gaussians.get_xyz.detach().cpu().numpy()")
+    b = src.index("    save_dir = os.path.join(cfg.model_path")
+    block = textwrap.dedent(src[a:b])
+    g = torch.Generator().manual_seed(4)
+    n, M = 500, 16
+    stub = types.SimpleNamespace(get_xyz=torch.randn(n, 3, generator=g), get_features=torch.randn(n, M, 3, generator=g),
+                                 get_opacity=torch.rand(n, 1, generator=g), get_scaling=torch.rand(n, 3, generator=g) + 0.01,
+                                 get_rotation=torch.nn.functional.normalize(torch.randn(n, 4, generator=g)))
+    stub.get_opacity[:3] = torch.tensor([[0.0], [1.0], [0.5]])  # the clip is active at both ends
+    ns = {"np": np, "gaussians": stub, "inverse_opacity": lambda x: np.log(x / (1 - x)), "inverse_scale": lambda x: np.log(x)}
+    exec(block, ns)
+    want = ns["elements"]  # structured array, f4 columns in the script's order
+    out = str(tmp_path / "viewer.ply")
+    plyio.write_viewer_ply(out, stub.get_xyz.numpy(), stub.get_features.numpy(), stub.get_opacity.numpy(),
+                           stub.get_scaling.numpy(), stub.get_rotation.numpy())
+    data = open(out, "rb").read()
+    end = data.index(b"end_header\n") + len(b"end_header\n")
+    header = data[:end].decode().split("\n")
+    assert header[2] == f"element vertex {n}"
+    assert [ln.split()[2] for ln in header if ln.startswith("property")] == list(want.dtype.names)
+    got = np.frombuffer(data, dtype=want.dtype, count=n, offset=end)
+    for c in want.dtype.names:
+        assert np.array_equal(got[c], want[c]), c
+    # and it reads back as a single-model scene
+    m = plyio.read_scene_ply(out)[""]
+    assert np.allclose(m["xyz"], stub.get_xyz.numpy()) and m["features_rest"].shape == (n, M - 1, 3)
