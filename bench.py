@@ -378,6 +378,16 @@ class DensifyLoop:
 
     def run(self, fence, n_densify=3):
         every = self.every
+        # A densify step re-sizes every buffer: with an empty caching allocator each new size is a device allocation, and
+        # on some hosts hipMalloc of a multi-GB block takes tens of ms (observed: 40 allocations in the region, 20-55 ms
+        # per iteration on those boxes, 3.9 ms on others -- allocator latency, not the path).  A trainer that re-sizes
+        # under load reserves its pool once: one 48 GB block handed back to torch's caching allocator, which then serves
+        # the re-sized buffers by splitting it (288 GB of HBM: there is room).
+        try:
+            pool = torch.empty(48 << 30, dtype=torch.uint8, device=self.dev)
+            del pool
+        except RuntimeError:
+            pass
         for _ in range(every):  # untimed calibration interval (also the warm-up)
             self.step()
         self.calibrate()
