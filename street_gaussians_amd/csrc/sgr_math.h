@@ -210,32 +210,47 @@ SGR_HD void sgr_extent(float opacity, float cov_a, float cov_c, float con_x, flo
     hy = sqrtf(2.0f * tau * ey) * 1.01f + 0.25f;
 }
 
+#ifndef SGR_CULL_FAST
+#define SGR_CULL_FAST 1  // 0: the round-2 form (a division per edge, library logf) -- A/B only (tools/build_variant.py)
+#endif
 // Exact part of the quadrant cull.  tau2 = 2*tau' (same inflation as sgr_extent; negative = never visible).
 SGR_HD float sgr_tau2(float opacity) {
     if (opacity < 0.0039f) return -1.0f;
-    const float tau = fmaxf(logf(255.0f * opacity), 0.0f) * 1.02f + 0.05f;
+#if defined(__HIP_DEVICE_COMPILE__) && SGR_CULL_FAST
+    // v_log_f32 (log2, ~1 ulp) instead of the library's logf (~25 instructions per staged instance): the 2 % + 0.05
+    // inflation below is five orders of magnitude above the difference
+    const float lg = __builtin_amdgcn_logf(255.0f * opacity) * 0.6931471805599453f;
+#else
+    const float lg = logf(255.0f * opacity);
+#endif
+    const float tau = fmaxf(lg, 0.0f) * 1.02f + 0.05f;
     return 2.0f * tau;
 }
 // Minimum of Q(d) = A*dx^2 + 2*B*dx*dy + C*dy^2 over the rectangle dx in [dx0,dx1], dy in [dy0,dy1]
 // (offsets of a pixel block from the splat centre).  Q is convex: 0 if the centre is inside, else the minimum
 // lies on one of the four edges, where Q is a 1-D parabola whose vertex is clamped to the edge.
-SGR_HD float sgr_min_quadform_rect(float A, float B, float C, float dx0, float dx1, float dy0, float dy1) {
+// nBiC = -B / C and nBiA = -B / A are formed ONCE per splat by the caller (the edge vertices are -B*d/C: written as a
+// division per edge the compiler emitted 16 IEEE divisions -- ~190 instructions -- per staged instance, 13 % of the
+// forward kernel's VALU work); a vertex that is off by an ulp moves Q by a second-order amount, far inside the 0.25 px +
+// 2 % margins of the caller.
+SGR_HD float sgr_min_quadform_rect(float A, float B, float C, float nBiA, float nBiC, float dx0, float dx1, float dy0,
+                                   float dy1) {
     if (dx0 <= 0.0f && dx1 >= 0.0f && dy0 <= 0.0f && dy1 >= 0.0f) return 0.0f;
     float m;
     {
-        const float dy = fminf(fmaxf(-B * dx0 / C, dy0), dy1);
+        const float dy = fminf(fmaxf(SGR_CULL_FAST ? nBiC * dx0 : -B * dx0 / C, dy0), dy1);
         m = A * dx0 * dx0 + 2.0f * B * dx0 * dy + C * dy * dy;
     }
     {
-        const float dy = fminf(fmaxf(-B * dx1 / C, dy0), dy1);
+        const float dy = fminf(fmaxf(SGR_CULL_FAST ? nBiC * dx1 : -B * dx1 / C, dy0), dy1);
         m = fminf(m, A * dx1 * dx1 + 2.0f * B * dx1 * dy + C * dy * dy);
     }
     {
-        const float dx = fminf(fmaxf(-B * dy0 / A, dx0), dx1);
+        const float dx = fminf(fmaxf(SGR_CULL_FAST ? nBiA * dy0 : -B * dy0 / A, dx0), dx1);
         m = fminf(m, A * dx * dx + 2.0f * B * dx * dy0 + C * dy0 * dy0);
     }
     {
-        const float dx = fminf(fmaxf(-B * dy1 / A, dx0), dx1);
+        const float dx = fminf(fmaxf(SGR_CULL_FAST ? nBiA * dy1 : -B * dy1 / A, dx0), dx1);
         m = fminf(m, A * dx * dx + 2.0f * B * dx * dy1 + C * dy1 * dy1);
     }
     return m;
@@ -245,12 +260,13 @@ SGR_HD float sgr_min_quadform_rect(float A, float B, float C, float dx0, float d
 SGR_HD uint32_t sgr_quadrant_mask(const float4& a, const float4& b, float tx0, float ty0) {
     uint32_t mask4 = 0;
     const float tau2 = sgr_tau2(b.w);
+    const float nBiA = -b.y / b.x, nBiC = -b.y / b.z;  // two divisions per splat instead of sixteen (SGR_CULL_FAST)
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const float qx0 = tx0 + (float)((q & 1) * 8), qy0 = ty0 + (float)((q >> 1) * 8);
         bool miss = (a.x + a.z < qx0) || (a.x - a.z > qx0 + 7.0f) || (a.y + a.w < qy0) || (a.y - a.w > qy0 + 7.0f);
         if (!miss) {
-            const float mq = sgr_min_quadform_rect(b.x, b.y, b.z, qx0 - 0.25f - a.x, qx0 + 7.25f - a.x,
+            const float mq = sgr_min_quadform_rect(b.x, b.y, b.z, nBiA, nBiC, qx0 - 0.25f - a.x, qx0 + 7.25f - a.x,
                                                    qy0 - 0.25f - a.y, qy0 + 7.25f - a.y);
             miss = mq > tau2;
         }
