@@ -309,8 +309,10 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     const int dcur = sgr_launch_sort_pairs32(gv.dkeys, gv.dvals, (uint32_t)P, 32, gv.dhist, gv.scan_tmp, stream, true, gv.aux,
                                              gv.aux_sorted);
     const uint32_t* order = gv.dvals[dcur];
+    // (second sequence of the same launches: the exclusive scan in index order = every Gaussian's first partial-gradient
+    // row of the backward, SgrGeomView::u0)
     sgr_launch_scan(reinterpret_cast<const uint32_t*>(gv.aux_sorted), gv.tt_sorted, (size_t)P, gv.scan_tmp, true, stream,
-                    nullptr, nullptr, 2);
+                    nullptr, nullptr, 2, reinterpret_cast<const uint32_t*>(gv.aux), gv.u0);
     SGR_STAGE("depth_sort+scan");
     prof_end(stream);
     // The window between "R is known" and "the GPU runs out of queued work" is only the ~0.12 ms of sort + scan
@@ -670,7 +672,7 @@ __global__ void sgr_export_kernel(int which, int P, SgrGeomView gv, void* dst) {
         case 4: ((float4*)dst)[i] = gv.rec[4 * (size_t)i + 1]; break;
         case 5: { const float4 c = gv.rec[4 * (size_t)i + 2]; ((float*)dst)[3 * i] = c.x; ((float*)dst)[3 * i + 1] = c.y; ((float*)dst)[3 * i + 2] = c.z; } break;
         case 6: ((uint32_t*)dst)[i] = gv.aux[i].x; break;
-        case 7: ((uint32_t*)dst)[i] = gv.point_offsets[i]; break;
+        case 7: ((uint32_t*)dst)[i] = gv.u0[i] + gv.aux[i].x; break;  // the reference's inclusive index-order scan
         case 14: { const float4 a = gv.rec[4 * (size_t)i]; ((float*)dst)[2 * i] = a.z; ((float*)dst)[2 * i + 1] = a.w; } break;
     }
 }
@@ -685,9 +687,6 @@ int sgr_export_internal(int which, int P, int R, int width, int height, char* ge
         if (P <= 0) return 0;
         const SgrGeomView gv = sgr_geom_carve(geom_buffer, (size_t)P);
         if (which == 3) return fail(SGR_E_INVALID, "cov3D is not materialised (the backward recomputes it)");
-        if (which == 7)  // the reference's index-order inclusive scan is not needed by the pipeline: made on demand
-            sgr_launch_scan(reinterpret_cast<const uint32_t*>(gv.aux), gv.point_offsets, (size_t)P, gv.scan_tmp, true, stream,
-                            nullptr, nullptr, 2);
         sgr_export_kernel<<<(P + 255) / 256, 256, 0, stream>>>(which, P, gv, dst);
         SGR_STAGE("export");
         return 0;

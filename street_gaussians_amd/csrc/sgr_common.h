@@ -38,9 +38,10 @@ struct SgrGeomView {
     float4* rec;  // [4P]
     uint2* aux;               // per Gaussian {tiles_touched, packed tile rect}; {0, 0} when culled
     uint2* aux_sorted;        // the same in (depth, id) order (written by the last pass of the depth sort)
-    uint32_t* u0;             // per Gaussian: its first slot in depth order = its first partial-gradient row (written by
-                              // duplicate: 4-byte scatter into this compact array instead of into the 64-byte records)
-    uint32_t* point_offsets;  // inclusive scan in index order: only materialised by sgr_export_internal (parity)
+    uint32_t* u0;             // per Gaussian: its first partial-gradient row of the backward = EXCLUSIVE scan of
+                              // tiles_touched in INDEX order (the reference's point_offsets minus tiles_touched), made by
+                              // the second sequence of the forward's scan launches.  Rows in index order: the row sum
+                              // streams them (in depth order it was a gather of ~190-byte runs: 1.67x the bytes)
     uint32_t* dkeys[2];       // depth bits per Gaussian (0xffffffff = culled), ping-pong for the depth sort
     uint32_t* dvals[2];       // Gaussian ids; after the sort dvals[cur] = ids in (depth, id) order (dvals[0] is never
                               // written by the preprocess: the first pass takes the element index as the value)
@@ -116,7 +117,6 @@ static inline SgrGeomView sgr_geom_carve(char* base, size_t P, char** end = null
     sgr_carve(p, v.aux, Pn);
     sgr_carve(p, v.aux_sorted, Pn);
     sgr_carve(p, v.u0, Pn);
-    sgr_carve(p, v.point_offsets, Pn);
     sgr_carve(p, v.clamped, Pn);
     sgr_carve(p, v.internal_radii, Pn);
     sgr_carve(p, v.dkeys[0], Pn);
@@ -127,7 +127,7 @@ static inline SgrGeomView sgr_geom_carve(char* base, size_t P, char** end = null
     {
         const size_t nh = sgr_sort_hist_words(Pn);
         sgr_carve(p, v.dhist, nh);
-        sgr_carve(p, v.scan_tmp, sgr_scan_tmp_count(nh > Pn ? nh : Pn));
+        sgr_carve(p, v.scan_tmp, 2 * sgr_scan_tmp_count(nh > Pn ? nh : Pn));  // two sequences per scan launch
     }
     if (end) *end = p;
     return v;
@@ -185,8 +185,11 @@ SgrFlagBlock sgr_acquire_flag_block();
 // device-wide scan: out may alias in; tmp needs sgr_scan_tmp_count(n) words; tmp[nblocks] (and *total_out) receive the
 // grand total; gather != nullptr scans in[gather[i]] instead of in[i]
 // in_stride: element i is in[i * in_stride] (scan of one field of an array of records)
+// in2 / out2: a second sequence of n elements scanned (exclusive, no gather, same stride) in the same three launches; tmp
+// then needs 2 * sgr_scan_tmp_count(n) words
 void sgr_launch_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, bool inclusive, hipStream_t s,
-                     uint32_t* total_out = nullptr, const uint32_t* gather = nullptr, int in_stride = 1);
+                     uint32_t* total_out = nullptr, const uint32_t* gather = nullptr, int in_stride = 1,
+                     const uint32_t* in2 = nullptr, uint32_t* out2 = nullptr);
 // stable LSD radix sorts on key bits [0, end_bit); return the index (0/1) of the buffer pair holding the result
 int sgr_sort_get_one_sweep();
 void sgr_sort_set_one_sweep(int on);  // A/B: 1 = the one-sweep form instead of histogram + row scan + scatter per pass

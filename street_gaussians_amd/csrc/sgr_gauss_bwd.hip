@@ -36,9 +36,11 @@ sgr_row_sum_kernel(int P, int S, const int* __restrict__ radii, SgrGeomView gv, 
 #pragma unroll
     for (int k = 0; k < 4 * NV; k++) acc[k] = 0.f;
     const bool live = idx < P;  // P need not be a multiple of 16: keep whole quads alive for the DPP steps
-    if (live && radii[idx] > 0) {
-        const uint32_t u0 = gv.u0[idx];
-        const uint32_t n = gv.aux[idx].x;  // tiles_touched
+    // tiles_touched is 0 for a culled Gaussian, so the row walk needs no look at the radius: the two loads below go out
+    // together and the dependent chain is {u0, n} -> flag -> row
+    const uint32_t n = live ? gv.aux[idx].x : 0u;
+    const uint32_t u0 = live ? gv.u0[idx] : 0u;  // defined for every Gaussian (exclusive scan)
+    if (n) {
         const uint8_t* flag = touched + u0;
         const float* rows = partials + (size_t)u0 * row_stride;
         auto add_row = [&](const float4 (&t)[NV]) __attribute__((always_inline)) {

@@ -209,8 +209,7 @@ sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, co
 
 // ---- K6: one (tile key, Gaussian id) per overlapped tile (rasterizer_impl.cu:70-111).  Lane i handles the i-th
 // Gaussian in (depth, id) order, so the instance array is already ordered by the low 32 bits of the reference's
-// 64-bit key and a STABLE sort on the tile id alone reproduces the reference's order, ties included.  The
-// Gaussian's first slot is also its first partial-gradient row in the backward (rec[3].x).
+// 64-bit key and a STABLE sort on the tile id alone reproduces the reference's order, ties included.
 // Wave-cooperative emission: the 64 Gaussians of a wave own ONE contiguous range of slots [start, end).  Lane l
 // writes slots start + 64*it + l (fully coalesced 256-byte stores; a lane-per-Gaussian loop writes 64 scattered
 // 4-byte runs per instruction and was store-issue bound: 0.08 ms for 62 MB) and finds the slot's owner with a binary
@@ -230,13 +229,7 @@ sgr_duplicate_kernel(int P, SgrGeomView gv, const uint32_t* __restrict__ order, 
         idx = order[i];
         off = (i == 0) ? 0u : offs_incl[i - 1];
         incl = offs_incl[i];
-        if (incl != off) {  // tiles_touched > 0
-            rect = gv.aux_sorted[i].y;
-            // first slot = first partial-gradient row of the backward: a 4-byte scatter into the compact u0 array (20 MB
-            // at 5 M Gaussians: its lines collect 16 stores each in L2; the same store into the 64-byte records touched
-            // 320 MB of lines once each and was what this kernel spent its time on)
-            gv.u0[idx] = off;
-        }
+        if (incl != off) rect = gv.aux_sorted[i].y;  // tiles_touched > 0
     }
     sOff[wave][lane] = off;  // lanes past P: 0xffffffff, never <= a slot
     sRect[wave][lane] = rect;

@@ -52,24 +52,32 @@ __device__ __forceinline__ uint32_t sgr_block_excl_scan256(uint32_t v, uint32_t*
 // scan kernels: ITEMS = 2048 per block = 256 threads x 8 consecutive elements
 // gather != nullptr: element i of the scanned sequence is in[gather[i]] (the forward scans tiles_touched in depth
 // order without materialising the permuted array)
+// Second sequence (in2 != nullptr): the launch carries TWO scans of n elements each -- workgroups [0, nb) do the first,
+// [nb, 2 nb) the second (no gather, exclusive, same stride) with their own block sums behind the first's.  The forward
+// uses it to get the index-order offsets of the partial-gradient rows (SgrGeomView::u0) in the launches that scan
+// tiles_touched in depth order anyway: these kernels are launch-latency bound, three more launches would cost 16 us.
 __global__ void __launch_bounds__(256) sgr_scan_reduce_kernel(const uint32_t* __restrict__ in, size_t n,
                                                               uint32_t* __restrict__ block_sums,
-                                                              const uint32_t* __restrict__ gather, int stride) {
+                                                              const uint32_t* __restrict__ gather, int stride,
+                                                              const uint32_t* __restrict__ in2, unsigned nb) {
     __shared__ uint32_t lds4[4];
-    const size_t base = (size_t)blockIdx.x * SGR_SCAN_ITEMS + (size_t)threadIdx.x * 8;
+    unsigned b = blockIdx.x;
+    if (b >= nb) { b -= nb; in = in2; gather = nullptr; block_sums += nb + 1; }
+    const size_t base = (size_t)b * SGR_SCAN_ITEMS + (size_t)threadIdx.x * 8;
     uint32_t s = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++)
         if (base + i < n) s += gather ? in[(size_t)gather[base + i] * stride] : in[(base + i) * stride];
     uint32_t total;
     sgr_block_excl_scan256(s, lds4, total);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+    if (threadIdx.x == 0) block_sums[b] = total;
 }
 
-// single block: exclusive scan of block_sums[0..nb) in place; block_sums[nb] = grand total
+// one block per sequence: exclusive scan of block_sums[0..nb) in place; block_sums[nb] = grand total
 __global__ void __launch_bounds__(256) sgr_scan_spine_kernel(uint32_t* __restrict__ block_sums, size_t nb,
                                                              uint32_t* __restrict__ total_out) {
     __shared__ uint32_t lds4[4];
+    if (blockIdx.x) { block_sums += nb + 1; total_out = nullptr; }
     uint32_t carry = 0;
     for (size_t start = 0; start < nb; start += 256) {
         const size_t i = start + threadIdx.x;
@@ -85,12 +93,15 @@ __global__ void __launch_bounds__(256) sgr_scan_spine_kernel(uint32_t* __restric
     }
 }
 
-template <bool INCLUSIVE>
 __global__ void __launch_bounds__(256) sgr_scan_final_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                              size_t n, const uint32_t* __restrict__ block_sums,
-                                                             const uint32_t* __restrict__ gather, int stride) {
+                                                             const uint32_t* __restrict__ gather, int stride, bool inclusive,
+                                                             const uint32_t* __restrict__ in2, uint32_t* __restrict__ out2,
+                                                             unsigned nb) {
     __shared__ uint32_t lds4[4];
-    const size_t base = (size_t)blockIdx.x * SGR_SCAN_ITEMS + (size_t)threadIdx.x * 8;
+    unsigned b = blockIdx.x;
+    if (b >= nb) { b -= nb; in = in2; out = out2; gather = nullptr; block_sums += nb + 1; inclusive = false; }
+    const size_t base = (size_t)b * SGR_SCAN_ITEMS + (size_t)threadIdx.x * 8;
     uint32_t v[8];
     uint32_t s = 0;
 #pragma unroll
@@ -99,26 +110,28 @@ __global__ void __launch_bounds__(256) sgr_scan_final_kernel(const uint32_t* __r
         s += v[i];
     }
     uint32_t total;
-    uint32_t run = sgr_block_excl_scan256(s, lds4, total) + block_sums[blockIdx.x];
+    uint32_t run = sgr_block_excl_scan256(s, lds4, total) + block_sums[b];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        if (INCLUSIVE) run += v[i];
+        if (inclusive) run += v[i];
         if (base + i < n) out[base + i] = run;
-        if (!INCLUSIVE) run += v[i];
+        if (!inclusive) run += v[i];
     }
 }
 
-// out may alias in.  tmp needs sgr_scan_tmp_count(n) words; tmp[nblocks] receives the grand total, and so does
-// *total_out when given.
+// out may alias in.  tmp needs sgr_scan_tmp_count(n) words (twice that with a second sequence); tmp[nblocks] receives
+// the grand total, and so does *total_out when given.  in2 / out2: a second, exclusive scan of in2[i * in_stride] in the
+// same three launches.
 void sgr_launch_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, bool inclusive, hipStream_t s,
-                     uint32_t* total_out, const uint32_t* gather, int in_stride) {
+                     uint32_t* total_out, const uint32_t* gather, int in_stride, const uint32_t* in2, uint32_t* out2) {
     if (n == 0) return;
     const size_t nb = (n + SGR_SCAN_ITEMS - 1) / SGR_SCAN_ITEMS;
+    const unsigned seqs = in2 ? 2u : 1u;
 
-    sgr_scan_reduce_kernel<<<(unsigned)nb, 256, 0, s>>>(in, n, tmp, gather, in_stride);
-    sgr_scan_spine_kernel<<<1, 256, 0, s>>>(tmp, nb, total_out);
-    if (inclusive) sgr_scan_final_kernel<true><<<(unsigned)nb, 256, 0, s>>>(in, out, n, tmp, gather, in_stride);
-    else sgr_scan_final_kernel<false><<<(unsigned)nb, 256, 0, s>>>(in, out, n, tmp, gather, in_stride);
+    sgr_scan_reduce_kernel<<<(unsigned)nb * seqs, 256, 0, s>>>(in, n, tmp, gather, in_stride, in2, (unsigned)nb);
+    sgr_scan_spine_kernel<<<seqs, 256, 0, s>>>(tmp, nb, total_out);
+    sgr_scan_final_kernel<<<(unsigned)nb * seqs, 256, 0, s>>>(in, out, n, tmp, gather, in_stride, inclusive, in2, out2,
+                                                             (unsigned)nb);
 }
 
 // ------------------------------------------------------------------------------------------------
