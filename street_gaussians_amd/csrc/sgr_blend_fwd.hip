@@ -15,8 +15,15 @@
 
 #define SGR_TILE_THREADS 256
 
+// Register budget (tools/occupancy_audit.py).  Left alone the allocator lands a few registers past an occupancy step
+// in most instantiations -- S = 0: 65 VGPRs (the allocation granule is 8, so that is 72 and 7 waves / SIMD instead of
+// 8), 1-4 channels 71 (7 instead of 8), 5-8: 89 (5 instead of 6), 9-12: 101 (4 instead of 5), 21-24: 138 (3 instead of
+// 4) -- and fits the step without a spill when asked to.  13-20 and 25-32 channels are limited by LDS, not registers.
+#ifndef SGR_FWD_WAVES
+#define SGR_FWD_WAVES(SMAX) ((SMAX) <= 4 ? 8 : (SMAX) == 8 ? 6 : (SMAX) == 12 ? 5 : (SMAX) == 24 ? 4 : 1)
+#endif
 template <int SMAX, bool CULL, bool EXACT>
-__global__ void __launch_bounds__(SGR_TILE_THREADS)
+__global__ void __launch_bounds__(SGR_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(SGR_FWD_WAVES(SMAX))))
 sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int S,
                      int gx, int gy, const float4* __restrict__ rec, const float* __restrict__ semantics,
                      const float* __restrict__ bg_color, float* __restrict__ out_color, float* __restrict__ out_depth,
