@@ -23,15 +23,26 @@ HEADERS = ["sgr_common.h", "sgr_math.h", os.path.join("..", "..", "include", "sg
 # shuffles; measured on MI355X it costs 6 % in the blend backward and 7 % in the per-Gaussian backward.
 # -mllvm -enable-post-misched=0: without the post-RA machine scheduler the blend kernels keep the order they were
 # written in (interleaved DPP groups, paired visits); measured -1.2 % on the blend backward, -0.7 % on the step.
+# -mllvm -amdgpu-use-amdgpu-trackers=1 (the AMDGPU register-pressure trackers in the scheduler): -0.3 % on both blend
+# kernels, same box.  Per file: the radix-sort kernels like the max-ILP scheduling strategy (-3.5 us on the depth sort +
+# scan and on the tile sort at 1 M Gaussians) which costs the blend kernels 2 %.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-fno-slp-vectorize", "-mllvm",
-         "-enable-post-misched=0", "-Wall", "-Wno-unused-function"]
+         "-enable-post-misched=0", "-mllvm", "-amdgpu-use-amdgpu-trackers=1", "-Wall", "-Wno-unused-function"]
+PER_FILE_FLAGS = {"sgr_scan_sort.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+
+
+def flags_for(src: str) -> list:
+    """Compiler flags of one kernel source (FLAGS + its per-file additions + SGR_EXTRA_FLAGS from the environment)."""
+    return FLAGS + PER_FILE_FLAGS.get(os.path.basename(src), []) + os.environ.get("SGR_EXTRA_FLAGS", "").split()
+
 
 
 def source_sha16() -> str:
     """First 16 hex digits of the SHA-256 over the compiler flags, the kernel sources and headers: identifies the build a profile was
     taken on (profiles/pmc_blend_bwd.json, bench.py's roofline.traffic)."""
     import hashlib
-    h = hashlib.sha256(" ".join(FLAGS + os.environ.get("SGR_EXTRA_FLAGS", "").split()).encode())
+    h = hashlib.sha256(" ".join(FLAGS + [f"{k}:{' '.join(v)}" for k, v in sorted(PER_FILE_FLAGS.items())] +
+                                os.environ.get("SGR_EXTRA_FLAGS", "").split()).encode())
     for name in sorted(SOURCES + [x for x in HEADERS if not x.startswith("..")]):
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
@@ -46,13 +57,18 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
     hdr_time = _newest([os.path.join(CSRC, h) for h in HEADERS])
+    # objects are only as fresh as the flags they were compiled with
+    stamp = os.path.join(OBJ, "flags.txt")
+    want = "\n".join(f"{s}: {' '.join(flags_for(s))}" for s in SOURCES)
+    if not os.path.exists(stamp) or open(stamp).read() != want:
+        force = True
 
     def compile_one(src):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         if not force and os.path.exists(o) and os.path.getmtime(o) > max(os.path.getmtime(s), hdr_time):
             return o, False
-        cmd = [hipcc] + FLAGS + os.environ.get("SGR_EXTRA_FLAGS", "").split() + ["-c", s, "-o", o]
+        cmd = [hipcc] + flags_for(src) + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd))
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -65,6 +81,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         results = list(ex.map(compile_one, SOURCES))
     objs = [o for o, _ in results]
+    with open(stamp, "w") as f:
+        f.write(want)
     if force or any(c for _, c in results) or not os.path.exists(LIB):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)

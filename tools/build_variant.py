@@ -22,7 +22,7 @@ os.makedirs(obj_dir, exist_ok=True)
 
 def one(src):
     o = os.path.join(obj_dir, src.replace(".hip", ".o"))
-    subprocess.check_call(["/opt/rocm/bin/hipcc"] + b.FLAGS + flags + ["-c", os.path.join(b.CSRC, src), "-o", o])
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + b.flags_for(src) + flags + ["-c", os.path.join(b.CSRC, src), "-o", o])
     return o
 
 

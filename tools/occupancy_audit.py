@@ -35,7 +35,7 @@ for src in b.SOURCES:
     if not src.endswith(".hip"):
         continue
     out = os.path.join("/tmp", "audit_" + src.replace(".hip", ".s"))
-    subprocess.run(["/opt/rocm/bin/hipcc"] + b.FLAGS + ["--offload-device-only", "-S", os.path.join(b.CSRC, src), "-o", out],
+    subprocess.run(["/opt/rocm/bin/hipcc"] + b.flags_for(src) + ["--offload-device-only", "-S", os.path.join(b.CSRC, src), "-o", out],
                    capture_output=True, text=True, check=True)
     s = open(out).read()
     for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", s, re.S):
