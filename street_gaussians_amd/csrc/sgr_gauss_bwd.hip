@@ -124,7 +124,10 @@ sgr_row_sum_kernel(int P, int S, const int* __restrict__ radii, SgrGeomView gv, 
 }
 
 // ---- stage 2: K12 + K13 ----------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(SGR_GB_THREADS)
+#ifndef SGR_GB_WAVES
+#define SGR_GB_WAVES 1
+#endif
+__global__ void __launch_bounds__(SGR_GB_THREADS) __attribute__((amdgpu_waves_per_eu(SGR_GB_WAVES)))
 sgr_gauss_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const int* __restrict__ radii,
                      const float* __restrict__ shs, const float* __restrict__ scales,
                      const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
@@ -142,20 +145,14 @@ sgr_gauss_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, con
     // SH rows of 48 floats (M = 16): the 64 rows of a wave are one contiguous 12 KB block.  Per-lane float4 loads at
     // a 192-byte stride touch 64 cache lines per instruction and were issue-bound (SQ_WAIT_INST_ANY 70 % of the
     // wave-cycles); instead the wave copies the block with coalesced 1 KB transfers through LDS, both ways.
-    __shared__ float4 sSH[SGR_GB_THREADS / 64][64 * 12];
+    // Half of the wave's rows at a time (6 KB per wave): with all 64 rows resident the 48 KB per workgroup allowed 3
+    // workgroups = 3 waves / SIMD on a kernel that streams 0.5 KB per Gaussian; the lanes whose rows are in LDS read
+    // them into registers before the other half arrives.
+    __shared__ float4 sSH[SGR_GB_THREADS / 64][32 * 12];
     const bool stage = shs != nullptr && M == 16;
     const int g0 = blockIdx.x * SGR_GB_THREADS + wave * 64;
     const int nrow4 = max(0, min(64, P - g0)) * 12;  // float4s of this wave's rows
-    if (stage) {
-        const uint64_t vis = __ballot(visible);
-        const float4* src = reinterpret_cast<const float4*>(shs) + (size_t)g0 * 12;
-#pragma unroll
-        for (int it = 0; it < 12; it++) {
-            const int f = it * 64 + lane;
-            if (f < nrow4 && ((vis >> (f / 12)) & 1ull)) sSH[wave][f] = src[f];
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
+    const int ncoef = (D + 1) * (D + 1);
     float acc[SGR_ROW_BASE_N];
 #pragma unroll
     for (int k = 0; k < SGR_ROW_BASE_N; k++) acc[k] = 0.f;
@@ -217,59 +214,85 @@ sgr_gauss_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, con
         // dL/dSH[k] = Y_k(dir) * dL/dRGB for k < (D+1)^2, zero above (backward.cu:46-105); the
         // view-direction path adds dnormvdv(dir_orig, dL/ddir) to dL/dmean (backward.cu:131-138).
         float* dsh = dL_dsh + (size_t)idx * M * 3;
-        const int ncoef = (D + 1) * (D + 1);
         const bool vec = ((M * 3) & 3) == 0 && M <= 16;  // 16-byte aligned rows: stream them as float4
-        float shl[48];
-        float dshv[48];
+        const int n4 = (ncoef * 3 + 3) >> 2;
+        // t[k] = sum_ch sh[3k + ch] * dL/dRGB[ch]: the row contracted with the colour gradient as it arrives, 16 live
+        // values instead of the 48 of the row (sgr_sh_dir_backward)
+        float t[16];
 #pragma unroll
-        for (int k = 0; k < 48; k++) { shl[k] = 0.f; dshv[k] = 0.f; }
+        for (int k = 0; k < 16; k++) t[k] = 0.f;
+        auto take4 = [&](int i, const float4& v) __attribute__((always_inline)) {
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if ((4 * i + j) / 3 < ncoef) t[(4 * i + j) / 3] += e[j] * dRGB[(4 * i + j) % 3];
+        };
+        if (stage) {
+            const uint64_t vis = __ballot(visible);
+            const float4* src = reinterpret_cast<const float4*>(shs) + (size_t)g0 * 12;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+#pragma unroll
+                for (int it = 0; it < 6; it++) {
+                    const int f = h * 384 + it * 64 + lane;
+                    if (f < nrow4 && ((vis >> (f / 12)) & 1ull)) sSH[wave][f - h * 384] = src[f];
+                }
+                __builtin_amdgcn_wave_barrier();
+                if ((lane >> 5) == h && visible) {
+#pragma unroll
+                    for (int i = 0; i < 12; i++)
+                        if (i < n4) take4(i, sSH[wave][(lane & 31) * 12 + i]);
+                }
+                __builtin_amdgcn_wave_barrier();  // consumed: the buffer may be overwritten
+            }
+        }
+        float Y[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) Y[k] = 0.f;
         if (visible) {
-            float Y[16];
             sgr_sh_basis(D, dir[0], dir[1], dir[2], Y);
             const float* sh = shs + (size_t)idx * M * 3;
-            if (vec) {
-                const float4* sh4 = stage ? &sSH[wave][lane * 12] : reinterpret_cast<const float4*>(sh);
-                const int n4 = (ncoef * 3 + 3) >> 2;
+            if (stage) {
+                // contracted above
+            } else if (vec) {
+                const float4* sh4 = reinterpret_cast<const float4*>(sh);
 #pragma unroll
-                for (int i = 0; i < 12; i++) {
-                    if (i < n4) {
-                        const float4 t = sh4[i];
-                        shl[4 * i] = t.x; shl[4 * i + 1] = t.y; shl[4 * i + 2] = t.z; shl[4 * i + 3] = t.w;
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 16; k++) {  // entries past the active degree were loaded as padding: clear them
-                    if (k >= ncoef) { shl[3 * k] = 0.f; shl[3 * k + 1] = 0.f; shl[3 * k + 2] = 0.f; }
-                }
+                for (int i = 0; i < 12; i++)
+                    if (i < n4) take4(i, sh4[i]);
             } else {
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    if (k < ncoef) { shl[3 * k] = sh[3 * k]; shl[3 * k + 1] = sh[3 * k + 1]; shl[3 * k + 2] = sh[3 * k + 2]; }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                if (k < ncoef) {
-                    dshv[3 * k] = Y[k] * dRGB[0]; dshv[3 * k + 1] = Y[k] * dRGB[1]; dshv[3 * k + 2] = Y[k] * dRGB[2];
-                }
+                for (int k = 0; k < 16; k++)
+                    if (k < ncoef) t[k] = sh[3 * k] * dRGB[0] + sh[3 * k + 1] * dRGB[1] + sh[3 * k + 2] * dRGB[2];
             }
             float ddir[3], dm[3];
-            sgr_sh_dir_backward(D, dir[0], dir[1], dir[2], shl, dRGB, ddir);
+            sgr_sh_dir_backward(D, dir[0], dir[1], dir[2], t, ddir);
             sgr_dnormvdv(dir_orig, ddir, dm);
             dmean[0] += dm[0]; dmean[1] += dm[1]; dmean[2] += dm[2];
-        }
-        // dL/dSH row: Y_k * dL/dRGB below the active degree, zeros above and for culled Gaussians
-        if (stage) {
-            __builtin_amdgcn_wave_barrier();  // every lane has read its row
 #pragma unroll
-            for (int i = 0; i < 12; i++)
-                sSH[wave][lane * 12 + i] = make_float4(dshv[4 * i], dshv[4 * i + 1], dshv[4 * i + 2], dshv[4 * i + 3]);
-            __builtin_amdgcn_wave_barrier();
+            for (int k = 0; k < 16; k++)
+                if (k >= ncoef) Y[k] = 0.f;
+        }
+        // dL/dSH row: Y_k * dL/dRGB below the active degree, zeros above and for culled Gaussians (Y = 0, dRGB = 0) --
+        // element e of the row is Y[e / 3] * dRGB[e % 3], formed where it is stored instead of held in 48 registers
+        auto elem4 = [&](int i) __attribute__((always_inline)) {
+            return make_float4(Y[(4 * i) / 3] * dRGB[(4 * i) % 3], Y[(4 * i + 1) / 3] * dRGB[(4 * i + 1) % 3],
+                               Y[(4 * i + 2) / 3] * dRGB[(4 * i + 2) % 3], Y[(4 * i + 3) / 3] * dRGB[(4 * i + 3) % 3]);
+        };
+        if (stage) {
             float4* dst = reinterpret_cast<float4*>(dL_dsh) + (size_t)g0 * 12;
 #pragma unroll
-            for (int it = 0; it < 12; it++) {
-                const int f = it * 64 + lane;
-                if (f < nrow4) dst[f] = sSH[wave][f];
+            for (int h = 0; h < 2; h++) {
+                if ((lane >> 5) == h) {
+#pragma unroll
+                    for (int i = 0; i < 12; i++) sSH[wave][(lane & 31) * 12 + i] = elem4(i);
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 6; it++) {
+                    const int f = h * 384 + it * 64 + lane;
+                    if (f < nrow4) dst[f] = sSH[wave][f - h * 384];
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         } else if (!live) {
         } else if (vec) {
@@ -277,11 +300,11 @@ sgr_gauss_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, con
             const int n4 = (M * 3) >> 2;
 #pragma unroll
             for (int i = 0; i < 12; i++)
-                if (i < n4) dsh4[i] = make_float4(dshv[4 * i], dshv[4 * i + 1], dshv[4 * i + 2], dshv[4 * i + 3]);
+                if (i < n4) dsh4[i] = elem4(i);
         } else {
 #pragma unroll
-            for (int k = 0; k < 48; k++)
-                if (k < M * 3) dsh[k] = dshv[k];
+            for (int k = 0; k < 16; k++)
+                if (k < M) { dsh[3 * k] = Y[k] * dRGB[0]; dsh[3 * k + 1] = Y[k] * dRGB[1]; dsh[3 * k + 2] = Y[k] * dRGB[2]; }
             for (int k = 48; k < M * 3; k++) dsh[k] = 0.f;
         }
     }

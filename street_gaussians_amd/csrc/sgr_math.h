@@ -381,44 +381,37 @@ SGR_HD void sgr_proj_depth_backward(const float* m, const SgrCam& cam, float g2x
     dL_dmean[2] += (view[10] - view[11] * mul3) * ddepth;
 }
 
-// backward.cu:20-139: given normalised dir (x,y,z), SH row `sh` (3 floats per coefficient) and the
-// (clamp-masked) dL/dRGB, returns dL/ddir; the caller applies dnormvdv.  dY/d{x,y,z} of the basis
-// functions, coefficient by coefficient.
-SGR_HD void sgr_sh_dir_backward(int deg, float x, float y, float z, const float* sh, const float* dRGB, float* dL_ddir) {
-    float dx[3] = {0, 0, 0}, dy[3] = {0, 0, 0}, dz[3] = {0, 0, 0};
-#define SGR_S(k, ch) sh[3 * (k) + (ch)]
-    for (int ch = 0; ch < 3; ch++) {
-        if (deg > 0) {
-            dx[ch] = -SGR_SH_C1 * SGR_S(3, ch);
-            dy[ch] = -SGR_SH_C1 * SGR_S(1, ch);
-            dz[ch] = SGR_SH_C1 * SGR_S(2, ch);
-            if (deg > 1) {
-                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                dx[ch] += SGR_SH_C2_0 * y * SGR_S(4, ch) + SGR_SH_C2_2 * 2.f * -x * SGR_S(6, ch) + SGR_SH_C2_3 * z * SGR_S(7, ch) +
-                          SGR_SH_C2_4 * 2.f * x * SGR_S(8, ch);
-                dy[ch] += SGR_SH_C2_0 * x * SGR_S(4, ch) + SGR_SH_C2_1 * z * SGR_S(5, ch) + SGR_SH_C2_2 * 2.f * -y * SGR_S(6, ch) +
-                          SGR_SH_C2_4 * 2.f * -y * SGR_S(8, ch);
-                dz[ch] += SGR_SH_C2_1 * y * SGR_S(5, ch) + SGR_SH_C2_2 * 2.f * 2.f * z * SGR_S(6, ch) + SGR_SH_C2_3 * x * SGR_S(7, ch);
-                if (deg > 2) {
-                    dx[ch] += (SGR_SH_C3_0 * SGR_S(9, ch) * 3.f * 2.f * xy + SGR_SH_C3_1 * SGR_S(10, ch) * yz +
-                               SGR_SH_C3_2 * SGR_S(11, ch) * -2.f * xy + SGR_SH_C3_3 * SGR_S(12, ch) * -3.f * 2.f * xz +
-                               SGR_SH_C3_4 * SGR_S(13, ch) * (-3.f * xx + 4.f * zz - yy) + SGR_SH_C3_5 * SGR_S(14, ch) * 2.f * xz +
-                               SGR_SH_C3_6 * SGR_S(15, ch) * 3.f * (xx - yy));
-                    dy[ch] += (SGR_SH_C3_0 * SGR_S(9, ch) * 3.f * (xx - yy) + SGR_SH_C3_1 * SGR_S(10, ch) * xz +
-                               SGR_SH_C3_2 * SGR_S(11, ch) * (-3.f * yy + 4.f * zz - xx) + SGR_SH_C3_3 * SGR_S(12, ch) * -3.f * 2.f * yz +
-                               SGR_SH_C3_4 * SGR_S(13, ch) * -2.f * xy + SGR_SH_C3_5 * SGR_S(14, ch) * -2.f * yz +
-                               SGR_SH_C3_6 * SGR_S(15, ch) * -3.f * 2.f * xy);
-                    dz[ch] += (SGR_SH_C3_1 * SGR_S(10, ch) * xy + SGR_SH_C3_2 * SGR_S(11, ch) * 4.f * 2.f * yz +
-                               SGR_SH_C3_3 * SGR_S(12, ch) * 3.f * (2.f * zz - xx - yy) + SGR_SH_C3_4 * SGR_S(13, ch) * 4.f * 2.f * xz +
-                               SGR_SH_C3_5 * SGR_S(14, ch) * (xx - yy));
-                }
+// backward.cu:20-139: given normalised dir (x,y,z) and the SH row already contracted with the (clamp-masked) dL/dRGB,
+// t[k] = sum_ch sh[3k + ch] * dL/dRGB[ch], returns dL/ddir = sum_k dY_k/d{x,y,z} * t[k]; the caller applies dnormvdv.
+// The reference sums dRGB/d{x,y,z} per channel first and contracts with dL/dRGB last; contracting first is the same sum
+// reassociated and needs 16 live values per Gaussian instead of 48 (the per-Gaussian backward's register budget).
+SGR_HD void sgr_sh_dir_backward(int deg, float x, float y, float z, const float* t, float* dL_ddir) {
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (deg > 0) {
+        dx = -SGR_SH_C1 * t[3];
+        dy = -SGR_SH_C1 * t[1];
+        dz = SGR_SH_C1 * t[2];
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            dx += SGR_SH_C2_0 * y * t[4] + SGR_SH_C2_2 * 2.f * -x * t[6] + SGR_SH_C2_3 * z * t[7] + SGR_SH_C2_4 * 2.f * x * t[8];
+            dy += SGR_SH_C2_0 * x * t[4] + SGR_SH_C2_1 * z * t[5] + SGR_SH_C2_2 * 2.f * -y * t[6] + SGR_SH_C2_4 * 2.f * -y * t[8];
+            dz += SGR_SH_C2_1 * y * t[5] + SGR_SH_C2_2 * 2.f * 2.f * z * t[6] + SGR_SH_C2_3 * x * t[7];
+            if (deg > 2) {
+                dx += (SGR_SH_C3_0 * t[9] * 3.f * 2.f * xy + SGR_SH_C3_1 * t[10] * yz + SGR_SH_C3_2 * t[11] * -2.f * xy +
+                       SGR_SH_C3_3 * t[12] * -3.f * 2.f * xz + SGR_SH_C3_4 * t[13] * (-3.f * xx + 4.f * zz - yy) +
+                       SGR_SH_C3_5 * t[14] * 2.f * xz + SGR_SH_C3_6 * t[15] * 3.f * (xx - yy));
+                dy += (SGR_SH_C3_0 * t[9] * 3.f * (xx - yy) + SGR_SH_C3_1 * t[10] * xz +
+                       SGR_SH_C3_2 * t[11] * (-3.f * yy + 4.f * zz - xx) + SGR_SH_C3_3 * t[12] * -3.f * 2.f * yz +
+                       SGR_SH_C3_4 * t[13] * -2.f * xy + SGR_SH_C3_5 * t[14] * -2.f * yz + SGR_SH_C3_6 * t[15] * -3.f * 2.f * xy);
+                dz += (SGR_SH_C3_1 * t[10] * xy + SGR_SH_C3_2 * t[11] * 4.f * 2.f * yz +
+                       SGR_SH_C3_3 * t[12] * 3.f * (2.f * zz - xx - yy) + SGR_SH_C3_4 * t[13] * 4.f * 2.f * xz +
+                       SGR_SH_C3_5 * t[14] * (xx - yy));
             }
         }
     }
-#undef SGR_S
-    dL_ddir[0] = dx[0] * dRGB[0] + dx[1] * dRGB[1] + dx[2] * dRGB[2];
-    dL_ddir[1] = dy[0] * dRGB[0] + dy[1] * dRGB[1] + dy[2] * dRGB[2];
-    dL_ddir[2] = dz[0] * dRGB[0] + dz[1] * dRGB[1] + dz[2] * dRGB[2];
+    dL_ddir[0] = dx;
+    dL_ddir[1] = dy;
+    dL_ddir[2] = dz;
 }
 
 // auxiliary.h:107-117

@@ -75,11 +75,11 @@ void hm_backward(int P, int D, int M, const float* means, const float* scales, c
         float Y[16];
         sgr_sh_basis(D, dir[0], dir[1], dir[2], Y);
         const float* sh = shs + (size_t)i * M * 3;
-        float shl[48] = {0};
+        float t[16] = {0};
         for (int k = 0; k < (D + 1) * (D + 1); k++)
-            for (int ch = 0; ch < 3; ch++) { shl[3 * k + ch] = sh[3 * k + ch]; dsh[((size_t)i * M + k) * 3 + ch] = Y[k] * dRGB[ch]; }
+            for (int ch = 0; ch < 3; ch++) { t[k] += sh[3 * k + ch] * dRGB[ch]; dsh[((size_t)i * M + k) * 3 + ch] = Y[k] * dRGB[ch]; }
         float ddir[3], dm[3];
-        sgr_sh_dir_backward(D, dir[0], dir[1], dir[2], shl, dRGB, ddir);
+        sgr_sh_dir_backward(D, dir[0], dir[1], dir[2], t, ddir);
         sgr_dnormvdv(dor, ddir, dm);
         for (int k = 0; k < 3; k++) dmean3D[3 * i + k] = dmean[k] + dm[k];
         for (int k = 0; k < 6; k++) dcov3D[6 * i + k] = dcov[k];
