@@ -81,10 +81,12 @@ sgr_filter_kernel(int P, const float* __restrict__ means3D, const float* __restr
     filter_means2D[2 * idx + 1] = pr.py;
 }
 
-// K2.  One Gaussian per lane.  The SH rows of a wave's 64 Gaussians are one contiguous 12 KB block (M = 16): per-lane
-// float4 loads at a 192-byte stride touch 64 cache lines per instruction, so -- once the geometry has decided which
-// Gaussians survive the cull -- the wave copies the rows of the survivors into LDS with coalesced 1 KB transfers
-// (rows of culled Gaussians are skipped float4 by float4) and every lane reads its own row from there.
+// K2.  One Gaussian per lane.  The SH rows of a wave's 64 Gaussians are one contiguous 12 KB block (M = 16) which every
+// lane reads with per-lane float4 loads at a 192-byte stride.  A/B form behind switch bit 6 (SGR_PRE_STAGE=1): once the
+// geometry has decided which Gaussians survive the cull, the wave copies the survivors' rows through LDS with
+// coalesced 1 KB transfers, half of its rows at a time -- measured on MI355X 0.099 vs 0.090 ms at 1 M Gaussians (the
+// extra phases lengthen a launch that is only three rounds of workgroups deep) and 0.346 vs 0.360 ms at 5 M: not the
+// default.
 // num_rendered = sum of tiles_touched does not depend on the depth order, so it is accumulated here (one atomic per
 // workgroup into header[1]) and the host can read it back while the depth sort and the offset scan are still running.
 __global__ void __launch_bounds__(SGR_PRE_THREADS)
@@ -96,7 +98,7 @@ sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     // rows padded to 13 float4 (52 dwords): the per-lane float4 reads of 16 consecutive rows then fall on 16 disjoint
     // 4-bank groups (a 48-dword stride puts them on 4).  Dynamic LDS: none when the rows are read directly.
     extern __shared__ float4 sSHdyn[];
-    float4 (*sSH)[64 * 13] = reinterpret_cast<float4 (*)[64 * 13]>(sSHdyn);
+    float4 (*sSH)[32 * 13] = reinterpret_cast<float4 (*)[32 * 13]>(sSHdyn);
     __shared__ uint32_t wave_sum[SGR_PRE_THREADS / 64];
     const SgrCam& cam = *camp;
     const int gidx = blockIdx.x * SGR_PRE_THREADS + threadIdx.x;
@@ -107,19 +109,52 @@ sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     SgrProj pr = sgr_preprocess_geom(idx, p, scales, rotations, cov3D_precomp, cam, live ? gv.header : nullptr, prefiltered);
     const bool ok = live && pr.ok;
 
-    const bool stage = stage_sh && shs != nullptr && M == 16;
+    // A/B form (switch bit 6): the rows of the wave's surviving Gaussians through LDS, HALF the wave's rows at a time
+    // (6.5 KB per wave), each lane folding its row into r, g, b as it reads it -- the same operations in the same order
+    // as the direct form below.
+    const bool stage = stage_sh && shs != nullptr && colors_precomp == nullptr && M == 16;
+    float rgb_s[3] = {0.f, 0.f, 0.f};
     if (stage) {
+#pragma clang fp contract(off)
+        float Y[16];
+        {
+            float dx = p[0] - cam.campos[0], dy = p[1] - cam.campos[1], dz = p[2] - cam.campos[2];
+            const float t0 = dx * dx, t1 = dy * dy, t2 = dz * dz;
+            const float len = sqrtf(t0 + t1 + t2);
+            dx = dx / len; dy = dy / len; dz = dz / len;
+            sgr_sh_basis(D, dx, dy, dz, Y);
+        }
+        const int ncoef = (D + 1) * (D + 1);
+        const int n4 = (ncoef * 3 + 3) >> 2;
         const uint64_t vis = __ballot(ok);
         const int g0 = blockIdx.x * SGR_PRE_THREADS + wave * 64;
         const int nrow4 = max(0, min(64, P - g0)) * 12;  // float4s of this wave's rows
         const float4* src = reinterpret_cast<const float4*>(shs) + (size_t)g0 * 12;
 #pragma unroll
-        for (int it = 0; it < 12; it++) {
-            const int f = it * 64 + lane;
-            const int row = f / 12;
-            if (f < nrow4 && ((vis >> row) & 1ull)) sSH[wave][f + row] = src[f];
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int it = 0; it < 6; it++) {
+                const int f = h * 384 + it * 64 + lane;
+                const int row = f / 12;
+                if (f < nrow4 && ((vis >> row) & 1ull)) sSH[wave][f - h * 384 + (row - 32 * h)] = src[f];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if ((lane >> 5) == h && ok) {
+#pragma unroll
+                for (int i = 0; i < 12; i++) {
+                    if (i < n4) {
+                        const float4 t = sSH[wave][(lane & 31) * 13 + i];
+                        const float e[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int k = (4 * i + j) / 3, ch = (4 * i + j) % 3;
+                            if (k < ncoef) rgb_s[ch] = (k == 0) ? Y[0] * e[j] : rgb_s[ch] + Y[k] * e[j];
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
     }
 
     uint32_t n = 0;
@@ -147,9 +182,11 @@ sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             const int ncoef = (D + 1) * (D + 1);
             const float* sh = shs + (size_t)idx * M * 3;
             float r = 0.f, g = 0.f, b = 0.f;
-            if (((M * 3) & 3) == 0 && M <= 16) {
-                // row stride is a multiple of 16 B: the row as float4 (12 at SH degree 3), from LDS when staged
-                const float4* sh4 = stage ? &sSH[wave][lane * 13] : reinterpret_cast<const float4*>(sh);
+            if (stage) {
+                r = rgb_s[0]; g = rgb_s[1]; b = rgb_s[2];
+            } else if (((M * 3) & 3) == 0 && M <= 16) {
+                // row stride is a multiple of 16 B: the row as float4 (12 at SH degree 3)
+                const float4* sh4 = reinterpret_cast<const float4*>(sh);
                 const int n4 = (ncoef * 3 + 3) >> 2;
                 float buf[48];
 #pragma unroll
@@ -302,8 +339,8 @@ void sgr_launch_preprocess(int P, int D, int M, const float* means3D, const floa
                            const float* colors_precomp, const SgrCam* cam, const SgrGeomView& gv, int* radii,
                            int prefiltered, bool stage_sh, hipStream_t s) {
     if (P <= 0) return;
-    const bool stage = stage_sh && shs != nullptr && M == 16;
-    const size_t lds = stage ? (size_t)(SGR_PRE_THREADS / 64) * 64 * 13 * sizeof(float4) : 0;
+    const bool stage = stage_sh && shs != nullptr && colors_precomp == nullptr && M == 16;
+    const size_t lds = stage ? (size_t)(SGR_PRE_THREADS / 64) * 32 * 13 * sizeof(float4) : 0;
     sgr_preprocess_kernel<<<(P + SGR_PRE_THREADS - 1) / SGR_PRE_THREADS, SGR_PRE_THREADS, lds, s>>>(
         P, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, cam, gv, radii, prefiltered,
         stage ? 1 : 0);
