@@ -179,6 +179,13 @@ def test_culling_is_invisible_and_backward_is_deterministic(name):
             assert torch.equal(int_a(k), int_s(k)), f"sort form changed {k}"
         for k in ["color", "depth", "alpha", "semantic"]:
             assert torch.equal(res_a[k], res_s[k]), f"sort form changed {k}"
+    with switches(_C.PRE_STAGE_SH):  # SH rows through LDS in the preprocess (A/B form): the same operations, the same bits
+        res_p, int_p = raw_forward(kw)
+        vis = res_a["radii"] > 0
+        for k in ["rgb", "clamped"]:
+            assert torch.equal(int_a(k)[vis], int_p(k)[vis]), f"staged SH rows changed {k}"
+        for k in ["color", "depth", "alpha", "semantic"]:
+            assert torch.equal(res_a[k], res_p[k]), f"staged SH rows changed {k}"
     if name in ILL_CONDITIONED:
         return  # the comparisons below are rounding-level statements; they do not apply to cancelling quadratic forms
     with switches(_C.NO_DPP):
