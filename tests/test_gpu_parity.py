@@ -52,6 +52,13 @@ def _cases():
     sc.scales[::2] = sc.scales[::2] * torch.tensor([900.0, 0.02, 0.02])
     sc.scales[1::4] = sc.scales[1::4] * torch.tensor([0.05, 400.0, 0.05])
     out["giant_degenerate"] = (cam, sc, dict())
+    # SH rows narrower than 16 coefficients (max_sh_degree 0 / 1 / 2 models: M = 1, 4, 9): 3-, 12- and 27-float rows take the
+    # scalar / float4 / scalar row paths of the preprocess and of the per-Gaussian backward instead of the LDS-staged one
+    cam = syn.make_camera(320, 200, fx=330.0, yaw_deg=-3.0)
+    out["sh_rows_M1"] = (cam, syn.make_scene(3000, cam, sh_degree_max=0, S=0, seed=11, scale_px=0.006), dict(deg=0))
+    out["sh_rows_M4"] = (cam, syn.make_scene(3000, cam, sh_degree_max=1, S=2, seed=12, scale_px=0.006), dict(deg=1))
+    out["sh_rows_M9"] = (cam, syn.make_scene(3000, cam, sh_degree_max=2, S=0, seed=13, scale_px=0.006), dict(deg=2))
+    out["sh_rows_M9_deg1"] = (cam, syn.make_scene(3000, cam, sh_degree_max=2, S=0, seed=14, scale_px=0.006), dict(deg=1))
     return out
 
 
