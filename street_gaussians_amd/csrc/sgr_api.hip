@@ -7,6 +7,7 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
 
@@ -150,6 +151,33 @@ static hipEvent_t readback_event() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     if (!ev[dev] && hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming) != hipSuccess) ev[dev] = nullptr;
     return ev[dev];
+}
+
+// The forward's one host wait.  hipEventSynchronize() parks the thread on an interrupt, and how long it takes to come
+// back is a property of the host (tens of microseconds on some boxes) -- time in which the GPU works off the ~0.12 ms of
+// depth sort + scan queued behind the read-back and then idles until the rest of the forward is queued.  So the thread
+// watches the pinned landing zone itself: both words were set to a value the device never writes (flag is 0 / 1,
+// num_rendered < 2^31).  Bounded: after SGR_SPIN_US microseconds (default 50 ms; 0 = never spin) it falls back to the
+// event, which is also what orders everything else behind the copy.
+#define SGR_READBACK_PENDING 0xffffffffu
+static hipError_t wait_for_readback(uint32_t* host_vals, hipEvent_t landed) {
+    static const long spin_us = [] { const char* e = getenv("SGR_SPIN_US"); return e ? atol(e) : 50000L; }();
+    if (spin_us > 0) {
+        volatile uint32_t* hv = host_vals;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            for (int i = 0; i < 256; i++) {
+                if (hv[0] != SGR_READBACK_PENDING && hv[1] != SGR_READBACK_PENDING) {
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                    return hipSuccess;
+                }
+                __builtin_ia32_pause();
+            }
+            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us)
+                break;
+        }
+    }
+    return hipEventSynchronize(landed);
 }
 
 // rasterizer_impl.cu:35-50
@@ -297,8 +325,16 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     uint32_t* host_vals = pinned_pair();
     hipEvent_t landed = readback_event();
     if (!host_vals || !landed) return fail(SGR_E_HIP, "pinned readback slot / event creation failed");
+    // both words carry a value the device never writes, so that the host can see them arrive (wait_for_readback)
+    host_vals[0] = host_vals[1] = SGR_READBACK_PENDING;
     SGR_HIP(hipMemcpyAsync(host_vals, gv.header, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     SGR_HIP(hipEventRecord(landed, stream));
+    // an error return between here and the wait must not leave this copy in flight: the next forward of this thread would
+    // take its late arrival for its own read-back
+    struct ReadbackDrain {
+        hipEvent_t ev;
+        ~ReadbackDrain() { if (ev) (void)hipEventSynchronize(ev); }
+    } drain{landed};
 
     // Depth pre-sort of the P Gaussians (32-bit keys, 4 passes over P elements), then K4: scan of tiles_touched in
     // that order.
@@ -338,7 +374,8 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
         bbase = binning_buffer(have_bytes, binning_user);
         if (!bbase) return fail(SGR_E_ALLOC, "binning buffer allocation failed");
     }
-    SGR_HIP(hipEventSynchronize(landed));  // the one host wait of the forward
+    SGR_HIP(wait_for_readback(host_vals, landed));  // the one host wait of the forward
+    drain.ev = nullptr;
     if (host_vals[0] & 1u)
         return fail(SGR_E_PREFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
     if (host_vals[1] > 0x7fffffffu) return fail(SGR_E_INVALID, "more than 2^31 tile instances");
