@@ -8,7 +8,8 @@
 // out[0]=quadrant visits (>=1 hit), out[1]=sum over (wave,batch) max over 4 4x4 blocks, out[2]= same for 8x2 rows,
 // out[3]=sum over (wave,batch) max over 2 8x4 halves, out[4]=lane hits total, out[5]=sum of 4x4 block visits,
 // out[6]=sum over waves (no batching) of max over 4x4 blocks, out[7]=# (tile,batch) rounds,
-// out[8]=sum over (tile,batch) of max over 16 blocks (whole-WG lockstep), out[9]=sum 8x4 half visits
+// out[8]=sum over (tile,batch) of max over 16 blocks (whole-WG lockstep), out[9]=sum 8x4 half visits,
+// out[10]=sum over rounds of the busiest quadrant's visits, out[11]=sum over rounds of the mean over the four quadrants
 void replay(int W, int H, const uint32_t* ranges, const uint32_t* plist, const float* m2d, const float* co,
             const uint32_t* ncontrib, int batch, double* out, float* tile_cost) {
   int gx = (W + 15) / 16, gy = (H + 15) / 16;
@@ -64,6 +65,7 @@ void replay(int W, int H, const uint32_t* ranges, const uint32_t* plist, const f
           a[1] += m; a[2] += m2; a[3] += m3; if (m > m16) m16 = m;
         }
         a[8] += m16; for (int q = 0; q < 4; ++q) if (cq[q] > mq) mq = cq[q]; tcost += mq + 6;
+        a[10] += mq; a[11] += 0.25 * (cq[0] + cq[1] + cq[2] + cq[3]);  // barrier skew of a round: max vs mean over the quadrants
       }
       for (int q = 0; q < 4; ++q) { int m = 0; for (int k = 0; k < 4; ++k) if (tot44[q][k] > m) m = tot44[q][k]; a[6] += m; }
       tile_cost[t] = (float)tcost;

@@ -28,8 +28,14 @@ out = np.zeros(16); cost = np.zeros(gx * gy, np.float32)
 arrs = [np.ascontiguousarray(x) for x in (fw.ranges.astype(np.uint32), fw.point_list.astype(np.uint32), fw.means2D.astype(np.float32), fw.conic_opacity.astype(np.float32), fw.n_contrib.astype(np.uint32))]
 L.replay(1920, 1280, *[p(a) for a in arrs], 128, p(out), p(cost))
 names = ["quadrant_visits", "max4_4x4_per_batch", "max4_8x2_per_batch", "max2_8x4_per_batch", "lane_hits", "sum_4x4_visits",
-         "max4_4x4_nobatch", "rounds", "max16_per_batch", "sum_8x4_visits"]
+         "max4_4x4_nobatch", "rounds", "max16_per_batch", "sum_8x4_visits", "sum_round_max_quadrant", "sum_round_mean_quadrant"]
 print({n: float(out[i]) for i, n in enumerate(names)})
+# barrier skew of the walk: a round ends when its busiest quadrant is done; the other three waves wait at the barrier
+for rb in (64, 128, 256, 512, 1 << 20):
+    o2 = np.zeros(16); c2 = np.zeros(gx * gy, np.float32)
+    L.replay(1920, 1280, *[p(a) for a in arrs], rb, p(o2), p(c2))
+    print(f"round of {rb if rb < 1 << 20 else 'whole list'} entries: rounds {o2[7]:.0f}, busiest-quadrant visits {o2[10]:.0f}, mean-quadrant visits "
+          f"{o2[11]:.0f} -> {100 * (o2[10] / o2[11] - 1):.1f} % of a wave's walk time waiting for the busiest quadrant")
 print("tile cost: mean", cost.mean(), "max", cost.max(), "min", cost.min(), "p10", np.percentile(cost, 10), "p90", np.percentile(cost, 90))
 ST = int(os.environ.get("SGR_SIM_ST", "8"))
 sgx = (gx + ST - 1) // ST; sgy = (gy + ST - 1) // ST
