@@ -511,13 +511,43 @@ def stage_hbm_frac(stage_ms, sb):
     return out
 
 
+def launch_plan(n_gpus, env, device_count, argv, port=None):
+    """What `bench.py --gpus N` does about its ranks.  Returns None when this process IS a rank (N = 1, or started by
+    torch.distributed.run: WORLD_SIZE == N), else the command line that re-executes bench.py as N ranks, one per GPU, under
+    torch.distributed.run on this node (rendezvous on 127.0.0.1).  Raises SystemExit (rc != 0) when N GPUs do not exist or
+    the launcher's world size contradicts --gpus: a run must never print a line for fewer ranks than it was asked for."""
+    world = env.get("WORLD_SIZE")
+    if world is not None:
+        if int(world) != n_gpus:
+            raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}")
+        return None
+    if n_gpus < 1:
+        raise SystemExit(f"--gpus {n_gpus}: need at least one GPU")
+    if device_count < n_gpus:
+        raise SystemExit(f"--gpus {n_gpus} but only {device_count} GPU(s) are visible: refusing to run on fewer ranks")
+    if n_gpus == 1:
+        return None
+    if port is None:
+        import socket
+        with socket.socket() as sk:  # a free port for the rendezvous
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     args = parse()
+    plan = launch_plan(args.gpus, os.environ, torch.cuda.device_count() if torch.cuda.is_available() else 0, sys.argv[1:])
+    if plan is not None:  # `python bench.py --gpus N` without a launcher: spawn the N ranks ourselves
+        import subprocess
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL across processes
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
+        raise SystemExit(subprocess.call(plan, env=env))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -590,16 +620,19 @@ def main():
     # ---- untimed extras: every stage bracketed (a short pass), a >= 1 s sustained region
     _, stage_ms = profiled_steps(L, wl, fence, min(50, max(5, args.steps)), 0x1FF)
     sustained = None
+    kernel_samples = (args.steps + every - 1) // every
+    kernel_region = f"the {args.steps} timed steps"
     if world == 1 and dist is None and dt < 1.0:
+        # >= 1 s of back-to-back steps: a K-step region of a few tens of ms pays its opening fence (an empty queue, one
+        # exposed host wait, clocks that dipped during the synchronisation) once per K steps.  The dominant kernel is
+        # bracketed on every 8th step here as well, so that a short --steps still has >= 16 duration samples.
         n = int(1.2 / max(dt / args.steps, 1e-5)) + 1
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(n):
-            wl.step()
-        fence()
-        sdt = time.perf_counter() - t1
+        sdt, s_timed = profiled_steps(L, wl, fence, n, 1 << 7, every=8)
         sustained = {"steps": n, "seconds": round(sdt, 3), "ms_per_step": round(1e3 * sdt / n, 4),
                      "iters_per_s": round(n / sdt, 3)}
+        if kernel_samples < 16 and s_timed.get("blend_bwd"):
+            timed = dict(timed, blend_bwd=s_timed["blend_bwd"])
+            kernel_samples, kernel_region = (n + 7) // 8, f"the sustained region of {n} steps"
     # parity mode of the blend kernels (the reference's power expression, accurate expf, true
     # division -- bit-identical alpha / depth / semantic images and rel-1e-4 end-to-end gradients against the reference's
     # kernels): an extra, untimed-for-the-headline region on the same workload, so that its cost is in the line
@@ -611,16 +644,20 @@ def main():
         try:
             for _ in range(5):
                 wl.step()
-            n_p = max(20, min(200, args.steps))
-            fence()
-            t1 = time.perf_counter()
-            for _ in range(n_p):
-                wl.step()
-            fence()
-            pdt = time.perf_counter() - t1
+            n_p = max(args.steps, int(0.6 / max(dt / args.steps, 1e-5)) + 1)  # the same kind of region as `sustained`
+            pdt, _ = profiled_steps(L, wl, fence, n_p, 0)
+            _, p_stage = profiled_steps(L, wl, fence, 16, (1 << 5) | (1 << 7) | (1 << 8))
             parity_mode = {"steps": n_p, "ms_per_step": round(1e3 * pdt / n_p, 4), "iters_per_s": round(n_p / pdt, 3),
-                           "what": "same workload with sgr_test_switches bit 7 (SGR_EXACT=1): opt-in validation mode, not "
-                                   "the default the headline is measured on"}
+                           "blend_fwd_ms": round(p_stage["blend_fwd"], 4) if p_stage.get("blend_fwd") else None,
+                           "blend_bwd_ms": round(p_stage["blend_bwd"], 4) if p_stage.get("blend_bwd") else None,
+                           "gauss_bwd_ms": round(p_stage["gauss_bwd"], 4) if p_stage.get("gauss_bwd") else None,
+                           "what": "same workload with sgr_test_switches bit 7 (SGR_EXACT=1): the mode that meets north_star's "
+                                   "1e-4 gate END TO END against the reference's kernels (alpha / depth / semantic images "
+                                   "bit-identical; tests/test_gpu_fullsize.py, tests/test_gpu_parity.py) -- the reference's power "
+                                   "expression, the device library's expf and the IEEE quotient T / (1 - alpha), unfused, "
+                                   "per-Gaussian backward without FP contraction; the default mode (`value`) uses v_exp_f32 "
+                                   "on a pre-scaled conic, a Newton-refined reciprocal and contraction: same algorithm, "
+                                   "different last bits (DESIGN.md section 4)"}
         finally:
             native_c.test_switches(prev)
         for _ in range(3):
@@ -662,14 +699,30 @@ def main():
                                 "source": "profiles/pmc_blend_bwd.json (SQ_INSTS_VALU) / live kernel_ms"}
             except Exception as ex:
                 traffic, traffic_note = None, f"profiles/pmc_blend_bwd.json unreadable: {ex}"
+        # `value`: whole-job throughput.  When the K timed steps lasted less than a second (N = 1) it is the figure of the
+        # >= 1 s sustained region (the K-step region itself stays in the line as `timed_region`)
+        value = round(world * args.steps / dt, 3)
+        ms_per_step = round(1e3 * dt / args.steps, 4)
+        timed_region = {"steps": args.steps, "ms_per_step": ms_per_step, "value": value,
+                        "what": "exactly --steps steps between two fences (barrier + synchronize)"}
+        if sustained is not None:
+            value, ms_per_step = sustained["iters_per_s"], sustained["ms_per_step"]
         line = {
             "metric": "train iters/s (fwd+bwd) @1M Gaussians 1920x1280 SH3",
-            "value": round(world * args.steps / dt, 3),
+            "value": value,
+            "value_source": ("sustained region (>= 1 s of back-to-back steps after the timed region; the timed region is "
+                             "`timed_region`)" if sustained is not None else "the timed region of --steps steps"),
+            "value_exact": parity_mode["iters_per_s"] if parity_mode is not None else None,
+            "ms_per_step_exact": parity_mode["ms_per_step"] if parity_mode is not None else None,
+            "modes": "value = default arithmetic of the blend kernels; value_exact = parity mode (SGR_EXACT=1), the mode that "
+                     "meets the 1e-4 gate end to end against the reference's kernels: see `parity_mode`",
             "unit": "iters/s",
             "n_gpus": world,
+            "rccl_ranks": (dist.get_world_size() if dist is not None else 0),
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "ms_per_step": ms_per_step,
+            "timed_region": timed_region,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -697,8 +750,8 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "kernel_ms": round(bwd_ms, 4) if bwd_ms else None,
                          "kernel_ms_source": f"HIP events around the kernel on its launch stream, mean over "
-                                             f"{(args.steps + every - 1) // every} launches of the {args.steps} timed "
-                                             f"steps (every {every}th step carries the event pair)",
+                                             f"{kernel_samples} launches of {kernel_region} "
+                                             f"(every 8th step at most carries the event pair)",
                          "blend_fwd": {"kernel_ms": round(fwd_ms, 4) if fwd_ms else None,
                                        "achieved": round(fwd_bytes / (fwd_ms * 1e-3) / 1e9, 2) if fwd_ms else None,
                                        "algorithmic_bytes_per_launch": fwd_bytes},
@@ -781,14 +834,13 @@ def other_configs(args, L, dev, fence):
         torch.cuda.empty_cache()
         # twice (fresh state each time), both kept: the region is ~0.15 s long with a host synchronisation at every
         # densify step, so a box whose host cores are busy elsewhere shows up here first (observed once: 55 ms iterations
-        # with normal kernels); the better run is the entry, the other one rides along
+        # with normal kernels).  The FIRST run is the entry (no selection), the second rides along
         runs = []
         for _ in range(2):
             torch.cuda.empty_cache()
             loop = DensifyLoop(args, 5_000_000, dev, args.densify_every)
             runs.append(loop.run(fence))
             del loop
-        runs.sort(key=lambda r: r["ms_per_step_amortised"])
         runs[0]["other_run"] = {k: runs[1][k] for k in ("ms_per_step_amortised", "raster_ms_steady_median", "densify_ms_mean",
                                                         "host_ms_to_queue_one_iteration", "device_allocations_in_region")}
         out.append(runs[0])

@@ -180,7 +180,10 @@ int sgr_export_internal(int which, int P, int R, int width, int height, char* ge
 /* ---- A/B switches of the blend kernels (tests, tools/gpu_ab.sh): bit 0 no quadrant cull, bit 1 no DPP wave
  * reduction, bit 2 no deterministic LDS combine, bit 3 the backward ignores the forward's hit record and redoes the
  * geometric cull, bit 4 the S = 0 backward runs the transposed-accumulation kernel (A/B design, slower),
- * bit 5 the radix sorts run in their one-sweep (decoupled look-back) form (A/B design, slower; SGR_ONESWEEP).
+ * bit 5 the radix sorts run in their one-sweep (decoupled look-back) form (A/B design, slower; SGR_ONESWEEP),
+ * bit 7 (SGR_EXACT=1) PARITY MODE: the blend kernels evaluate the reference's own power expression, the device
+ * library's expf and the IEEE quotient T / (1 - alpha), unfused -- alpha / depth / semantic images bit-identical to the
+ * reference's kernels, gradients within rel 1e-4 end to end.
  * mask >= 0 sets them process-wide, mask < 0 only queries; returns the previous mask.  The initial
  * value comes from the environment (SGR_NO_CULL, SGR_NO_DPP, SGR_NO_DET, SGR_NO_HITS, SGR_V2), read once. */
 int sgr_test_switches(int mask);
@@ -196,6 +199,11 @@ int sgr_test_sort32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t*
 size_t sgr_test_sort_hist_words(uint32_t n);
 size_t sgr_test_scan_tmp_words(size_t n);
 int sgr_test_wave_sum(const float* in, float* out_dpp, float* out_shfl, int nwaves, void* stream);
+/* parity-mode elementary functions against the toolchain's own (device arrays of n floats each): exp_lib[i] = expf(x[i]),
+ * exp_ref[i] = the written-out sequence the blend kernels run in SGR_EXACT mode; div_lib[i] = a[i] / b[i] (hipcc's IEEE
+ * expansion), div_ref[i] = the shared-reciprocal form.  The tests require bit equality over the kernels' operand ranges. */
+int sgr_test_exact_math(int n, const float* x, float* exp_lib, float* exp_ref, const float* a, const float* b,
+                        float* div_lib, float* div_ref, void* stream);
 
 #ifdef __cplusplus
 }

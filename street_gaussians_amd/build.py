@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libsgr_hip.so")
-SOURCES = ["sgr_preprocess.hip", "sgr_scan_sort.hip", "sgr_blend_fwd.hip", "sgr_blend_bwd.hip", "sgr_gauss_bwd.hip",
+SOURCES = ["sgr_preprocess.hip", "sgr_scan_sort.hip", "sgr_blend_fwd.hip", "sgr_blend_bwd.hip", "sgr_gauss_bwd.hip", "sgr_gauss_bwd_strict.hip",
            "sgr_knn.hip", "sgr_multiview.hip", "sgr_scene.hip", "sgr_loss.hip", "sgr_densify.hip", "sgr_api.hip"]
 HEADERS = ["sgr_common.h", "sgr_math.h", os.path.join("..", "..", "include", "sgr.h"),
            os.path.join("..", "..", "include", "sgr_scene.h"), os.path.join("..", "..", "include", "sgr_loss.h"), os.path.join("..", "..", "include", "sgr_densify.h")]
@@ -29,6 +29,8 @@ HEADERS = ["sgr_common.h", "sgr_math.h", os.path.join("..", "..", "include", "sg
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-fno-slp-vectorize", "-mllvm",
          "-enable-post-misched=0", "-mllvm", "-amdgpu-use-amdgpu-trackers=1", "-Wall", "-Wno-unused-function"]
 PER_FILE_FLAGS = {"sgr_scan_sort.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+# sources that #include another source (a second instantiation under other names / other FP settings)
+INCLUDES = {"sgr_gauss_bwd_strict.hip": ["sgr_gauss_bwd.hip"]}
 
 
 def flags_for(src: str) -> list:
@@ -66,7 +68,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     def compile_one(src):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
-        if not force and os.path.exists(o) and os.path.getmtime(o) > max(os.path.getmtime(s), hdr_time):
+        dep_time = max([os.path.getmtime(s), hdr_time] + [os.path.getmtime(os.path.join(CSRC, d)) for d in INCLUDES.get(src, [])])
+        if not force and os.path.exists(o) and os.path.getmtime(o) > dep_time:
             return o, False
         cmd = [hipcc] + flags_for(src) + ["-c", s, "-o", o]
         if verbose:

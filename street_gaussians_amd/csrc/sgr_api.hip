@@ -43,6 +43,13 @@ void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, cons
                           float4* cd, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dsemantic,
                           const SgrStatSink& sink, hipStream_t s);
+// the same compiled with FP contraction off (sgr_gauss_bwd_strict.hip): parity mode
+void sgr_launch_gauss_bwd_strict(int P, int D, int M, int S, const float* means3D, const int* radii, const float* shs,
+                                 const float* scales, const float* rotations, const float* cov3D_precomp, const SgrCam* cam,
+                                 const SgrGeomView& gv, const float* partials, int row_stride, const uint8_t* touched,
+                                 float4* cd, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+                                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dsemantic,
+                                 const SgrStatSink& sink, hipStream_t s);
 void sgr_launch_masked_color_grad(int P, const uint32_t* clamped, const float* dL_dcolor, float* out, hipStream_t s);
 void sgr_launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, size_t means_stride,
                                    const float* campos, size_t campos_stride, const float* drgb, size_t drgb_stride,
@@ -527,9 +534,9 @@ int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, 
         prof_end(stream);
     }
     prof_begin(8, stream);
-    sgr_launch_gauss_bwd(P, D, M, S, means3D, radii_ptr, shs, scales, rotations, cov3D_precomp, cam_slot(gv), gv, partials,
-                         stride, touched, cd, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
-                         dL_drot, dL_dsemantic, sink, stream);
+    ((switches() & 128) ? sgr_launch_gauss_bwd_strict : sgr_launch_gauss_bwd)(
+        P, D, M, S, means3D, radii_ptr, shs, scales, rotations, cov3D_precomp, cam_slot(gv), gv, partials, stride, touched, cd,
+        dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, dL_dsemantic, sink, stream);
     SGR_STAGE("gauss_bwd");
     prof_end(stream);
     if (touched && (switches() & (1 | 8)) != 0) SGR_HIP(hipMemsetAsync(touched, 0, (size_t)R, stream));
@@ -791,6 +798,25 @@ int sgr_test_sort32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t*
 }
 size_t sgr_test_sort_hist_words(uint32_t n) { return sgr_sort_hist_words(n ? n : 1); }
 size_t sgr_test_scan_tmp_words(size_t n) { return sgr_scan_tmp_count(n ? n : 1); }
+__global__ void sgr_exact_math_test_kernel(int n, const float* x, float* exp_lib, float* exp_ref, const float* a,
+                                           const float* b, float* div_lib, float* div_ref) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    exp_lib[i] = expf(x[i]);
+    exp_ref[i] = sgr_expf_ref(x[i]);
+    const SgrRcp rc = sgr_rcp_refined(b[i]);
+    div_lib[i] = a[i] / b[i];
+    div_ref[i] = sgr_div_by(a[i], b[i], rc.y);
+}
+int sgr_test_exact_math(int n, const float* x, float* exp_lib, float* exp_ref, const float* a, const float* b,
+                        float* div_lib, float* div_ref, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int debug = 1;
+    if (n <= 0) return 0;
+    sgr_exact_math_test_kernel<<<(n + 255) / 256, 256, 0, stream>>>(n, x, exp_lib, exp_ref, a, b, div_lib, div_ref);
+    SGR_STAGE("exact_math");
+    return 0;
+}
 int sgr_test_wave_sum(const float* in, float* out_dpp, float* out_shfl, int nwaves, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const int debug = 1;

@@ -47,6 +47,11 @@ struct SgrBwdBatch { static constexpr int value = SMAX <= 8 ? SGR_BWD_BATCH : SG
 #ifndef SGR_FACTORED
 #define SGR_FACTORED 1
 #endif
+// parity mode: 1 = expf / division written out without their range handling (sgr_math.h: sgr_expf_ref, sgr_div_by; same
+// bits for the operands of this kernel), 0 = the library's expf and the compiler's IEEE `/` (A/B: tools/build_variant.py)
+#ifndef SGR_EXACT_TRIM
+#define SGR_EXACT_TRIM 1
+#endif
 #ifndef SGR_FOLD
 #define SGR_FOLD 1
 #endif
@@ -363,6 +368,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
         }
     }
     const float bgdot = bg_color[0] * dLdC0 + bg_color[1] * dLdC1 + bg_color[2] * dLdC2;
+    const bool bg_zero = bg_color[0] == 0.0f && bg_color[1] == 0.0f && bg_color[2] == 0.0f;  // scalar loads: wave-uniform
     // d(pixel)/d(ndc) (backward.cu:501-502) with the 1/log2(e) of the pre-scaled conic folded in
     // EXACT (parity mode): the conic is staged with exact power-of-two scalings only (scale constant 1 instead of log2 e),
     // G comes from the reference's own power expression + the accurate expf, T is recovered by a true division
@@ -491,7 +497,9 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                     const float oma = 1.0f - alpha;
                     float inv1ma = __builtin_amdgcn_rcpf(oma);
                     inv1ma = fmaf(fmaf(-oma, inv1ma, 1.0f), inv1ma, inv1ma);  // Newton step: T recovery compounds per layer
-                    T = EXACT ? T / oma : T * inv1ma;  // T = T / (1 - alpha) (backward.cu:547)
+                    // T = T / (1 - alpha) (backward.cu:547).  EXACT: the IEEE quotient, from the refined reciprocal above
+                    // and two residual corrections (sgr_div_by: the bits of `/` for these operand ranges)
+                    T = EXACT ? (SGR_EXACT_TRIM ? sgr_div_by(T, oma, inv1ma) : T / oma) : T * inv1ma;
                     wm = alpha * T;
                     const float one_m_la = 1.0f - last_alpha;
                     float d;
@@ -543,7 +551,13 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                     }
                     last_alpha = alpha;
                     d *= T;
-                    Gd = EXACT ? G * (d + (-T_final / oma) * bgdot) : G * fmaf(-T_final * inv1ma, bgdot, d);  // backward.cu:611-614
+                    // backward.cu:611-614.  EXACT with a black background (bg_zero, wave-uniform): (-T_final / oma) * 0 adds a
+                    // signed zero -- the second quotient is skipped
+                    if (EXACT)
+                        Gd = (SGR_EXACT_TRIM && bg_zero) ? G * d
+                                                         : G * (d + (SGR_EXACT_TRIM ? sgr_div_by(-T_final, oma, inv1ma) : -T_final / oma) * bgdot);
+                    else
+                        Gd = G * fmaf(-T_final * inv1ma, bgdot, d);
                 }
                 if (SMAX > 0 && !(DPP && SGR_FOLD)) {
 #pragma unroll
@@ -630,8 +644,8 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                 const int j0 = chunk * 64 + sgr_pop_lowest(m);
                 const float4 a0 = sA[j0], q0 = sB[j0];
                 const float dx0 = a0.x - pxf, dy0 = a0.y - pyf;
-                const float pw0 = EXACT ? sgr_power_ref(-2.0f * q0.x, -q0.y, -2.0f * q0.z, dx0, dy0) : sgr_power2(q0.x, q0.y, q0.z, dx0, dy0);
-                const float G0 = EXACT ? expf(pw0) : __builtin_amdgcn_exp2f(pw0);
+                const float pw0 = EXACT ? sgr_power_ref_staged(q0.x, q0.y, q0.z, dx0, dy0) : sgr_power2(q0.x, q0.y, q0.z, dx0, dy0);
+                const float G0 = EXACT ? (SGR_EXACT_TRIM ? sgr_expf_ref(pw0) : expf(pw0)) : __builtin_amdgcn_exp2f(pw0);
                 process(j0, q0, dx0, dy0, pw0, G0, fminf(0.99f, q0.w * G0), true);
             }
             while (m) {
@@ -642,9 +656,9 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                 const float4 a0 = sA[j0], q0 = sB[j0];
                 const float4 a1 = sA[j1], q1 = sB[j1];
                 const float dx0 = a0.x - pxf, dy0 = a0.y - pyf, dx1 = a1.x - pxf, dy1 = a1.y - pyf;
-                const float pw0 = EXACT ? sgr_power_ref(-2.0f * q0.x, -q0.y, -2.0f * q0.z, dx0, dy0) : sgr_power2(q0.x, q0.y, q0.z, dx0, dy0);
-                const float pw1 = EXACT ? sgr_power_ref(-2.0f * q1.x, -q1.y, -2.0f * q1.z, dx1, dy1) : sgr_power2(q1.x, q1.y, q1.z, dx1, dy1);
-                const float G0 = EXACT ? expf(pw0) : __builtin_amdgcn_exp2f(pw0), G1 = EXACT ? expf(pw1) : __builtin_amdgcn_exp2f(pw1);
+                const float pw0 = EXACT ? sgr_power_ref_staged(q0.x, q0.y, q0.z, dx0, dy0) : sgr_power2(q0.x, q0.y, q0.z, dx0, dy0);
+                const float pw1 = EXACT ? sgr_power_ref_staged(q1.x, q1.y, q1.z, dx1, dy1) : sgr_power2(q1.x, q1.y, q1.z, dx1, dy1);
+                const float G0 = EXACT ? (SGR_EXACT_TRIM ? sgr_expf_ref(pw0) : expf(pw0)) : __builtin_amdgcn_exp2f(pw0), G1 = EXACT ? (SGR_EXACT_TRIM ? sgr_expf_ref(pw1) : expf(pw1)) : __builtin_amdgcn_exp2f(pw1);
                 const float al0 = fminf(0.99f, q0.w * G0), al1 = fminf(0.99f, q1.w * G1);
                 process(j0, q0, dx0, dy0, pw0, G0, al0, true);
                 process(j1, q1, dx1, dy1, pw1, G1, al1, true);
@@ -718,8 +732,11 @@ sgr_blend_bwd_kernel_s0(SGR_BWD_ARGS) {
     sgr_blend_bwd_body<0, CULL, DPP, DET, SgrBwdBatch<0>::value>(SGR_BWD_PASS);
 }
 // parity mode (sgr_math.h: sgr_power_ref): the shipped configuration only (cull / hit record, DPP, deterministic)
+#ifndef SGR_BWD_EXACT_WAVES
+#define SGR_BWD_EXACT_WAVES(SMAX) ((SMAX) == 0 ? 8 : SGR_BWD_WAVES(SMAX))
+#endif
 template <int SMAX>
-__global__ void __launch_bounds__(SGR_TILE_THREADS)
+__global__ void __launch_bounds__(SGR_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(SGR_BWD_EXACT_WAVES(SMAX))))
 sgr_blend_bwd_kernel_exact(SGR_BWD_ARGS) {
     sgr_blend_bwd_body<SMAX, true, true, true, SgrBwdBatch<SMAX>::value, true>(SGR_BWD_PASS);
 }

@@ -14,6 +14,9 @@
 #include "sgr_math.h"
 
 #define SGR_TILE_THREADS 256
+#ifndef SGR_EXACT_TRIM
+#define SGR_EXACT_TRIM 1  // parity mode: sgr_expf_ref instead of the library's expf (same bits, sgr_math.h)
+#endif
 
 // Register budget (tools/occupancy_audit.py).  Left alone the allocator lands a few registers past an occupancy step
 // in most instantiations -- S = 0: 65 VGPRs (the allocation granule is 8, so that is 72 and 7 waves / SIMD instead of
@@ -95,8 +98,9 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
             const float4 a = r[0];
             const float4 b = r[1];
             sA[tid] = a;
-            // EXACT (parity mode): the conic as it is -- the walk evaluates the reference's own power expression
-            sB[tid] = EXACT ? b : make_float4(-0.5f * SGR_LOG2E * b.x, -SGR_LOG2E * b.y, -0.5f * SGR_LOG2E * b.z, b.w);
+            // EXACT (parity mode): exact power-of-two scalings only -- the walk evaluates the reference's own power
+            // expression on the staged triple (sgr_power_ref_staged)
+            sB[tid] = EXACT ? make_float4(-0.5f * b.x, -b.y, -0.5f * b.z, b.w) : make_float4(-0.5f * SGR_LOG2E * b.x, -SGR_LOG2E * b.y, -0.5f * SGR_LOG2E * b.z, b.w);
             sC[tid] = r[2];
             if (SMAX > 0) {  // channels S..SMAX-1 are staged as zeros so the walk needs no per-channel test
 #pragma unroll
@@ -185,9 +189,9 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                     const int b0 = sgr_pop_lowest(m);
                     const int j0 = chunk * 64 + b0;
                     const float4 a0 = sA[j0], q0 = sB[j0];
-                    const float pw0 = EXACT ? sgr_power_ref(q0.x, q0.y, q0.z, a0.x - pxf, a0.y - pyf)
+                    const float pw0 = EXACT ? sgr_power_ref_staged(q0.x, q0.y, q0.z, a0.x - pxf, a0.y - pyf)
                                             : sgr_power2(q0.x, q0.y, q0.z, a0.x - pxf, a0.y - pyf);
-                    blend_one(j0, b0, pw0, fminf(0.99f, q0.w * (EXACT ? expf(pw0) : __builtin_amdgcn_exp2f(pw0))));
+                    blend_one(j0, b0, pw0, fminf(0.99f, q0.w * (EXACT ? (SGR_EXACT_TRIM ? sgr_expf_ref(pw0) : expf(pw0)) : __builtin_amdgcn_exp2f(pw0))));
                 }
                 while (m) {
                     // two survivors per trip: their LDS reads and exp() are independent, only the blend is ordered
@@ -196,12 +200,12 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                     const int j0 = chunk * 64 + b0, j1 = chunk * 64 + b1;
                     const float4 a0 = sA[j0], q0 = sB[j0];
                     const float4 a1 = sA[j1], q1 = sB[j1];
-                    const float pw0 = EXACT ? sgr_power_ref(q0.x, q0.y, q0.z, a0.x - pxf, a0.y - pyf)
+                    const float pw0 = EXACT ? sgr_power_ref_staged(q0.x, q0.y, q0.z, a0.x - pxf, a0.y - pyf)
                                             : sgr_power2(q0.x, q0.y, q0.z, a0.x - pxf, a0.y - pyf);
-                    const float pw1 = EXACT ? sgr_power_ref(q1.x, q1.y, q1.z, a1.x - pxf, a1.y - pyf)
+                    const float pw1 = EXACT ? sgr_power_ref_staged(q1.x, q1.y, q1.z, a1.x - pxf, a1.y - pyf)
                                             : sgr_power2(q1.x, q1.y, q1.z, a1.x - pxf, a1.y - pyf);
-                    const float al0 = fminf(0.99f, q0.w * (EXACT ? expf(pw0) : __builtin_amdgcn_exp2f(pw0)));
-                    const float al1 = fminf(0.99f, q1.w * (EXACT ? expf(pw1) : __builtin_amdgcn_exp2f(pw1)));
+                    const float al0 = fminf(0.99f, q0.w * (EXACT ? (SGR_EXACT_TRIM ? sgr_expf_ref(pw0) : expf(pw0)) : __builtin_amdgcn_exp2f(pw0)));
+                    const float al1 = fminf(0.99f, q1.w * (EXACT ? (SGR_EXACT_TRIM ? sgr_expf_ref(pw1) : expf(pw1)) : __builtin_amdgcn_exp2f(pw1)));
                     blend_one(j0, b0, pw0, al0);
                     blend_one(j1, b1, pw1, al1);  // if the wave finished on j0 every lane's threshold is +inf: a no-op
                 }

@@ -297,6 +297,62 @@ SGR_HD float sgr_power_ref(float cx, float cy, float cz, float dx, float dy) {
 #pragma clang fp contract(off)
     return -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
 }
+// The same value from a conic staged as hx = -0.5*cx, ny = -cy, hz = -0.5*cz: scaling by -0.5 and negation commute with
+// every rounding of the expression above (powers of two; the operands are far from the subnormal range), so
+//   RN(RN(hx*dx)*dx) = -0.5*RN(RN(cx*dx)*dx),  RN(A' + B') = -0.5*RN(A + B),  X - RN(RN(cy*dx)*dy) = X + RN(RN(ny*dx)*dy)
+// bit for bit -- 8 instead of 9 VALU instructions, and the staged triple is the one the backward's gradient terms use.
+// tests/test_host_math.py holds the identity against sgr_power_ref.
+SGR_HD float sgr_power_ref_staged(float hx, float ny, float hz, float dx, float dy) {
+#pragma clang fp contract(off)
+    return (hx * dx * dx + hz * dy * dy) + ny * dx * dy;
+}
+
+// ---- parity-mode elementary functions ------------------------------------------------------------------------------
+// expf as the device library evaluates it on gfx950 (ocml expF / LLVM's f32 exp lowering, read off the ISA hipcc emits
+// for `expf`: ph = x*c, pl = fma(x, cc, fma(x, c, -ph)), e = rint(ph), v_exp_f32(ph - e + pl), ldexp by e), operation by
+// operation -- WITHOUT its two range selects (x < -103.28 -> 0, x > 88.72 -> inf: two v_cmp + two v_cndmask + the wait
+// states between them, 6 issue slots of 15).  The blend kernels never use G for a positive power, and for very negative
+// arguments ldexp underflows to the same 0 on its own as long as `e` is finite; one v_max on ph keeps it finite (for
+// ph >= -200 the clamp is the identity, below it pl absorbs the difference and the result is 0 either way; a NaN
+// argument still gives NaN through pl).  Bit-identical to expf for every x <= 88.72 incl. -inf and NaN
+// (sgr_test_exact_math, tests/test_gpu_primitives.py).
+SGR_HD float sgr_expf_ref(float x) {
+#pragma clang fp contract(off)
+    const float c = 0x1.715476p+0f, cc = 0x1.4ae0bep-26f;  // c + cc = 49 bits of log2(e)
+    const float ph = fmaxf(x * c, -200.0f);
+    const float pl = fmaf(x, cc, fmaf(x, c, -ph));
+    const float e = __builtin_rintf(ph);
+    const float a = (ph - e) + pl;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(a), (int)e);
+#else
+    return ldexpf(exp2f(a), (int)e);
+#endif
+}
+
+// a / b and a2 / b as hipcc's IEEE-754 expansion of `/` computes them (v_div_scale, v_rcp_f32, a Newton step on the
+// reciprocal, two residual corrections of the quotient, v_div_fmas, v_div_fixup: 11 instructions per quotient), for
+// operands that need neither scaling nor fix-up -- every (T, 1 - alpha) and (T_final, 1 - alpha) of the blend backward:
+// 0 <= a <= 1, 0.01 <= b <= 1 -- where v_div_scale / v_div_fmas / v_div_fixup are the identity.  The refined reciprocal
+// is shared between the two quotients: 3 + 5 + 5 instead of 22 instructions, same bits (sgr_test_exact_math sweeps the
+// operand ranges against `/` on the GPU; tests/test_host_math.py shows that the result does not depend on the last
+// bit of the v_rcp_f32 seed).
+struct SgrRcp { float b, y; };
+SGR_HD SgrRcp sgr_rcp_refined(float b) {
+#pragma clang fp contract(off)
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float y0 = __builtin_amdgcn_rcpf(b);
+#else
+    const float y0 = 1.0f / b;
+#endif
+    return SgrRcp{b, fmaf(fmaf(-b, y0, 1.0f), y0, y0)};
+}
+SGR_HD float sgr_div_by(float a, float b, float y) {  // y = refined reciprocal of b
+#pragma clang fp contract(off)
+    float q = a * y;
+    q = fmaf(fmaf(-b, q, a), y, q);
+    return fmaf(fmaf(-b, q, a), y, q);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Per-Gaussian backward maths (float tolerance only, so contraction is left to the compiler).

@@ -152,3 +152,68 @@ def oracle_backward_same_state(oracle, fw, res, wts, S, parallel=False):
                                parallel=parallel)
     finally:
         fw.alpha = own
+
+
+def strict_gate(a, b, name="", rel=1e-4, abs_frac=2e-6, allow=0):
+    """north_star's own gate, |a-b| <= 1e-4*max(|a|,|b|) + 2e-6*max|b| with NO element outside (`allow` = the measured,
+    documented exceptions of a case); logs what was measured.  Returns the number of elements outside."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    if a.size == 0:
+        return 0
+    assert np.isfinite(a).all(), f"{name}: non-finite values"
+    scale = max(np.abs(b).max(), 1e-30)
+    err = np.abs(a - b)
+    bad = err > rel * np.maximum(np.abs(a), np.abs(b)) + abs_frac * scale
+    nbad = int(bad.sum())
+    _log(dict(kind="strict", name=name, n=int(a.size), rel=rel, abs_frac=abs_frac, outside=nbad,
+              worst_abs_over_scale=float(err.max() / scale)))
+    assert nbad <= allow, f"{name}: {nbad}/{a.size} outside rel {rel} + {abs_frac}*scale (worst {err.max() / scale:.3g} of the scale)"
+    return nbad
+
+
+GRAD_NAMES = ["means2D", "colors", "opacity", "means3D", "cov3D", "sh", "scales", "rotations", "semantics"]
+
+
+def exact_mode_against_reference_kernels(kw, wts, S, label, rf=None, gref=None, allow=None, color_rel=1e-4):
+    """The library in its parity mode (sgr_test_switches bit 7, SGR_EXACT=1) against the reference's OWN kernels
+    (oracle/_ref, strict build), END TO END, each side on its own forward, held to north_star's statement itself:
+    every integer output identical; alpha / depth / semantic images and n_contrib bit-identical; the colour image within
+    rel 1e-4 with no outlier; all nine gradient tensors within rel 1e-4 + 2e-6 of the tensor's scale with NO element
+    outside (`allow`: {tensor: count}, the documented exceptions of a case).  `rf` / `gref`: the reference's forward
+    state and gradients when the caller already has them (or a dict of golden arrays).  Returns (res, g)."""
+    own = rf is None
+    if own:
+        from oracle import ref
+        rf = ref.forward(**kw)
+        gref = ref.backward(rf, wts["color"], wts["depth"], wts["alpha"], wts["semantic"] if S else None)
+    with switches(_C.test_switches(-1) | _C.EXACT):
+        res, internal = raw_forward(kw)
+        g = raw_backward(kw, res, wts)
+        torch.cuda.synchronize()
+    golden = isinstance(rf, dict)
+    get = (lambda k: np.asarray(rf[k])) if golden else (lambda k: npy(getattr(rf, k)))
+    R = int(rf["num_rendered"]) if golden else rf.num_rendered
+    assert res["R"] == R, label
+    assert (npy(res["radii"]) == get("radii")).all(), label
+    if R:
+        pl = np.asarray(rf["point_list"]) if golden else npy(rf.internal("point_list")).view(np.uint32)
+        assert (npy(internal("point_list")).view(np.uint32) == pl).all(), label
+        if not golden:
+            assert (npy(internal("keys")).view(np.uint64) == npy(rf.internal("keys")).view(np.uint64)).all(), label
+    rg = np.asarray(rf["ranges"]) if golden else npy(rf.internal("ranges")).view(np.uint32)
+    assert (npy(internal("ranges")).view(np.uint32).reshape(-1) == rg.reshape(-1)).all(), label
+    for k in ["alpha", "depth"] + (["semantic"] if S else []):
+        assert np.array_equal(npy(res[k]).reshape(-1), get(k).reshape(-1)), f"{label}: {k} image not bit-identical"
+    if not golden:
+        assert torch.equal(internal("n_contrib").view(torch.int32).reshape(-1), rf.internal("n_contrib").reshape(-1)), label
+    image_close(npy(res["color"]).reshape(-1), get("color").reshape(-1), rel=color_rel, name=f"exact {label}: color", max_outliers=0)
+    for k in GRAD_NAMES:
+        if k == "semantics" and not S:
+            continue
+        want = np.asarray(gref["g_" + k]) if golden else npy(gref[k])
+        strict_gate(npy(g[k]).reshape(-1), want.reshape(-1), name=f"exact {label}: {k}", allow=(allow or {}).get(k, 0))
+    if own:
+        rf.free()
+    return res, g

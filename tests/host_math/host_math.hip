@@ -97,4 +97,19 @@ void hm_quadrant_masks(int n, const float* means2D, const float* conic_opacity, 
 }
 
 float hm_power2(float qa, float qb, float qc, float dx, float dy) { return sgr_power2(qa, qb, qc, dx, dy); }
+// parity mode: the staged power expression against the reference's own, and the shared-reciprocal quotient for a given
+// reciprocal seed (the test perturbs the seed by an ulp either way: the device's v_rcp_f32 is only accurate to 1 ulp)
+void hm_power_ref_pair(int n, const float* c, const float* d, float* ref, float* staged) {
+    for (int i = 0; i < n; i++) {
+        ref[i] = sgr_power_ref(c[3 * i], c[3 * i + 1], c[3 * i + 2], d[2 * i], d[2 * i + 1]);
+        staged[i] = sgr_power_ref_staged(-0.5f * c[3 * i], -c[3 * i + 1], -0.5f * c[3 * i + 2], d[2 * i], d[2 * i + 1]);
+    }
+}
+void hm_div_by_seed(int n, const float* a, const float* b, const float* seed, float* q) {
+    for (int i = 0; i < n; i++) {
+        const float y0 = seed[i];
+        const float y = fmaf(fmaf(-b[i], y0, 1.0f), y0, y0);
+        q[i] = sgr_div_by(a[i], b[i], y);
+    }
+}
 }

@@ -183,7 +183,13 @@ def _outside(a, b, rel, abs_frac):
     return dict(n=int(a.size), outside=int(bad.sum()), worst_abs_over_scale=float(err.max() / scale))
 
 
-@pytest.mark.parametrize("name,P,S", [("headline_1M", 1_000_000, 0), ("configs2_2M_S19", 2_000_000, 19)])
+# Parity mode (sgr_test_switches bit 7): documented exceptions of "no element outside rel 1e-4 + 2e-6 of the scale",
+# {config: {tensor: count}} -- empty: none measured (profiles/r4/threeway_fullsize.json)
+EXACT_ALLOW = {}
+
+
+@pytest.mark.parametrize("name,P,S", [("configs1_500k", 500_000, 0), ("headline_1M", 1_000_000, 0),
+                                      ("configs2_2M_S19", 2_000_000, 19), ("configs4_5M", 5_000_000, 0)])
 def test_threeway_against_reference_kernels_at_baseline_size(name, P, S):
     from oracle import ref
     if not ref.available():
@@ -290,10 +296,14 @@ def test_threeway_against_reference_kernels_at_baseline_size(name, P, S):
     for k, st in rec["images"].items():
         assert st["hip_vs_ref"]["outside_frac"] <= IMG_FLIP_FRAC, (k, st)
         assert st["hip_vs_ref"]["worst_abs_over_scale"] <= IMG_FLIP_CAP, (k, st)
-    # parity mode: alpha_out (hence T_final) is the strict build's, bit for bit; its gradients sit next to the C oracle's
-    assert rec["images"]["alpha"]["hip_exact_bit_identical"], rec["images"]["alpha"]
+    # parity mode, north_star's statement itself, END TO END at this BASELINE size: alpha_out (hence T_final), depth and the
+    # semantic image are the strict build's bit for bit, colour within rel 1e-4 without an outlier, and NO gradient element
+    # outside rel 1e-4 + 2e-6 of its tensor's scale
+    for k in ["alpha", "depth"] + (["semantic"] if S else []):
+        assert rec["images"][k]["hip_exact_bit_identical"], (k, rec["images"][k])
+    assert rec["images"]["color"]["hip_exact_vs_ref"]["outside"] == 0, rec["images"]["color"]
     for k, st in rec["grads"].items():
-        assert st["hip_exact_vs_ref"]["outside"] <= 1.5 * st["oracle_vs_ref"]["outside"] + 2e-5 * st["hip_vs_ref"]["n"] + 8, (k, st)
+        assert st["hip_exact_vs_ref"]["outside"] <= EXACT_ALLOW.get(name, {}).get(k, 0), ("parity mode", k, st["hip_exact_vs_ref"])
     for k, st in rec["grads"].items():
         n = st["hip_vs_ref"]["n"]
         # yardstick: how far two VALID builds of the reference's own sources are from each other (contraction off vs the

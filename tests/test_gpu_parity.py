@@ -14,8 +14,8 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_utils import (dev, grad_close, image_close, npy, oracle_backward_same_state, raw_backward, raw_forward, settings,
-                       switches)
+from gpu_utils import (dev, exact_mode_against_reference_kernels, grad_close, image_close, npy,
+                       oracle_backward_same_state, raw_backward, raw_forward, settings, strict_gate, switches)
 from street_gaussians_amd import _C
 from helpers import oracle_kwargs, small_case
 from oracle import oracle
@@ -153,6 +153,27 @@ def _color_mag(fw, wts):
     return {"colors": gabs["colors"], "sh": np.abs(gabs["sh"]) + gabs["colors"][:, None, :] * 0.3}
 
 
+# documented exceptions of the strict gate in parity mode (elements outside rel 1e-4 + 2e-6 of the scale), per case
+EXACT_ALLOW = {}
+
+
+@pytest.mark.parametrize("name", [n for n in CASES if n not in ILL_CONDITIONED])
+def test_exact_mode_cases_against_reference_kernels(name):
+    """Every case of this file in the parity mode (sgr_test_switches bit 7) against the reference's own kernels, end to
+    end, each side on its own forward: integer outputs identical, alpha / depth / semantic / n_contrib bit-identical, colour
+    within rel 1e-4 without an outlier, all gradients inside rel 1e-4 + 2e-6 of the scale without an element outside."""
+    _ref()
+    cam, sc, kw = _kw(name)
+    S = sc.semantics.shape[1]
+    wts = syn.loss_weights(cam, S=S)
+    res, g = exact_mode_against_reference_kernels(kw, wts, S, name, allow=EXACT_ALLOW.get(name))
+    # parity mode is as deterministic as the default one
+    with switches(_C.EXACT):
+        g2 = raw_backward(kw, res, wts)
+    for k in g:
+        assert torch.equal(g[k], g2[k]), f"exact mode: {k} not deterministic"
+
+
 @pytest.mark.parametrize("name", ["mid_20k_sem3", "huge_splats", "sem19_deg1", "giant_degenerate"])
 def test_culling_is_invisible_and_backward_is_deterministic(name):
     """The ballot cull may only skip pairs that fail the alpha test: images must be BIT-identical with the cull
@@ -207,14 +228,20 @@ def test_culling_is_invisible_and_backward_is_deterministic(name):
         grad_close(npy(g_a[k]), npy(g_d[k]), rel=1e-4, abs_frac=2e-5, name=f"v2:{k}", max_outlier_frac=0.0)
 
 
+@pytest.mark.parametrize("mode", ["default", "exact"])
 @pytest.mark.parametrize("P,S,scale_px", [(1, 0, 0.8), (2, 20, 0.3), (65, 1, 0.05), (129, 7, 0.02)])
-def test_edge_sizes(P, S, scale_px):
+def test_edge_sizes(P, S, scale_px, mode):
     """Ragged sizes: fewer Gaussians than a wave, one Gaussian covering the whole tile grid (a single owner of every
-    slot in the cooperative duplicate kernel), the reference's maximum number of semantic channels (NUM_CLASSES = 20, config.h:16), P just past a wave boundary."""
+    slot in the cooperative duplicate kernel), the reference's maximum number of semantic channels (NUM_CLASSES = 20, config.h:16), P just past a wave boundary.
+    mode "exact": the parity mode against the reference's own kernels, north_star's gate itself, end to end."""
     cam = syn.make_camera(200, 120, fx=150.0)
     sc = syn.make_scene(P, cam, S=S, seed=20 + P, scale_px=scale_px, zmin=2.0, zmax=4.0, margin=0.5)
     kw = oracle_kwargs(cam, sc, deg=3)
     wts = syn.loss_weights(cam, S=S)
+    if mode == "exact":
+        _ref()
+        exact_mode_against_reference_kernels(kw, wts, S, f"edge{P}")
+        return
     fw = oracle.forward(**kw)
     ref = oracle.backward(fw, wts["color"], wts["depth"], wts["alpha"], wts["semantic"] if S else None)
     res, internal = raw_forward(kw)
@@ -274,10 +301,12 @@ def test_side_stream_varying_sizes_and_repeated_backward():
     torch.cuda.current_stream().wait_stream(side)
 
 
+@pytest.mark.parametrize("mode", ["default", "exact"])
 @pytest.mark.parametrize("seed", range(8))
-def test_random_scenes_against_oracle(seed):
+def test_random_scenes_against_oracle(seed, mode):
     """Randomised sweep: odd image sizes, yawed cameras, off-screen margins, scale modifiers, backgrounds, SH degrees
-    and semantic widths drawn from the seed; integer outputs bit-exact, images and gradients within tolerance."""
+    and semantic widths drawn from the seed; integer outputs bit-exact, images and gradients within tolerance.
+    mode "exact": the parity mode against the reference's own kernels, north_star's gate itself, end to end."""
     rng = np.random.default_rng(1000 + seed)
     W, H = int(rng.integers(17, 400)), int(rng.integers(17, 300))
     cam = syn.make_camera(W, H, fx=float(rng.uniform(0.4, 1.6)) * W, yaw_deg=float(rng.uniform(-8, 8)))
@@ -289,6 +318,10 @@ def test_random_scenes_against_oracle(seed):
     kw = oracle_kwargs(cam, sc, deg=deg, bg=torch.tensor(rng.uniform(0, 1, 3), dtype=torch.float32))
     kw["scale_modifier"] = float(rng.choice([1.0, 0.7, 1.3]))
     wts = syn.loss_weights(cam, S=S, seed=seed)
+    if mode == "exact":
+        _ref()
+        exact_mode_against_reference_kernels(kw, wts, S, f"rand{seed}")
+        return
     fw = oracle.forward(**kw)
     ref = oracle.backward(fw, wts["color"], wts["depth"], wts["alpha"], wts["semantic"] if S else None)
     res, internal = raw_forward(kw)
@@ -567,12 +600,17 @@ def test_knn_against_reference_kernels():
 
 # ---------------------------------------------------------------------------------------------------
 # golden fixtures generated from the reference kernels on the MI355X box (tests/golden/make_golden.py)
+@pytest.mark.parametrize("mode", ["default", "exact"])
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(HERE, "golden", "*.npz"))) or [None])
-def test_golden_fixture(path):
+def test_golden_fixture(path, mode):
     if path is None:
         pytest.skip("no golden fixtures committed yet")
     from golden.make_golden import load_case
     kw, wts, gold = load_case(path)
+    if mode == "exact":  # the committed outputs of the reference's kernels: bit-identical images, the north-star gate itself
+        S = int(gold["semantics"].shape[1])
+        exact_mode_against_reference_kernels(kw, wts, S, "golden " + os.path.basename(path), rf=gold, gref=gold)
+        return
     res, internal = raw_forward(kw)
     assert res["R"] == int(gold["num_rendered"])
     assert (npy(res["radii"]) == gold["radii"]).all()
@@ -748,7 +786,6 @@ def test_exact_parity_mode_is_bit_faithful_to_the_reference_kernels(S):
     for k in GRAD_KEYS:
         if k == "semantics" and not S:
             continue
-        grad_close(npy(g[k]).reshape(-1), npy(gref[names[k]]).reshape(-1), name=f"exact end-to-end {k} vs ref", rel=1e-4,
-                   abs_frac=2e-6, max_outlier_frac=1e-4)  # dL/drot, dL/dscale: the per-Gaussian stage is compiled with contraction
+        strict_gate(npy(g[k]).reshape(-1), npy(gref[names[k]]).reshape(-1), name=f"exact end-to-end {k} vs ref")
     rf.free()
     fw.free()

@@ -122,3 +122,40 @@ def test_wave_sum_dpp_equals_shuffle():
     ref = x.reshape(nw, 64).sum(1).numpy()
     assert (a.cpu().numpy() == ref).all()
     assert (b.cpu().numpy() == ref).all()
+
+
+def test_parity_mode_elementary_functions_have_the_bits_of_expf_and_division():
+    """SGR_EXACT mode runs expf and T / (1 - alpha) written out without their range handling (sgr_math.h: sgr_expf_ref,
+    sgr_div_by).  They must have the bits of the device library's expf and of hipcc's IEEE `/`: dense sweeps of the operand
+    ranges the blend kernels produce, plus the special arguments the shortened expf still has to get right."""
+    L, check = _lib()
+    n = 1 << 24
+    g = torch.Generator().manual_seed(5)
+    # expf: every power the kernels can form -- (-inf, 0] densely around the range where alpha >= 1/255 is possible
+    # (x >= -5.6), the whole underflow region, huge negative arguments, positive ones up to the overflow select, NaN
+    x = torch.cat([-8.0 * torch.rand(n // 2, generator=g), -120.0 * torch.rand(n // 4, generator=g),
+                   -torch.exp(88.0 * torch.rand(n // 8, generator=g)), 88.7 * torch.rand(n // 8 - 16, generator=g),
+                   torch.tensor([0.0, -0.0, -float("inf"), float("nan"), -1e38, -3.4e38, -87.3, -88.0, -103.2, -103.3,
+                                 -104.0, -126.0, -149.0, -150.0, -1e-45, -1e-38])]).float()
+    assert x.numel() == n
+    # quotients: numerator T or T_final in [0, 1], denominator 1 - alpha in [0.01, 1 - 1/255] (alpha = min(0.99, .) >= 1/255)
+    # (numerators are 0 or >= 2^-24: T_final = 1 - alpha_out with alpha_out <= 1; a subnormal one would need v_div_scale)
+    a = torch.cat([torch.rand(n // 2, generator=g), 1e-4 * torch.rand(n // 4, generator=g),
+                   torch.clamp(torch.rand(n // 4, generator=g) ** 8, min=2.0 ** -24)]).float()
+    a[:4] = torch.tensor([0.0, 1.0, 1e-4, 2.0 ** -24])
+    b = (0.01 + (1.0 - 1.0 / 255.0 - 0.01) * torch.rand(n, generator=g)).float()
+    b[:n // 16] = 1.0 - torch.clamp(torch.rand(n // 16, generator=g) * 0.99, min=1.0 / 255.0)  # as the kernel forms it
+    xd, ad, bd = x.cuda(), a.cuda(), b.cuda()
+    outs = [torch.empty(n, device="cuda") for _ in range(4)]
+    check(L.sgr_test_exact_math(n, _vp(xd), _vp(outs[0]), _vp(outs[1]), _vp(ad), _vp(bd), _vp(outs[2]), _vp(outs[3]), None))
+    torch.cuda.synchronize()
+    e_lib, e_ref, d_lib, d_ref = (o.cpu().view(torch.int32) for o in outs)
+    nan = torch.isnan(x)
+    assert torch.isnan(outs[1].cpu()[nan]).all()
+    bad = (e_lib != e_ref) & ~nan
+    assert not bad.any(), f"expf: {int(bad.sum())} of {n} differ, first at x = {x[bad][:5].tolist()}"
+    bad = d_lib != d_ref
+    assert not bad.any(), f"division: {int(bad.sum())} of {n} differ, first at {a[bad][:5].tolist()} / {b[bad][:5].tolist()}"
+    # and the quotient really is the correctly rounded one
+    q64 = (a.double() / b.double()).float()
+    assert (outs[3].cpu() == q64).all()

@@ -138,3 +138,28 @@ def test_power2_matches_reference_expression(hm):
         qa, qb, qc = np.float32(-0.5) * LOG2E * np.float32(A), -LOG2E * np.float32(B), np.float32(-0.5) * LOG2E * np.float32(C_)
         got = hm.hm_power2(C.c_float(qa), C.c_float(qb), C.c_float(qc), C.c_float(dx), C.c_float(dy))
         assert abs(got - ref) <= 2e-6 * max(1.0, A * dx * dx + C_ * dy * dy + abs(B * dx * dy))
+
+
+def test_parity_mode_staged_power_and_quotient_identities(hm):
+    """SGR_EXACT mode stages the conic as (-0.5 cx, -cy, -0.5 cz) and forms T / (1 - alpha) from a refined reciprocal:
+    the staged power must have the bits of the reference's expression (forward.cu:420), and the quotient must be the
+    correctly rounded one whatever the last bit of the reciprocal seed is (v_rcp_f32 is accurate to 1 ulp; the GPU test
+    sgr_test_exact_math compares against hipcc's own `/`)."""
+    rng = np.random.default_rng(3)
+    n = 2_000_000
+    c = np.stack([np.exp(rng.uniform(-9, 2, n)), rng.normal(0, 0.3, n) * np.exp(rng.uniform(-9, 1, n)),
+                  np.exp(rng.uniform(-9, 2, n))], 1).astype(np.float32)
+    d = rng.uniform(-40, 40, (n, 2)).astype(np.float32)
+    ref, staged = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    hm.hm_power_ref_pair(n, _p(c), _p(d), _p(ref), _p(staged))
+    assert (ref.view(np.int32) == staged.view(np.int32)).all()
+    # numerators: T and T_final = 1 - alpha_out, i.e. 0 or >= 2^-24 (a subnormal numerator would need v_div_scale)
+    a = np.concatenate([rng.uniform(0, 1, n // 2), np.maximum(rng.uniform(0, 1, n // 2) ** 8, 2.0 ** -24)]).astype(np.float32)
+    a[:3] = [0.0, 1.0, 2.0 ** -24]
+    b = rng.uniform(0.01, 1 - 1 / 255, n).astype(np.float32)
+    want = (a.astype(np.float64) / b.astype(np.float64)).astype(np.float32)
+    y = (np.float32(1) / b).astype(np.float32)
+    for seed in (y, np.nextafter(y, np.float32(2)), np.nextafter(y, np.float32(0))):
+        q = np.zeros(n, np.float32)
+        hm.hm_div_by_seed(n, _p(a), _p(b), _p(np.ascontiguousarray(seed, dtype=np.float32)), _p(q))
+        assert (q == want).all(), int((q != want).sum())
