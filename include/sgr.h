@@ -100,6 +100,9 @@ typedef struct sgr_backward_extras {
     float* max_radii2D;        /* [P]   */
     const sgr_stat_segment* segments; /* host memory; NULL = identity map over the call's P Gaussians */
     int n_segments;
+    int rows; /* length of the three persistent arrays (rows); with segments every [dst_offset, dst_offset + count) must lie
+               * inside [0, rows) and the destination ranges must be pairwise disjoint (two segments on the same rows would be
+               * a racy read-modify-write) -- checked on the host, SGR_E_INVALID otherwise.  0 = unknown: not checked. */
 } sgr_backward_extras;
 int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, int width, int height,
                     const float* means3D, const float* shs, const float* colors_precomp, const float* semantics,

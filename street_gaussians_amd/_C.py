@@ -70,7 +70,7 @@ class _StatSegment(C.Structure):  # sgr_stat_segment (include/sgr.h)
 
 class _BackwardExtras(C.Structure):  # sgr_backward_extras (include/sgr.h)
     _fields_ = [("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p), ("max_radii2D", C.c_void_p),
-                ("segments", C.POINTER(_StatSegment)), ("n_segments", C.c_int)]
+                ("segments", C.POINTER(_StatSegment)), ("n_segments", C.c_int), ("rows", C.c_int)]
 
 
 MAX_STAT_SEGMENTS = 128  # SGR_MAX_STAT_SEGMENTS
@@ -224,7 +224,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                         raise SgrError("statistics segment outside the persistent tensors")
                     seg_arr[k] = _StatSegment(int(s0), int(cnt), int(d0))
                 keep.append(seg_arr)
-            extras = _BackwardExtras(acc.data_ptr(), den.data_ptr(), mr.data_ptr(), seg_arr, nseg)
+            extras = _BackwardExtras(acc.data_ptr(), den.data_ptr(), mr.data_ptr(), seg_arr, nseg, int(rows))
         check(_native.lib().sgr_backward_ex(
             P, int(degree), M, int(R), S, p(background, "bg"), W, H, p(means3D, "means3D"), p(sh, "sh"),
             p(colors, "colors_precomp"), p(semantics, "semantics"), p(alphas, "alpha"), p(scales, "scales"),

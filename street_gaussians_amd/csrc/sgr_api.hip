@@ -10,6 +10,7 @@
 #include <chrono>
 #include <mutex>
 #include <string>
+#include <thread>
 
 #include "../../include/sgr.h"
 #include "sgr_math.h"
@@ -148,7 +149,8 @@ int sgr_set_error(int code, const std::string& msg) { return fail(code, msg); } 
 // per-thread pinned landing zone for the forward's one device->host readback
 static uint32_t* pinned_pair() {
     static thread_local uint32_t* p = nullptr;
-    if (!p && hipHostMalloc((void**)&p, 64, hipHostMallocPortable) != hipSuccess) p = nullptr;
+    // coherent (uncached on the device side): the host watches these words while the copy is in flight
+    if (!p && hipHostMalloc((void**)&p, 64, hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess) p = nullptr;
     return p;
 }
 // ... and the event that marks "the readback has landed" while later kernels are already queued behind it
@@ -164,11 +166,12 @@ static hipEvent_t readback_event() {
 // back is a property of the host (tens of microseconds on some boxes) -- time in which the GPU works off the ~0.12 ms of
 // depth sort + scan queued behind the read-back and then idles until the rest of the forward is queued.  So the thread
 // watches the pinned landing zone itself: both words were set to a value the device never writes (flag is 0 / 1,
-// num_rendered < 2^31).  Bounded: after SGR_SPIN_US microseconds (default 50 ms; 0 = never spin) it falls back to the
+// num_rendered < 2^31).  Bounded: after SGR_SPIN_US microseconds (default 2 ms -- the copy lands within ~0.2 ms of being
+// queued; 0 = never spin) it falls back to the
 // event, which is also what orders everything else behind the copy.
 #define SGR_READBACK_PENDING 0xffffffffu
 static hipError_t wait_for_readback(uint32_t* host_vals, hipEvent_t landed) {
-    static const long spin_us = [] { const char* e = getenv("SGR_SPIN_US"); return e ? atol(e) : 50000L; }();
+    static const long spin_us = [] { const char* e = getenv("SGR_SPIN_US"); return e ? atol(e) : 2000L; }();
     if (spin_us > 0) {
         volatile uint32_t* hv = host_vals;
         const auto t0 = std::chrono::steady_clock::now();
@@ -178,7 +181,11 @@ static hipError_t wait_for_readback(uint32_t* host_vals, hipEvent_t landed) {
                     std::atomic_thread_fence(std::memory_order_acquire);
                     return hipSuccess;
                 }
+#if defined(__x86_64__) || defined(__i386__)
                 __builtin_ia32_pause();
+#else
+                std::this_thread::yield();
+#endif
             }
             if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us)
                 break;
@@ -475,6 +482,17 @@ int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, 
                 sink.start[i] = sg.src_start;
                 sink.count[i] = sg.count;
                 sink.shift[i] = sg.dst_offset - sg.src_start;
+            }
+            // destinations: inside the persistent arrays and pairwise disjoint (n <= 128: the quadratic check is nothing)
+            for (int i = 0; i < n; i++) {
+                const sgr_stat_segment& a = extras->segments[i];
+                if (extras->rows > 0 && (long)a.dst_offset + a.count > (long)extras->rows)
+                    return fail(SGR_E_INVALID, "statistics sink: a segment's destination lies outside the persistent arrays");
+                for (int j = 0; j < i; j++) {
+                    const sgr_stat_segment& b = extras->segments[j];
+                    if (a.count > 0 && b.count > 0 && a.dst_offset < b.dst_offset + b.count && b.dst_offset < a.dst_offset + a.count)
+                        return fail(SGR_E_INVALID, "statistics sink: two segments write the same persistent rows");
+                }
             }
             sink.nseg = n;
             if (n == 0) sink.accum = sink.denom = sink.max_radii = nullptr;  // nothing of this frame is tracked

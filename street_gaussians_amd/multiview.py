@@ -213,6 +213,9 @@ class FactoredGradReducer:
             if shs is None or means3D is None:
                 raise ValueError("give (shs, means3D) or segments")
             parts = list(shs) if isinstance(shs, (tuple, list)) else [shs]
+            if len(parts) > 2:
+                raise ValueError("shs is one [P, M, 3] parameter or the reference's pair (features_dc, features_rest); "
+                                 f"got {len(parts)} parts (extra parts would silently get no gradient)")
             if len(parts) == 1:  # one [P, M, 3] parameter: its gradient is the rebuilt tensor as a whole
                 self._single = parts[0]
                 segments = [SHSegment(parts[0][:, :1, :], parts[0][:, 1:, :] if parts[0].shape[1] > 1 else None, means3D)]
@@ -226,6 +229,15 @@ class FactoredGradReducer:
             if not sg.posed and sg.fourier_dim != 1:
                 raise ValueError("a static segment has one DC row (features_dc [n, 1, 3])")
         self.M = 1 + (int(self.segments[0].features_rest.shape[1]) if self.segments[0].features_rest is not None else 0)
+        for i, sg in enumerate(self.segments):  # one rebuild kernel, one row width: every segment must have the same layout
+            dc, rest = sg.features_dc, sg.features_rest
+            if dc.dim() != 3 or dc.shape[2] != 3:
+                raise ValueError(f"segment {i}: features_dc must be [n, C, 3], got {tuple(dc.shape)}")
+            m_i = 1 + (int(rest.shape[1]) if rest is not None else 0)
+            if m_i != self.M:
+                raise ValueError(f"segment {i} has {m_i} SH coefficients, segment 0 has {self.M}: all segments must share M")
+            if rest is not None and (rest.dim() != 3 or rest.shape[0] != dc.shape[0] or rest.shape[2] != 3):
+                raise ValueError(f"segment {i}: features_rest must be [n, M-1, 3] with the same n as features_dc")
         first = self.segments[0].features_dc
         self.group, self.force = group, force
         self.k = int(views_per_rank)
@@ -273,7 +285,18 @@ class FactoredGradReducer:
         in rasterization order (the reference's per-frame graph_obj_list, street_gaussian_model.py:230-250), and for
         posed segments with fourier_dim > 1 their Fourier mix of this frame, ``idft[i]`` = [fourier_dim]
         (gaussian_model_actor.py:71-80: features_dc is mixed over its fourier dimension by the frame's IDFT row)."""
-        self._frame = ([int(m) for m in models], dict(idft or {}))
+        models = [int(m) for m in models]
+        for m in models:
+            if not 0 <= m < len(self.segments):
+                raise ValueError(f"set_frame: segment index {m} out of range (have {len(self.segments)})")
+        if len(set(models)) != len(models):
+            raise ValueError("set_frame: a segment is rendered at most once per frame")
+        self._frame = (models, dict(idft or {}))
+
+    @property
+    def frame_num_points(self) -> int:
+        """Gaussians of the declared frame: what the next rasterizer backward over this reducer's set must report."""
+        return sum(self.segments[m].n for m in self._frame[0])
 
     # -- rasterizer backward hook --
     def _observe(self, grad_colors, geomBuffer, campos, sh_degree, num_points, means3D=None):

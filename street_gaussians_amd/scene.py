@@ -232,6 +232,12 @@ class FlatScene:
             for k in _FLAT:
                 t = getattr(s, k)
                 if t is None:
+                    # row-wise attributes share ONE cumulative row offset (views(), the kernel pointers): a segment
+                    # without one of them would shift every later segment's block.  Only `semantic` has its own offset
+                    # (sem_width may be 0).
+                    if k != "semantic":
+                        raise ValueError(f"FlatScene: segment {len(meta) - 1} has no `{k}`; every segment must carry "
+                                         "xyz, rotation, scaling, opacity, features_dc and features_rest")
                     continue
                 t = t.detach().float()
                 parts[k].append(t.reshape(-1) if k in ("features_dc", "semantic") else t.reshape(n, -1))
@@ -241,6 +247,10 @@ class FlatScene:
         for k in _FLAT:
             t = torch.cat(parts[k], 0).contiguous() if parts[k] else torch.zeros(0, device=dev)
             tensors[k] = t.requires_grad_(requires_grad)
+        n_actors = sum(1 for m in meta if m["kind"] == SEG_ACTOR)
+        if len(poses) != n_actors:
+            raise ValueError(f"FlatScene: {n_actors} actor segments but {len(poses)} poses (every actor needs its "
+                             "[7] pose: obj_rot wxyz + obj_trans)")
         P = torch.stack(poses).contiguous().requires_grad_(requires_grad) if poses else None
         return cls(meta, tensors, P)
 
@@ -280,6 +290,9 @@ class FlatScene:
         bool [n] mask per segment or None (training-time symmetry flips, :270-283)."""
         fm = list(flip_masks) if flip_masks is not None else [None] * len(self.meta)
         P = self.poses if poses is None else poses
+        n_actors = sum(1 for m in self.meta if m["kind"] == SEG_ACTOR)
+        if n_actors and (P is None or P.shape[0] != n_actors):
+            raise ValueError(f"FlatScene.compose: {n_actors} actor segments need a [{n_actors}, 7] pose tensor")
         if P is not None and (P.dtype != torch.float32 or not P.is_contiguous()):
             P = P.float().contiguous()
         ids = None
@@ -431,6 +444,9 @@ class FlatStats:
         in general a subset / re-ordering of the persistent models.  None = every model, in order (a static graph)."""
         if models is None:
             return self.xyz_gradient_accum, self.denom, self.max_radii2D
+        models = [int(m) for m in models]
+        if len(set(models)) != len(models):  # two segments on the same persistent rows: a racy read-modify-write
+            raise ValueError("FlatStats.sink: a sub-model is rendered at most once per frame")
         starts = [0]
         for c in self.counts:
             starts.append(starts[-1] + c)
