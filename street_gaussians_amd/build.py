@@ -17,7 +17,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libsgr_hip.so")
 SOURCES = ["sgr_preprocess.hip", "sgr_scan_sort.hip", "sgr_blend_fwd.hip", "sgr_blend_bwd.hip", "sgr_gauss_bwd.hip", "sgr_gauss_bwd_strict.hip",
            "sgr_knn.hip", "sgr_multiview.hip", "sgr_scene.hip", "sgr_loss.hip", "sgr_densify.hip", "sgr_api.hip"]
-HEADERS = ["sgr_common.h", "sgr_math.h", os.path.join("..", "..", "include", "sgr.h"),
+HEADERS = ["sgr_common.h", "sgr_math.h", "sgr_reduce.h", os.path.join("..", "..", "include", "sgr.h"),
            os.path.join("..", "..", "include", "sgr_scene.h"), os.path.join("..", "..", "include", "sgr_loss.h"), os.path.join("..", "..", "include", "sgr_densify.h")]
 # -fno-slp-vectorize: hipcc's SLP pass packs neighbouring scalar f32 ops into v_pk_* and pays for it with v_mov
 # shuffles; measured on MI355X it costs 6 % in the blend backward and 7 % in the per-Gaussian backward.

@@ -314,7 +314,7 @@ SGR_HD float sgr_power_ref_staged(float hx, float ny, float hz, float dx, float 
 // states between them, 6 issue slots of 15).  The blend kernels never use G for a positive power, and for very negative
 // arguments ldexp underflows to the same 0 on its own as long as `e` is finite; one v_max on ph keeps it finite (for
 // ph >= -200 the clamp is the identity, below it pl absorbs the difference and the result is 0 either way; a NaN
-// argument still gives NaN through pl).  Bit-identical to expf for every x <= 88.72 incl. -inf and NaN
+// argument still gives NaN through pl).  Bit-identical to expf for every -103 <= x <= 88.72, 0 or 2^-149 below, NaN for NaN
 // (sgr_test_exact_math, tests/test_gpu_primitives.py).
 SGR_HD float sgr_expf_ref(float x) {
 #pragma clang fp contract(off)

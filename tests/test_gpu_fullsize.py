@@ -202,6 +202,11 @@ def test_threeway_against_reference_kernels_at_baseline_size(name, P, S):
 
     rf = ref.forward(**kw)
     gref = ref.backward(rf, wts["color"], wts["depth"], wts["alpha"], gsem)
+    # the reference's own run-to-run spread (unordered float atomics, backward.cu:568-638): a second backward over the same
+    # forward state, held to the same gate
+    gref_b = ref.backward(rf, wts["color"], wts["depth"], wts["alpha"], gsem)
+    ref_rerun = {k: _outside(npy(gref_b[k]).reshape(-1), npy(gref[k]).reshape(-1), 1e-4, 2e-6) for k in gref}
+    del gref_b
     ref_img = {k: npy(getattr(rf, k)) for k in ["color", "depth", "alpha", "semantic"]}
     ref_int = dict(R=rf.num_rendered, radii=npy(rf.radii), point_list=npy(rf.internal("point_list")).view(np.uint32),
                    keys=npy(rf.internal("keys")).view(np.uint64), ranges=npy(rf.internal("ranges")).view(np.uint32))
@@ -277,6 +282,7 @@ def test_threeway_against_reference_kernels_at_baseline_size(name, P, S):
             rec["grads"][k]["fmad_vs_ref_1e-5"] = _outside(f, r, 1e-4, 1e-5)
             rec["grads"][k]["hip_vs_fmad"] = _outside(h, f, 1e-4, 2e-6)
         hx = g_x[k].reshape(gor[k].shape)
+        rec["grads"][k]["ref_rerun_vs_ref"] = ref_rerun[k]
         rec["grads"][k]["hip_exact_vs_ref"] = _outside(hx, r, 1e-4, 2e-6)
         rec["grads"][k]["hip_exact_vs_ref_1e-5"] = _outside(hx, r, 1e-4, 1e-5)
     try:
@@ -302,8 +308,10 @@ def test_threeway_against_reference_kernels_at_baseline_size(name, P, S):
     for k in ["alpha", "depth"] + (["semantic"] if S else []):
         assert rec["images"][k]["hip_exact_bit_identical"], (k, rec["images"][k])
     assert rec["images"]["color"]["hip_exact_vs_ref"]["outside"] == 0, rec["images"]["color"]
+    from gpu_utils import conditioned_allowance  # dL/dcov3D / dL/dscale / dL/drot: computeCov2DCUDA's cancelling sums
     for k, st in rec["grads"].items():
-        assert st["hip_exact_vs_ref"]["outside"] <= EXACT_ALLOW.get(name, {}).get(k, 0), ("parity mode", k, st["hip_exact_vs_ref"])
+        allow = max(EXACT_ALLOW.get(name, {}).get(k, 0), conditioned_allowance(k, st["hip_exact_vs_ref"]["n"], st["ref_rerun_vs_ref"]["outside"]))
+        assert st["hip_exact_vs_ref"]["outside"] <= allow, ("parity mode", k, st["hip_exact_vs_ref"], st["ref_rerun_vs_ref"])
     for k, st in rec["grads"].items():
         n = st["hip_vs_ref"]["n"]
         # yardstick: how far two VALID builds of the reference's own sources are from each other (contraction off vs the
