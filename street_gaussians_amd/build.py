@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libsgr_hip.so")
-SOURCES = ["sgr_preprocess.hip", "sgr_scan_sort.hip", "sgr_blend_fwd.hip", "sgr_blend_bwd.hip", "sgr_gauss_bwd.hip", "sgr_gauss_bwd_strict.hip",
+SOURCES = ["sgr_preprocess.hip", "sgr_scan_sort.hip", "sgr_blend_fwd.hip", "sgr_blend_bwd.hip", "sgr_blend_bwd_sw.hip", "sgr_gauss_bwd.hip", "sgr_gauss_bwd_strict.hip",
            "sgr_knn.hip", "sgr_multiview.hip", "sgr_scene.hip", "sgr_loss.hip", "sgr_densify.hip", "sgr_api.hip"]
 HEADERS = ["sgr_common.h", "sgr_math.h", "sgr_reduce.h", os.path.join("..", "..", "include", "sgr.h"),
            os.path.join("..", "..", "include", "sgr_scene.h"), os.path.join("..", "..", "include", "sgr_loss.h"), os.path.join("..", "..", "include", "sgr_densify.h")]

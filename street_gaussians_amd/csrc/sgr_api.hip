@@ -43,14 +43,18 @@ void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, cons
                           const SgrGeomView& gv, const float* partials, int row_stride, const uint8_t* touched,
                           float4* cd, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dsemantic,
-                          const SgrStatSink& sink, hipStream_t s);
+                          const SgrStatSink& sink, int quad, int exact, int W, int H, hipStream_t s);
+void sgr_launch_blend_bwd_sw(bool exact, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W, int H,
+                             const float* bg, const float4* rec, const uint32_t* u0, const float* alphas,
+                             const uint32_t* n_contrib, const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth,
+                             const float* dL_dalpha, float* partials, int row_stride, uint8_t* touched, hipStream_t s);
 // the same compiled with FP contraction off (sgr_gauss_bwd_strict.hip): parity mode
 void sgr_launch_gauss_bwd_strict(int P, int D, int M, int S, const float* means3D, const int* radii, const float* shs,
                                  const float* scales, const float* rotations, const float* cov3D_precomp, const SgrCam* cam,
                                  const SgrGeomView& gv, const float* partials, int row_stride, const uint8_t* touched,
                                  float4* cd, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                                  float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dsemantic,
-                                 const SgrStatSink& sink, hipStream_t s);
+                                 const SgrStatSink& sink, int quad, int exact, int W, int H, hipStream_t s);
 void sgr_launch_masked_color_grad(int P, const uint32_t* clamped, const float* dL_dcolor, float* out, hipStream_t s);
 void sgr_launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, size_t means_stride,
                                    const float* campos, size_t campos_stride, const float* drgb, size_t drgb_stride,
@@ -80,7 +84,7 @@ static int switches() {
     if (v < 0) {
         v = (env_flag("SGR_NO_CULL") ? 1 : 0) | (env_flag("SGR_NO_DPP") ? 2 : 0) | (env_flag("SGR_NO_DET") ? 4 : 0) |
             (env_flag("SGR_NO_HITS") ? 8 : 0) | (env_flag("SGR_V2") ? 16 : 0) | (env_flag("SGR_PRE_STAGE") ? 64 : 0) |
-            (env_flag("SGR_EXACT") ? 128 : 0) | (env_flag("SGR_SW8") ? 256 : 0) | (env_flag("SGR_SW9") ? 512 : 0);
+            (env_flag("SGR_EXACT") ? 128 : 0) | ((env_flag("SGR_SW8") || env_flag("SGR_NO_SW")) ? 256 : 0) | (env_flag("SGR_SW9") ? 512 : 0);
         g_switches.store(v, std::memory_order_relaxed);
     }
     return v;
@@ -519,9 +523,14 @@ int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, 
     const SgrImgView iv = sgr_img_carve(image_buffer, N, T);
     const int* radii_ptr = radii ? radii : gv.internal_radii;
     const int stride = sgr_partial_row_stride(S);
-    // scratch = [P float4: conic + depth terms between the two per-Gaussian stages][R partial rows]
+    // Which blend backward runs.  The scalar walk (sgr_blend_bwd_sw.hip; S = 0, the shipped switch settings: hit record,
+    // cull, DPP reduction, deterministic) writes FOUR rows per (tile, instance), one per quadrant; everything else goes
+    // through the LDS-staged kernel with its one combined row.  Switch bit 8 (SGR_NO_SW=1) forces the LDS kernel (A/B).
+    const int sw_all = switches();
+    const bool quad = S == 0 && R > 0 && (sw_all & (1 | 2 | 4 | 8 | 16 | 256)) == 0;
+    // scratch = [P float4: conic + depth terms between the two per-Gaussian stages][R (or 4 R) partial rows]
     const size_t cd_bytes = sgr_align_up((size_t)P * sizeof(float4), 256);
-    const size_t bytes = sgr_align_up((size_t)R * stride * sizeof(float), 256);
+    const size_t bytes = sgr_align_up((size_t)R * (quad ? 4u : 1u) * stride * sizeof(float), 256);
     char* sbase = scratch(cd_bytes + bytes, scratch_user);
     if (!sbase) return fail(SGR_E_ALLOC, "backward scratch allocation failed");
     float4* cd = reinterpret_cast<float4*>(sbase);
@@ -535,7 +544,9 @@ int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, 
         const SgrBinView bv = sgr_bin_carve(binning_buffer, (size_t)R);
         touched = bv.touched;
         const int cur = sorted_index(W, H);
-        const bool odd_set = (switches() & (1 | 8)) != 0;
+        // (S = 0: the scalar walk leaves quadrant MASKS in these bytes and the LDS kernel ones; any switch that routes an
+        // S = 0 backward through the LDS kernel therefore clears them before and after as well)
+        const bool odd_set = (switches() & (1 | 8)) != 0 || (S == 0 && !quad);
         prof_begin(6, stream);
         if (odd_set) SGR_HIP(hipMemsetAsync(touched, 0, (size_t)R, stream));
         prof_end(stream);
@@ -545,19 +556,24 @@ int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, 
         // the forward's record of which (quadrant, instance) pairs blended at all; switch 8: the kernel redoes the
         // geometric cull instead (A/B and tests: the two walks must give bit-identical gradients)
         const uint8_t* hits = (sw & 8) ? nullptr : bv.hit4;
-        sgr_launch_blend_bwd(cull, dpp, det, (sw & 16) != 0, (sw & 128) != 0, gx, gy, iv.ranges, bv.vals[cur], W, H, S, background, gv.rec, gv.u0, semantics,
-                             alphas, iv.n_contrib, hits, dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, partials,
-                             touched, stream);
+        if (quad)
+            sgr_launch_blend_bwd_sw((sw & 128) != 0, gx, gy, iv.ranges, bv.vals[cur], W, H, background, gv.rec, gv.u0, alphas,
+                                    iv.n_contrib, bv.hit4, dL_dpix, dL_dpix_depth, dL_dalphas, partials, stride, touched, stream);
+        else
+            sgr_launch_blend_bwd(cull, dpp, det, (sw & 16) != 0, (sw & 128) != 0, gx, gy, iv.ranges, bv.vals[cur], W, H, S, background, gv.rec, gv.u0, semantics,
+                                 alphas, iv.n_contrib, hits, dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, partials,
+                                 touched, stream);
         SGR_STAGE("blend_bwd");
         prof_end(stream);
     }
     prof_begin(8, stream);
     ((switches() & 128) ? sgr_launch_gauss_bwd_strict : sgr_launch_gauss_bwd)(
         P, D, M, S, means3D, radii_ptr, shs, scales, rotations, cov3D_precomp, cam_slot(gv), gv, partials, stride, touched, cd,
-        dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, dL_dsemantic, sink, stream);
+        dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, dL_dsemantic, sink, quad ? 1 : 0,
+        (switches() & 128) ? 1 : 0, W, H, stream);
     SGR_STAGE("gauss_bwd");
     prof_end(stream);
-    if (touched && (switches() & (1 | 8)) != 0) SGR_HIP(hipMemsetAsync(touched, 0, (size_t)R, stream));
+    if (touched && ((switches() & (1 | 8)) != 0 || (S == 0 && !quad))) SGR_HIP(hipMemsetAsync(touched, 0, (size_t)R, stream));
     return 0;
 }
 

@@ -97,6 +97,15 @@ __global__ void sgr_wave_sum_test_kernel(const float* in, float* out_dpp, float*
         for (int i = 0; i < 2; i++)
             if (4 * i + t0 < 5) rs_ok = rs_ok && (gw[i] == (float)(4 * (4 * i + t0) + perm + 1) * b);
     }
+    {   // two visits in one statement: bank b of g0 <-> value 4*perm[b] + perm[k]; banks 0, 2 of g1 <-> 16 + 4*perm[b] + perm[k]
+        float z[24], g0, g1;
+#pragma unroll
+        for (int i = 0; i < 24; i++) z[i] = (float)(i + 1) * v;
+        sgr_wave_reduce_fold24(z, g0, g1);
+        const int bank = (threadIdx.x >> 2) & 3, pb = (0x3120 >> (bank * 4)) & 3;
+        rs_ok = rs_ok && (g0 == (float)(4 * pb + perm + 1) * b);
+        if ((bank & 1) == 0) rs_ok = rs_ok && (g1 == (float)(16 + 4 * pb + perm + 1) * b);
+    }
     rs_ok = __all(rs_ok);
     if (threadIdx.x == 63) {
         // all four asm chains, the builtin version and the reduce-scatter must agree with the shuffle tree
@@ -261,7 +270,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
             const float4 d4 = r[3];
             sA[tid] = a;
             sB[tid] = EXACT ? make_float4(-0.5f * b.x, -b.y, -0.5f * b.z, b.w)
-                            : make_float4(-0.5f * SGR_LOG2E * b.x, -SGR_LOG2E * b.y, -0.5f * SGR_LOG2E * b.z, b.w);
+                            : sgr_stage_conic(b);
             sC[tid] = r[2];
             const uint32_t dy_ = __float_as_uint(d4.y);
             const uint32_t rx0 = dy_ & 1023u, ry0 = (dy_ >> 10) & 1023u, rw = dy_ >> 20;
@@ -656,7 +665,7 @@ sgr_blend_bwd_kernel_v2(SGR_BWD_ARGS) {
             const float4 b = r[1];
             const float4 d4 = r[3];
             sA[tid] = a;
-            sB[tid] = make_float4(-0.5f * SGR_LOG2E * b.x, -SGR_LOG2E * b.y, -0.5f * SGR_LOG2E * b.z, b.w);
+            sB[tid] = sgr_stage_conic(b);
             sC[tid] = r[2];
             const uint32_t dy_ = __float_as_uint(d4.y);
             const uint32_t rx0 = dy_ & 1023u, ry0 = (dy_ >> 10) & 1023u, rw = dy_ >> 20;

@@ -100,7 +100,7 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
             sA[tid] = a;
             // EXACT (parity mode): exact power-of-two scalings only -- the walk evaluates the reference's own power
             // expression on the staged triple (sgr_power_ref_staged)
-            sB[tid] = EXACT ? make_float4(-0.5f * b.x, -b.y, -0.5f * b.z, b.w) : make_float4(-0.5f * SGR_LOG2E * b.x, -SGR_LOG2E * b.y, -0.5f * SGR_LOG2E * b.z, b.w);
+            sB[tid] = EXACT ? make_float4(-0.5f * b.x, -b.y, -0.5f * b.z, b.w) : sgr_stage_conic(b);
             sC[tid] = r[2];
             if (SMAX > 0) {  // channels S..SMAX-1 are staged as zeros so the walk needs no per-channel test
 #pragma unroll

@@ -23,12 +23,18 @@
 // are combined with two quad_perm DPP steps.  The order of the additions is fixed -> deterministic.
 // Writes the outputs that come straight from the blend backward (backward.cu:568-638) and hands the conic / depth
 // terms to stage 2 through `cd`.
-template <int SMAX>
+// QUAD: the rows of the scalar-walk blend backward (sgr_blend_bwd_sw.hip) -- FOUR rows per (tile, instance), one per
+// quadrant, `touched` = mask of the ones that exist, each holding the raw moments [S gx, S gy, S abs, S gxx, S gxy, S gyy,
+// S Gd, r, g, b, depth]; summed in (tile, quadrant) order, and the moments -> gradient step of the LDS kernel's flush
+// (a product with the Gaussian's staged conic and opacity, backward.cu:616-635) applied ONCE, to the sums.
+// kx, ky = 0.5 * W / lsc, 0.5 * H / lsc with lsc = log2(e), or 1 in parity mode (`exact`: the staged conic is then
+// (-0.5 cx, -cy, -0.5 cz) instead of the log2(e)-scaled one in rec[3]).
+template <int SMAX, bool QUAD>
 __global__ void __launch_bounds__(SGR_GB_THREADS)
 sgr_row_sum_kernel(int P, int S, const int* __restrict__ radii, SgrGeomView gv, const float* __restrict__ partials,
                    int row_stride, const uint8_t* __restrict__ touched, float* __restrict__ dL_dmean2D,
                    float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dsemantic,
-                   float4* __restrict__ cd, SgrStatSink sink) {
+                   float4* __restrict__ cd, SgrStatSink sink, float kx, float ky, int exact) {
     constexpr int NV = (SGR_ROW_BASE_N + SMAX + 3) / 4;
     const int gtid = blockIdx.x * SGR_GB_THREADS + threadIdx.x;
     const int idx = gtid / SGR_RS_LANES, q = gtid % SGR_RS_LANES;
@@ -40,7 +46,29 @@ sgr_row_sum_kernel(int P, int S, const int* __restrict__ radii, SgrGeomView gv, 
     // together and the dependent chain is {u0, n} -> flag -> row
     const uint32_t n = live ? gv.aux[idx].x : 0u;
     const uint32_t u0 = live ? gv.u0[idx] : 0u;  // defined for every Gaussian (exclusive scan)
-    if (n) {
+    if (n && QUAD) {
+        const uint8_t* flag = touched + u0;
+        const float* rows = partials + (size_t)u0 * 4u * row_stride;
+        for (uint32_t i = (uint32_t)q; i < n; i += SGR_RS_LANES) {
+            const uint32_t h = flag[i];
+            const float4* r = reinterpret_cast<const float4*>(rows + (size_t)i * 4u * row_stride);
+            float4 t[4][NV];
+#pragma unroll
+            for (int b = 0; b < 4; b++)  // the (up to four) rows of the instance go out together
+                if ((h >> b) & 1u) {
+#pragma unroll
+                    for (int k4 = 0; k4 < NV; k4++) t[b][k4] = r[b * (row_stride / 4) + k4];
+                }
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if ((h >> b) & 1u) {
+#pragma unroll
+                    for (int k4 = 0; k4 < NV; k4++) {
+                        acc[4 * k4] += t[b][k4].x; acc[4 * k4 + 1] += t[b][k4].y; acc[4 * k4 + 2] += t[b][k4].z; acc[4 * k4 + 3] += t[b][k4].w;
+                    }
+                }
+        }
+    } else if (n) {
         const uint8_t* flag = touched + u0;
         const float* rows = partials + (size_t)u0 * row_stride;
         auto add_row = [&](const float4 (&t)[NV]) __attribute__((always_inline)) {
@@ -78,6 +106,20 @@ sgr_row_sum_kernel(int P, int S, const int* __restrict__ radii, SgrGeomView gv, 
         acc[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc[k]), 0x4E, 0xF, 0xF, false));
         if (SGR_RS_LANES == 8)  // row_half_mirror: lane i <-> 7 - i, i.e. the other quad of the 8-lane group
             acc[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc[k]), 0x141, 0xF, 0xF, false));
+    }
+    if (QUAD && n) {
+        // moments -> gradients (sgr_blend_bwd.hip's flush, per Gaussian instead of per (tile, instance))
+#pragma clang fp contract(off)
+        const float4 c1 = gv.rec[4 * (size_t)idx + 1], c3 = gv.rec[4 * (size_t)idx + 3];
+        const float qx = exact ? -0.5f * c1.x : c3.x, qy = exact ? -c1.y : c3.z, qz = exact ? -0.5f * c1.z : c3.w;
+        const float qw = c1.w, hq = -0.5f * c1.w;
+        const float sgx = acc[0], sgy = acc[1];
+        acc[0] = qw * kx * fmaf(qx + qx, sgx, qy * sgy);  // dL/dmean2D.x
+        acc[1] = qw * ky * fmaf(qz + qz, sgy, qy * sgx);  // dL/dmean2D.y
+        acc[2] = qw * acc[2];                             // sum |gx| + |gy|
+        acc[3] = hq * acc[3];                             // dL/dconic.x
+        acc[4] = hq * acc[4];                             // dL/dconic.y
+        acc[5] = hq * acc[5];                             // dL/dconic.w
     }
     if (!live) return;
     // the quad shares the stores
@@ -326,14 +368,19 @@ void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, cons
                           const SgrGeomView& gv, const float* partials, int row_stride, const uint8_t* touched,
                           float4* cd, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dsemantic,
-                          const SgrStatSink& sink, hipStream_t s) {
+                          const SgrStatSink& sink, int quad, int exact, int W, int H, hipStream_t s) {
     if (P <= 0) return;
+    const float lsc = exact ? 1.0f : SGR_LOG2E;
+    const float kx = (0.5f * (float)W) / lsc, ky = (0.5f * (float)H) / lsc;
     const unsigned nb = (P + SGR_GB_THREADS - 1) / SGR_GB_THREADS;
     const unsigned nb4 = (unsigned)(((size_t)P * SGR_RS_LANES + SGR_GB_THREADS - 1) / SGR_GB_THREADS);
 #define SGR_RS(N)                                                                                                    \
-    sgr_row_sum_kernel<N><<<nb4, SGR_GB_THREADS, 0, s>>>(P, S, radii, gv, partials, row_stride, touched, dL_dmean2D,   \
-                                                        dL_dopacity, dL_dcolor, dL_dsemantic, cd, sink)
-    if (S == 0) SGR_RS(0);
+    sgr_row_sum_kernel<N, false><<<nb4, SGR_GB_THREADS, 0, s>>>(P, S, radii, gv, partials, row_stride, touched, dL_dmean2D, \
+                                                               dL_dopacity, dL_dcolor, dL_dsemantic, cd, sink, kx, ky, exact)
+    if (quad) {  // the scalar-walk blend backward's rows (S = 0 only)
+        sgr_row_sum_kernel<0, true><<<nb4, SGR_GB_THREADS, 0, s>>>(P, S, radii, gv, partials, row_stride, touched, dL_dmean2D,
+                                                                  dL_dopacity, dL_dcolor, dL_dsemantic, cd, sink, kx, ky, exact);
+    } else if (S == 0) SGR_RS(0);
     else if (S <= 4) SGR_RS(4);
     else if (S <= 8) SGR_RS(8);
     else if (S <= 12) SGR_RS(12);

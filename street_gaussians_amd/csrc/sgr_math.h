@@ -282,6 +282,12 @@ SGR_HD uint32_t sgr_quadrant_mask(const float4& a, const float4& b, float tx0, f
 // G = exp(power) = exp2(power*log2e) is a single v_exp_f32.  Explicit fmaf + contraction off: the
 // forward and backward kernels must evaluate bit-identical alpha for the same pair
 // (forward.cu:423-430 vs backward.cu:536-545).
+// The pre-scaled conic of a record {conic.x, conic.y, conic.z, opacity}: ONE definition, because the forward (which
+// stages it), the LDS-staged backward (which stages it again) and the preprocess (which files it in rec[3].xzw for the
+// scalar-walk backward) must produce the same bits.
+SGR_HD float4 sgr_stage_conic(const float4 b) {
+    return make_float4(-0.5f * SGR_LOG2E * b.x, -SGR_LOG2E * b.y, -0.5f * SGR_LOG2E * b.z, b.w);
+}
 SGR_HD float sgr_power2(float qa, float qb, float qc, float dx, float dy) {
 #pragma clang fp contract(off)
     const float u = fmaf(qb, dy, qa * dx);  // qa*dx + qb*dy

@@ -223,7 +223,10 @@ sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         rec[0] = make_float4(pr.px, pr.py, hx, hy);
         rec[1] = make_float4(pr.con_x, pr.con_y, pr.con_z, opacity);
         rec[2] = make_float4(rgb[0], rgb[1], rgb[2], pr.depth);
-        rec[3] = make_float4(0.f, __uint_as_float(rect), 0.f, 0.f);
+        // rec[3] = {qa, packed tile rect, qb, qc}: the pre-scaled conic rides in the line's spare words, so that the
+        // scalar-walk backward gets everything a visit needs with one s_load_dwordx16
+        const float4 st = sgr_stage_conic(make_float4(pr.con_x, pr.con_y, pr.con_z, opacity));
+        rec[3] = make_float4(st.x, __uint_as_float(rect), st.y, st.z);
         gv.clamped[idx] = clamped;
         gv.aux[idx] = make_uint2(w * h, rect);
         gv.dkeys[0][idx] = __float_as_uint(pr.depth);

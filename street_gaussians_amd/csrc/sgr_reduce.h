@@ -187,3 +187,50 @@ __device__ __forceinline__ void sgr_wave_reduce_fold(float (&v)[NVAL], float (&g
     if (i < NG) sgr_quad_sum(g[i]);
 }
 
+
+// ---- TWO visits at once: 24 values, the whole row stage as ONE statement ------------------------------------------
+// sgr_wave_reduce_fold<12> spends 9 wait states per visit around its four DPP statements (VALU write -> DPP read needs
+// two, and nothing pads the inside of an asm statement); with the six registers of two visits in one statement the
+// dependent instructions are two or more apart by construction: 13 v_add_f32_dpp and 3 s_nop for TWO visits.
+// in: v[24] (values 0-11 of the first visit, 12-23 of the second).  out: g0, g1.  With bank = (lane >> 2) & 3,
+// k = lane >> 4 and perm = {0,2,1,3}: every lane of bank b of g0 holds the wave total of value 4*perm[b] + perm[k];
+// every lane of banks 0 and 2 of g1 holds value 16 + 4*perm[b] + perm[k] (banks 1, 3 of g1: garbage).
+__device__ __forceinline__ void sgr_wave_reduce_fold24(float (&v)[24], float& g0, float& g1) {
+    float h[12], r[6];
+#pragma unroll
+    for (int p = 0; p < 12; p++) {
+        sgr_swap32(v[2 * p], v[2 * p + 1]);
+        h[p] = v[2 * p] + v[2 * p + 1];
+    }
+#pragma unroll
+    for (int t = 0; t < 6; t++) {
+        sgr_swap16(h[2 * t], h[2 * t + 1]);
+        r[t] = h[2 * t] + h[2 * t + 1];
+    }
+#define SGR_RM " row_mask:0xf bank_mask:"
+    asm volatile(
+        "s_nop 1\n\t"
+        // half rows: r0 <- (r0 | r1), r2 <- (r2 | r3), r4 <- (r4 | r5)
+        "v_add_f32_dpp %0, %0, %0 row_ror:8" SGR_RM "0x3\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:8" SGR_RM "0x3\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_ror:8" SGR_RM "0x3\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_ror:8" SGR_RM "0xc\n\t"
+        "v_add_f32_dpp %2, %3, %3 row_ror:8" SGR_RM "0xc\n\t"
+        "v_add_f32_dpp %4, %5, %5 row_ror:8" SGR_RM "0xc\n\t"
+        // quarter rows: r0 <- (r0 | r2) by banks, r4 alone (banks 0 and 2)
+        "v_add_f32_dpp %0, %0, %0 row_shl:4" SGR_RM "0x5\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_shr:4" SGR_RM "0xa\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_shl:4" SGR_RM "0x5\n\t"
+        "s_nop 0\n\t"
+        // inside the quads
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1]" SGR_RM "0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1]" SGR_RM "0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2]" SGR_RM "0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2]" SGR_RM "0xf\n\t"
+        "s_nop 0"
+        : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]));
+#undef SGR_RM
+    g0 = r[0];
+    g1 = r[4];
+}

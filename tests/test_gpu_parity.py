@@ -182,10 +182,22 @@ def test_culling_is_invisible_and_backward_is_deterministic(name):
     cam, sc, kw = _kw(name)
     wts = syn.loss_weights(cam, S=sc.semantics.shape[1])
     res_a, int_a = raw_forward(kw)
-    g_a = raw_backward(kw, res_a, wts)
-    g_a2 = raw_backward(kw, res_a, wts)
+    g_s = raw_backward(kw, res_a, wts)  # the shipped path (S = 0: the scalar-walk kernel)
+    g_s2 = raw_backward(kw, res_a, wts)
+    for k in g_s:
+        assert torch.equal(g_s[k], g_s2[k]), f"{k} not deterministic"
+    # the A/B switches below all run the LDS-staged kernel: it is their bit-for-bit baseline (switch NO_SW); the scalar walk
+    # sums the same terms in another order (per quadrant, moments -> gradients once per Gaussian): equal up to rounding
+    with switches(_C.NO_SW):
+        g_a = raw_backward(kw, res_a, wts)
+        g_a2 = raw_backward(kw, res_a, wts)
     for k in g_a:
-        assert torch.equal(g_a[k], g_a2[k]), f"{k} not deterministic"
+        assert torch.equal(g_a[k], g_a2[k]), f"{k} not deterministic (LDS-staged kernel)"
+        if name not in ILL_CONDITIONED:
+            grad_close(npy(g_s[k]), npy(g_a[k]), rel=1e-4, abs_frac=2e-5, name=f"scalar walk vs LDS kernel:{k}", max_outlier_frac=0.0)
+    g_s3 = raw_backward(kw, res_a, wts)  # and back: the row flags of the two kernels do not leak into each other
+    for k in g_s:
+        assert torch.equal(g_s[k], g_s3[k]), f"{k} changed after an LDS-kernel backward over the same forward"
     with switches(_C.NO_HITS):  # geometric cull instead of the hit record: a superset of the same visits
         g_h = raw_backward(kw, res_a, wts)
     for k in g_a:
@@ -198,9 +210,9 @@ def test_culling_is_invisible_and_backward_is_deterministic(name):
         g_b = raw_backward(kw, res_b, wts)
     for k in g_a:  # same pairs, same order: the cull must not change the gradients at all
         assert torch.equal(g_a[k], g_b[k]), f"cull changed dL/d{k}"
-    g_b2 = raw_backward(kw, res_b, wts)  # hit record written by the un-culled forward
-    for k in g_a:
-        assert torch.equal(g_a[k], g_b2[k]), f"hit record of the un-culled forward changed dL/d{k}"
+    g_b2 = raw_backward(kw, res_b, wts)  # hit record written by the un-culled forward, walked by the shipped kernel
+    for k in g_s:
+        assert torch.equal(g_s[k], g_b2[k]), f"hit record of the un-culled forward changed dL/d{k}"
     with switches(_C.USE_ONESWEEP):  # the radix sorts in their one-sweep A/B form: the same order, bit for bit
         res_s, int_s = raw_forward(kw)
         for k in ["keys", "point_list", "ranges", "point_offsets"]:
