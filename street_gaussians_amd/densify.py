@@ -47,13 +47,16 @@ def densify_and_prune(params: Dict[str, torch.Tensor], xyz_gradient_accum: torch
                       prune_big: bool, states: Optional[Dict[str, Tuple[torch.Tensor, torch.Tensor]]] = None,
                       grad_column: int = 0, n_split: int = 2, normals: Optional[torch.Tensor] = None,
                       variant: Optional[str] = None, sphere_center=None, sphere_radius: Optional[float] = None,
-                      box_min=None, box_max=None, box_normals: Optional[torch.Tensor] = None):
+                      box_min=None, box_max=None, box_normals: Optional[torch.Tensor] = None, normal_source=None):
     """params: {'xyz' [N,3], 'f_dc' [N,C,3], 'f_rest' [N,M-1,3], 'opacity' [N,1], 'scaling' [N,3], 'rotation' [N,4],
     'semantic' [N,S]} raw parameters; states: optional {name: (exp_avg, exp_avg_sq)} shaped like the parameters.
     Returns (new_params, new_states, scalars, index) with scalars = {'points_total', 'points_clone', 'points_split',
     'points_pruned'} and index = {'src', 'kind'} (source row and 0 keep / 1 clone / 2 split child per result row).
     variant "bkgd" needs sphere_center [3] and sphere_radius; variant "actor" needs box_min / box_max [3] and takes
-    box_normals [n_candidates, 2, 3] (standard normals; drawn when omitted)."""
+    box_normals [n_candidates, 2, 3] (standard normals; drawn when omitted).
+    normal_source: a callable (rows, device[, cols]) -> standard normals, asked for the split's samples (and the actor
+    variant's box samples) when the tensors are not given -- how view-sharded training keeps replicated Gaussians
+    identical across ranks (multiview.ReplicatedNormals)."""
     if variant not in _VARIANTS:
         raise ValueError(f"unknown variant {variant!r}")
     if _VARIANTS[variant] != 0:
@@ -61,7 +64,8 @@ def densify_and_prune(params: Dict[str, torch.Tensor], xyz_gradient_accum: torch
                                  extent=extent, percent_dense=percent_dense, percent_big_ws=percent_big_ws,
                                  prune_big=prune_big, states=states, grad_column=grad_column, n_split=n_split,
                                  normals=normals, variant=variant, sphere_center=sphere_center,
-                                 sphere_radius=sphere_radius, box_min=box_min, box_max=box_max, box_normals=box_normals)
+                                 sphere_radius=sphere_radius, box_min=box_min, box_max=box_max, box_normals=box_normals,
+                                 normal_source=normal_source)
     xyz = params["xyz"]
     if not xyz.is_cuda:
         raise SgrError("densify_and_prune needs HIP (cuda) tensors: there is no CPU path")
@@ -92,7 +96,7 @@ def densify_and_prune(params: Dict[str, torch.Tensor], xyz_gradient_accum: torch
         new_params = {k: gather(params[k], False) for k in PARAMS if k in params}
         if n_norm:
             if normals is None:
-                normals = torch.randn(n_norm, 3, device=dev)
+                normals = normal_source(n_norm, dev) if normal_source is not None else torch.randn(n_norm, 3, device=dev)
             if tuple(normals.shape) != (n_norm, 3):
                 raise RuntimeError(f"normals must have dimensions ({n_norm}, 3)")
             check(L.sgr_densify_split_children(n_out, int(n_split), _p(src), _p(kind), _p(srow), _p(f32(params["xyz"])),
@@ -116,7 +120,7 @@ def _gather(L, t, src, kind, n_out, zero_new, stream, N):
 
 def _densify_two_step(params, xyz_gradient_accum, denom, *, max_grad, min_opacity, extent, percent_dense, percent_big_ws,
                       prune_big, states, grad_column, n_split, normals, variant, sphere_center, sphere_radius, box_min,
-                      box_max, box_normals):
+                      box_max, box_normals, normal_source=None):
     xyz = params["xyz"]
     if not xyz.is_cuda:
         raise SgrError("densify_and_prune needs HIP (cuda) tensors: there is no CPU path")
@@ -140,7 +144,7 @@ def _densify_two_step(params, xyz_gradient_accum, denom, *, max_grad, min_opacit
         cand = {k: _gather(L, params[k], src, kind, n_cand, False, stream, N) for k in ("xyz", "scaling", "rotation", "opacity")}
         if n_norm:
             if normals is None:
-                normals = torch.randn(n_norm, 3, device=dev)
+                normals = normal_source(n_norm, dev) if normal_source is not None else torch.randn(n_norm, 3, device=dev)
             if tuple(normals.shape) != (n_norm, 3):
                 raise RuntimeError(f"normals must have dimensions ({n_norm}, 3)")
             check(L.sgr_densify_split_children(n_cand, int(n_split), _p(src), _p(kind), _p(srow), _p(f32(params["xyz"])),
@@ -159,7 +163,8 @@ def _densify_two_step(params, xyz_gradient_accum, denom, *, max_grad, min_opacit
             hi = [float(v) for v in torch.as_tensor(box_max).flatten().tolist()]
             box = (C.c_float * 6)(*lo, *hi)
             if box_normals is None:
-                box_normals = torch.randn(n_cand, 2, 3, device=dev)
+                box_normals = (normal_source(n_cand * 2, dev).view(n_cand, 2, 3) if normal_source is not None
+                               else torch.randn(n_cand, 2, 3, device=dev))
             if tuple(box_normals.shape) != (n_cand, 2, 3):
                 raise RuntimeError(f"box_normals must have dimensions ({n_cand}, 2, 3)")
             box_normals = f32(box_normals)

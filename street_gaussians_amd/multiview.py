@@ -45,19 +45,41 @@ class GradReducer:
         self.average = average
         self.force = force  # run the collective even with one rank (testing)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        ref = self.params[0]
+        self._side = torch.cuda.Stream(ref.device) if ref.is_cuda else None  # the exchange's own stream
+        self._works = []
+        self._inflight = False
+        self._store = None
+        self._layout()
+
+    def _layout(self) -> None:
+        """(Re)builds the flat bucket and its per-parameter views for ``self.params``.  The storage is kept when it is
+        large enough (it is allocated with 1/8 head-room): a densify step changes every size, and on some hosts a fresh
+        device allocation costs tens of ms."""
         self._numel = [p.numel() for p in self.params]
         total = sum(self._numel)
         pad = (-total) % max(self.world, 1)  # reduce_scatter needs equal shards
         ref = self.params[0]
-        self.flat = torch.zeros(total + pad, dtype=torch.float32, device=ref.device)
-        self._side = torch.cuda.Stream(ref.device) if ref.is_cuda else None  # the exchange's own stream
-        self._works = []
-        self._inflight = False
+        need = total + pad
+        if self._store is None or self._store.numel() < need or self._store.device != ref.device:
+            self._store = torch.zeros(need + need // 8, dtype=torch.float32, device=ref.device)
+        self.flat = self._store[:need]
         self._views = []
         off = 0
         for p, n in zip(self.params, self._numel):
             self._views.append(self.flat[off:off + n].view(p.shape))
             off += n
+
+    def rebuild(self, params: Iterable[torch.Tensor]) -> None:
+        """The parameter set changed size (densify / prune, train.py:187-210): joins an exchange still in flight and lays the
+        bucket out for the new tensors.  Every rank must call it with parameters of the same shapes (replicated densify)."""
+        if self._inflight:
+            self.wait()
+        for p, v in zip(self.params, self._views):  # old gradients that alias the old bucket are meaningless now
+            if p.grad is not None and p.grad.data_ptr() == v.data_ptr():
+                p.grad = None
+        self.params = list(params)
+        self._layout()
 
     @property
     def nbytes(self) -> int:
@@ -208,6 +230,31 @@ class FactoredGradReducer:
                  force: bool = False, mask_fn=None, rebuild_fn=None, segments: Optional[Sequence[SHSegment]] = None):
         from . import rasterizer as _rast
         self.dense = GradReducer(dense_params, group=group, mode=mode, force=force)
+        self.group, self.force = group, force
+        self.k = int(views_per_rank)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._mask_fn, self._rebuild_fn = mask_fn, rebuild_fn
+        self._pending = []
+        self._buf_store = [None, None]
+        self._all_store = None
+        self._configure(shs, means3D, segments)
+        self._rast = _rast
+        _rast.BACKWARD_OBSERVERS.append(self._observe)
+
+    def rebuild(self, dense_params: Iterable[torch.Tensor], shs=None, means3D: Optional[torch.Tensor] = None,
+                segments: Optional[Sequence[SHSegment]] = None) -> None:
+        """After a densify / prune step (train.py:187-210: every parameter changes its length): joins an exchange that is
+        still in flight, then lays the dense bucket and the per-view payload out for the new parameters -- same arguments
+        as the constructor.  Storage is reused when it is large enough.  All ranks must rebuild with the same shapes: with
+        replicated Gaussians the densify step itself has to be identical everywhere (``densify_replicated``)."""
+        if getattr(self, "_begun", False):
+            self.wait()
+        if self._pending:
+            raise RuntimeError("rebuild() between a rasterizer backward and its exchange: run the exchange first")
+        self.dense.rebuild(dense_params)
+        self._configure(shs, means3D, segments)
+
+    def _configure(self, shs, means3D, segments) -> None:
         self._single = None
         if segments is None:
             if shs is None or means3D is None:
@@ -239,11 +286,6 @@ class FactoredGradReducer:
             if rest is not None and (rest.dim() != 3 or rest.shape[0] != dc.shape[0] or rest.shape[2] != 3):
                 raise ValueError(f"segment {i}: features_rest must be [n, M-1, 3] with the same n as features_dc")
         first = self.segments[0].features_dc
-        self.group, self.force = group, force
-        self.k = int(views_per_rank)
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self._mask_fn, self._rebuild_fn = mask_fn, rebuild_fn
-        self._pending = []
         dev = first.device
         # payload row of one view: [campos 3 | dRGB of every segment, statics first then posed | positions of the posed
         # segments | Fourier mix (idft) of every posed segment]
@@ -266,14 +308,23 @@ class FactoredGradReducer:
             self._idft_off[i] = off
             off += self.segments[i].fourier_dim
         self._row = off
-        self._bufs = [torch.zeros(self.k, self._row, dtype=torch.float32, device=dev) for _ in range(2)]
+
+        def fit(store, rows):  # a [rows, row] view of a store that is kept across rebuilds (1/8 head-room)
+            need = rows * self._row
+            if store is None or store.numel() < need or store.device != dev:
+                store = torch.zeros(need + need // 8, dtype=torch.float32, device=dev)
+            else:
+                store[:need].zero_()
+            return store, store[:need].view(rows, self._row)
+        self._bufs = []
+        for b in range(2):
+            self._buf_store[b], v = fit(self._buf_store[b], self.k)
+            self._bufs.append(v)
         self._free_ev = [None, None]  # event on the side stream: "the all-gather that read buffer b is done"
         self._cur = 0
         self._mine = self._bufs[0]
-        self._all = torch.zeros(self.world * self.k, self._row, dtype=torch.float32, device=dev)
+        self._all_store, self._all = fit(self._all_store, self.world * self.k)
         self._frame = (list(range(len(self.segments))), {})
-        self._rast = _rast
-        _rast.BACKWARD_OBSERVERS.append(self._observe)
 
     # legacy attribute (bench.py, tests): the single static model's positions
     @property
@@ -480,6 +531,75 @@ def reduce_densification_stats(xyz_gradient_accum: torch.Tensor, denom: torch.Te
     xyz_gradient_accum.copy_(packed[:n].view_as(xyz_gradient_accum))
     denom.copy_(packed[n:].view_as(denom))
     dist.all_reduce(max_radii2D, op=dist.ReduceOp.MAX, group=group)
+
+
+class ReplicatedNormals:
+    """Standard normals that are IDENTICAL on every rank: the source of the split's samples when Gaussians are
+    replicated (the reference draws ``torch.normal(mean=0, std=stds)`` inside densify_and_split,
+    /root/reference/lib/models/gaussian_model.py:469-473 -- per process, so replicas would drift apart at the first split).
+
+    mode "broadcast" (default): rank 0 draws, everybody receives (exact by construction, 12 bytes per new point);
+    mode "seeded": every rank draws from a generator seeded with (seed, call index) -- no traffic, identical as long as the
+    ranks run the same generator implementation on the same device type.
+    Call it with (rows, device); it returns a [rows, 3] float32 tensor.  Pass it as ``densify_and_prune(normal_source=...)``."""
+
+    def __init__(self, seed: int = 0, group: Optional[dist.ProcessGroup] = None, mode: str = "broadcast"):
+        if mode not in ("broadcast", "seeded"):
+            raise ValueError("mode must be 'broadcast' or 'seeded'")
+        self.seed, self.group, self.mode, self.calls = int(seed), group, mode, 0
+
+    def __call__(self, rows: int, device, cols: int = 3) -> torch.Tensor:
+        self.calls += 1
+        multi = dist.is_initialized() and dist.get_world_size(self.group) > 1
+        if self.mode == "seeded" or not multi:
+            g = torch.Generator(device=device)
+            g.manual_seed((self.seed * 1_000_003 + self.calls) & 0x7FFFFFFFFFFFFFFF)
+            return torch.randn(int(rows), cols, generator=g, device=device, dtype=torch.float32)
+        if dist.get_rank(self.group) == 0:
+            g = torch.Generator(device=device)
+            g.manual_seed((self.seed * 1_000_003 + self.calls) & 0x7FFFFFFFFFFFFFFF)
+            t = torch.randn(int(rows), cols, generator=g, device=device, dtype=torch.float32)
+        else:
+            t = torch.empty(int(rows), cols, device=device, dtype=torch.float32)
+        dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        return t
+
+
+def replicas_identical(tensors: Sequence[torch.Tensor], group: Optional[dist.ProcessGroup] = None) -> bool:
+    """True when every tensor of the list is BIT-identical on all ranks (shapes included): one int64 checksum per tensor
+    (the sum of its 32-bit words + its length), reduced with MIN and MAX.  Collective: every rank must call it."""
+    sums = []
+    for t in tensors:
+        w = t.detach().contiguous().view(-1)
+        w = w.view(torch.int32) if w.element_size() == 4 else w.to(torch.float32).view(torch.int32)
+        # position-weighted, so that two rows swapped do not cancel
+        idx = torch.arange(1, w.numel() + 1, device=w.device, dtype=torch.int64)
+        sums.append((w.to(torch.int64) * (idx % 65521 + 1)).sum() + w.numel())
+    if not sums:
+        return True
+    v = torch.stack(sums)
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return True
+    lo, hi = v.clone(), v.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    return bool(torch.equal(lo, hi))
+
+
+def densify_replicated(params, xyz_gradient_accum: torch.Tensor, denom: torch.Tensor, max_radii2D: torch.Tensor, *,
+                       normals: ReplicatedNormals, states=None, group: Optional[dist.ProcessGroup] = None,
+                       densify_fn=None, **kw):
+    """One densify / prune step of view-sharded training (SURVEY 8e "what does NOT shard"; the reference's
+    train.py:187-210 on one process): the per-view densification statistics are combined across ranks (sums / max,
+    street_gaussian_model.py:551-571 as if one process had rendered every view), then EVERY rank runs the same
+    ``densify_and_prune`` on the same inputs with the same normals, so that the replicas stay bit-identical without
+    moving a single parameter.  Returns what ``densify.densify_and_prune`` returns; afterwards re-create the leaf
+    parameters and call ``rebuild`` on the reducers.  ``densify_fn`` replaces densify.densify_and_prune (CPU tests)."""
+    reduce_densification_stats(xyz_gradient_accum, denom, max_radii2D, group=group)
+    if densify_fn is None:
+        from . import densify as _d
+        densify_fn = _d.densify_and_prune
+    return densify_fn(params, xyz_gradient_accum, denom, states=states, normal_source=normals, **kw)
 
 
 def view_for_rank(views: list, step: int, rank: Optional[int] = None, world: Optional[int] = None):

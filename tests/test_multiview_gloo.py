@@ -248,3 +248,126 @@ def test_factored_grad_reducer_scene_segments_world2():
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok in res), res
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Replicated densify (BASELINE configs[4]: Gaussians replicated, views sharded, densify / prune ACTIVE): per-view statistics are
+# combined across ranks, every rank runs the same densify_and_prune with the same normals, the reducers are rebuilt for the
+# new P, and the next exchange works on the new parameters -- which must stay BIT-identical on all ranks.
+def _densify_cpu(params, accum, denom, *, states, normal_source, max_grad, min_opacity, extent, percent_dense, percent_big_ws,
+                 prune_big, n_split=2, **_):
+    """densify.densify_and_prune's contract on CPU tensors through the step-by-step torch restatement of the reference
+    (tests/torch_ref_densify.py, pinned to GaussianModel.densify_and_prune in tests/test_densify_cpu.py)."""
+    import torch_ref_densify as trd
+    m = trd.Model(params, states, accum, denom)
+    # the split's normals: one row per child, asked from the source once the count is known (it is a function of the
+    # statistics, i.e. identical on every rank after the reduce)
+    grads = (accum[:, 0:1] / denom).nan_to_num(0.0).squeeze(-1)
+    big = torch.exp(params["scaling"]).max(dim=1).values > percent_dense * extent
+    n_norm = n_split * int(((grads >= max_grad) & big).sum())
+    normals = normal_source(n_norm, params["xyz"].device)
+    sc = m.densify_and_prune(max_grad, min_opacity, extent, percent_dense, percent_big_ws, prune_big, normals, N=n_split)
+    return m.p, m.s, sc, None
+
+
+def _densify_worker(rank, world, port, q, mode):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from street_gaussians_amd import multiview, rasterizer
+    import torch_ref_densify as trd
+    P, M, deg = 301, 16, 3
+    g = torch.Generator().manual_seed(11)  # identical replicas to start with
+    raw = {"xyz": torch.randn(P, 3, generator=g) * 3 + torch.tensor([0.0, 0.0, 10.0]), "f_dc": torch.randn(P, 1, 3, generator=g),
+           "f_rest": torch.randn(P, M - 1, 3, generator=g) * 0.1, "opacity": torch.randn(P, 1, generator=g),
+           "scaling": torch.randn(P, 3, generator=g) * 0.5 - 1.0, "rotation": torch.randn(P, 4, generator=g),
+           "semantic": torch.zeros(P, 0)}
+    states = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in raw.items()}
+    failed = []
+
+    def chk(i, cond):
+        if not cond:
+            failed.append(i)
+        return cond
+
+    def leaves(p):
+        return {k: v.clone().requires_grad_(True) for k, v in p.items() if v.numel()}
+
+    def fake_backward(par, red, step):
+        """What this rank's rasterizer backward reports for ITS view: rank-dependent gradients and colour gradients."""
+        n = par["xyz"].shape[0]
+        gr = torch.Generator().manual_seed(1000 * step + rank)
+        for k in ("xyz", "opacity", "scaling", "rotation"):
+            par[k].grad = torch.randn(par[k].shape, generator=gr)
+        campos = torch.randn(3, generator=gr)
+        for obs in list(rasterizer.BACKWARD_OBSERVERS):
+            obs(grad_colors=torch.randn(n, 3, generator=gr), geomBuffer=torch.rand(n, 3, generator=gr) < 0.2, campos=campos,
+                sh_degree=deg, num_points=n)
+
+    par = leaves(raw)
+    dense = lambda p: [p[k] for k in ("xyz", "opacity", "scaling", "rotation")]
+    rn = multiview.ReplicatedNormals(seed=5, mode=mode)
+    with multiview.FactoredGradReducer(dense(par), (par["f_dc"], par["f_rest"]), par["xyz"],
+                                       mask_fn=lambda geom, gc, n: gc * (~geom).float(), rebuild_fn=_rebuild_ref) as red:
+        plain = multiview.GradReducer(dense(par))
+        for step in range(3):
+            fake_backward(par, red, step)
+            red.all_reduce()
+            n = par["xyz"].shape[0]
+            chk(1, par["f_rest"].grad.shape == (n, M - 1, 3) and par["xyz"].grad.shape == (n, 3))
+            chk(2, multiview.replicas_identical([par[k].grad for k in par], None))  # summed gradients: the same everywhere
+            # an "optimiser step" on the summed gradients keeps the replicas identical
+            with torch.no_grad():
+                for k in par:
+                    raw[k] = (par[k] - 0.01 * par[k].grad).detach()
+            # this rank's per-view densification statistics (different on every rank)
+            gs = torch.Generator().manual_seed(77 * step + rank)
+            accum = torch.rand(n, 2, generator=gs) * 2e-3
+            denom = torch.ones(n, 1) + (torch.rand(n, 1, generator=gs) < 0.5).float()
+            radii = torch.rand(n, generator=gs) * 30
+            alone = accum.clone()
+            raw["semantic"] = torch.zeros(n, 0)
+            new_p, new_s, sc, _ = multiview.densify_replicated(
+                raw, accum, denom, radii, normals=rn, states=states, densify_fn=_densify_cpu, max_grad=2.2e-3 / 1.5,
+                min_opacity=0.2, extent=1.0, percent_dense=0.35, percent_big_ws=1e9, prune_big=False)
+            chk(3, not torch.equal(alone, accum))  # the statistics were combined ...
+            chk(4, multiview.replicas_identical([accum, denom, radii]))  # ... to the same values on every rank
+            # (the first step clones, splits and prunes; later ones find fewer candidates among the now smaller points)
+            chk(5, (sc["points_clone"] > 0 and sc["points_split"] > 0 and sc["points_pruned"] > 0) if step == 0
+                else sc["points_clone"] + sc["points_split"] > 0) or failed.append(dict(sc))
+            raw, states = {k: v.detach() for k, v in new_p.items()}, new_s
+            chk(6, raw["xyz"].shape[0] != n)  # P changed
+            # the replicas: parameters and Adam moments bit-identical on all ranks
+            chk(7, multiview.replicas_identical([raw[k] for k in trd.NAMES] + [t for k in trd.NAMES for t in states[k]]))
+            par = leaves(raw)
+            red.rebuild(dense(par), (par["f_dc"], par["f_rest"]), par["xyz"])
+            plain.rebuild(dense(par))
+            # the flat bucket follows too
+            for p_ in dense(par):
+                p_.grad = torch.full(p_.shape, float(rank + 1))
+            plain.all_reduce()
+            chk(8, all(torch.equal(p_.grad, torch.full(p_.shape, float(sum(range(1, world + 1))))) for p_ in dense(par)))
+        # a divergent replica is detected
+        bad = raw["xyz"].clone()
+        if rank == 1:
+            bad[3, 1] += 1e-7
+        chk(9, not multiview.replicas_identical([bad]))
+    q.put((rank, failed))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["broadcast", "seeded"])
+def test_replicated_densify_keeps_the_replicas_identical_world2(mode):
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_densify_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(not f for _, f in res), res
