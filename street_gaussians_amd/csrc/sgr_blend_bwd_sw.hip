@@ -35,6 +35,27 @@ __device__ __forceinline__ sgr_i16 sgr_sload_rec(const float4* __restrict__ p) {
     return *reinterpret_cast<const sgr_i16*>(__builtin_assume_aligned(p, 64));
 }
 
+// "these values exist now": an empty statement that takes them in and hands them back (nothing upstream of them can be
+// scheduled below it) and may touch memory as far as the compiler knows (no load can be hoisted above it)
+__device__ __forceinline__ void sgr_pin12(float (&v)[12]) {
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                      "+v"(v[9]), "+v"(v[10]) :: "memory");
+}
+__device__ __forceinline__ void sgr_pin12a(float (&v)[24]) {
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                      "+v"(v[9]), "+v"(v[10]) :: "memory");
+}
+__device__ __forceinline__ void sgr_pin12b(float (&v)[24]) {
+    asm volatile("" : "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]), "+v"(v[16]), "+v"(v[17]), "+v"(v[18]), "+v"(v[19]),
+                      "+v"(v[20]), "+v"(v[21]), "+v"(v[22]) :: "memory");
+}
+// Keeps ALL sixteen registers of a record allocated up to this point.  The kernel never reads some of its words (the
+// cull extents, in the default mode the raw conic): hipcc hands those registers to other values as soon as the load has
+// landed -- and has to WAIT for the load in order to do so, in the middle of the work the load was meant to run under.
+__device__ __forceinline__ void sgr_keep(const sgr_i16& r) { asm volatile("" ::"s"(r)); }
+#ifndef SGR_SW_PREFETCH
+#define SGR_SW_PREFETCH 1
+#endif
 #ifndef SGR_SW_WAVES
 #define SGR_SW_WAVES 8
 #endif
@@ -209,9 +230,69 @@ sgr_blend_bwd_sw_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
                 return reinterpret_cast<float*>(reinterpret_cast<char*>(partials) + (((uint64_t)hi << 32) | lo));
             };
             // The odd visit of the chunk goes first and alone, then units of two: their 24 sums share one reduce-scatter.
-            // The records are NOT prefetched: the fetch of a unit is exposed (an L2-resident line: ~200-300 cycles per ~2500
-            // cycles of a wave's unit at eight waves per SIMD), and the seven other waves of the SIMD issue meanwhile.  (A
-            // software prefetch needs both generations of records live: 64 SGPRs, which hipcc spills through v_writelane.)
+            // The records of the NEXT unit are fetched while the current one is reduced (SGR_SW_PREFETCH).  For that the old
+            // records must be dead when the new loads are issued -- otherwise both generations are live (64 SGPRs: hipcc
+            // spills them through v_writelane) -- and hipcc sinks per-pixel arithmetic below the loads when left alone:
+            // sgr_pin() makes the per-pixel results exist before it (and is a compiler barrier for memory operations),
+            // __builtin_amdgcn_sched_barrier keeps the machine scheduler from undoing it.
+#if SGR_SW_PREFETCH
+            int jA = 0, jB = 0;
+            if (left & 1) {
+                const int j = sgr_pop_lowest(m);
+                issue(RA, j);
+                left--;
+                float v[12], g[1];
+                pixel(RA, base - j, v);
+                float* const row = rowptr(j);
+                sgr_pin12(v);
+                __builtin_amdgcn_sched_barrier(0);
+                if (left != 0) {
+                    jA = sgr_pop_lowest(m);
+                    jB = sgr_pop_lowest(m);
+                    issue(RA, jA);
+                    issue(RB, jB);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                sgr_wave_reduce_fold<12>(v, g);
+                if (st_a) row[vidx] = g[0];
+            } else {
+                jA = sgr_pop_lowest(m);
+                jB = sgr_pop_lowest(m);
+                issue(RA, jA);
+                issue(RB, jB);
+            }
+            while (left != 0) {
+                float v[24];
+                left -= 2;
+                // first visit, then its record's registers take the next unit's first record (in flight under the second
+                // visit and the reduction); the same for the second
+                pixel(RA, base - jA, v);
+                float* const rowA = rowptr(jA);
+                sgr_pin12a(v);
+                __builtin_amdgcn_sched_barrier(0);
+                sgr_keep(RA);
+                if (left != 0) {
+                    jA = sgr_pop_lowest(m);
+                    issue(RA, jA);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                pixel(RB, base - jB, v + 12);
+                float* const rowB = rowptr(jB);
+                sgr_pin12b(v);
+                __builtin_amdgcn_sched_barrier(0);
+                sgr_keep(RB);
+                if (left != 0) {
+                    jB = sgr_pop_lowest(m);
+                    issue(RB, jB);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                float g0, g1;
+                sgr_wave_reduce_fold24(v, g0, g1);
+                if (st_a) rowA[vidx] = g0;
+                if (st_b0) rowB[vidx - 12u] = g0;
+                if (st_b1) rowB[4u + vidx] = g1;
+            }
+#else
             if (left & 1) {
                 const int j = sgr_pop_lowest(m);
                 issue(RA, j);
@@ -238,6 +319,7 @@ sgr_blend_bwd_sw_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
                 if (st_b0) rowB[vidx - 12u] = g0;
                 if (st_b1) rowB[4u + vidx] = g1;
             }
+#endif
         }
         g_c = g_n;
         h_c = h_n;

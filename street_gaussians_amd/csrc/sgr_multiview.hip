@@ -37,27 +37,44 @@ sgr_sh_grad_from_views_kernel(int P, int D, int M, int V, const float* __restric
     float acc[48];
 #pragma unroll
     for (int k = 0; k < 48; k++) acc[k] = 0.f;
-    float p[3] = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
-    for (int v = 0; v < V; v++) {
-        const float* g = drgb + (size_t)v * drgb_stride + (size_t)idx * 3;
-        const float d0 = g[0], d1 = g[1], d2 = g[2];
-        if (d0 == 0.f && d1 == 0.f && d2 == 0.f) continue;  // culled / fully clamped / not rendered in this view
-        if (means_stride) {
-            const float* mp = means3D + (size_t)v * means_stride + (size_t)idx * 3;
-            p[0] = mp[0]; p[1] = mp[1]; p[2] = mp[2];
-        }
-        const float* cp = campos + (size_t)v * campos_stride;
-        // same expressions as the per-view backward (sgr_gauss_bwd.hip)
-        const float ox = p[0] - cp[0], oy = p[1] - cp[1], oz = p[2] - cp[2];
-        const float len = sqrtf(ox * ox + oy * oy + oz * oz);
-        float Y[16];
-        sgr_sh_basis(D, ox / len, oy / len, oz / len, Y);
+    const float p0[3] = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+    // Views four at a time: the 12 (24 with per-view positions) loads of a group go out together, then the arithmetic
+    // runs on registers.  (One view per trip with an early `continue` made every view's loads wait for the previous
+    // view's arithmetic: at V = 8 the kernel was a chain of eight dependent round trips to HBM.)  The sum runs in view
+    // order whatever the grouping: deterministic and identical on every rank.
+    for (int v0 = 0; v0 < V; v0 += 4) {
+        float d[4][3], pp[4][3], cc[4][3];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            if (k < ncoef) {
-                acc[3 * k] += Y[k] * d0;
-                acc[3 * k + 1] += Y[k] * d1;
-                acc[3 * k + 2] += Y[k] * d2;
+        for (int j = 0; j < 4; j++) {
+            const int v = min(v0 + j, V - 1);  // clamped: the extra loads of a ragged last group are discarded
+            const float* g = drgb + (size_t)v * drgb_stride + (size_t)idx * 3;
+            d[j][0] = g[0]; d[j][1] = g[1]; d[j][2] = g[2];
+            if (means_stride) {
+                const float* mp = means3D + (size_t)v * means_stride + (size_t)idx * 3;
+                pp[j][0] = mp[0]; pp[j][1] = mp[1]; pp[j][2] = mp[2];
+            } else {
+                pp[j][0] = p0[0]; pp[j][1] = p0[1]; pp[j][2] = p0[2];
+            }
+            const float* cp = campos + (size_t)v * campos_stride;  // wave-uniform: scalar loads
+            cc[j][0] = cp[0]; cc[j][1] = cp[1]; cc[j][2] = cp[2];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (v0 + j >= V) break;
+            const float d0 = d[j][0], d1 = d[j][1], d2 = d[j][2];
+            if (d0 == 0.f && d1 == 0.f && d2 == 0.f) continue;  // culled / fully clamped / not rendered in this view
+            // same expressions as the per-view backward (sgr_gauss_bwd.hip)
+            const float ox = pp[j][0] - cc[j][0], oy = pp[j][1] - cc[j][1], oz = pp[j][2] - cc[j][2];
+            const float len = sqrtf(ox * ox + oy * oy + oz * oz);
+            float Y[16];
+            sgr_sh_basis(D, ox / len, oy / len, oz / len, Y);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (k < ncoef) {
+                    acc[3 * k] += Y[k] * d0;
+                    acc[3 * k + 1] += Y[k] * d1;
+                    acc[3 * k + 2] += Y[k] * d2;
+                }
             }
         }
     }
