@@ -100,6 +100,10 @@ typedef struct sgr_backward_extras {
     float* max_radii2D;        /* [P]   */
     const sgr_stat_segment* segments; /* host memory; NULL = identity map over the call's P Gaussians */
     int n_segments;
+    void* color_ready_event; /* optional hipEvent_t, recorded on `stream` right after the row-sum stage: dL_dmean2D,
+                              * dL_dopacity and dL_dcolor are FINAL from that event on, while the per-Gaussian stage (K12 + K13)
+                              * is still to run -- a view-sharded trainer starts the all-gather of its dRGB behind it
+                              * (street_gaussians_amd.multiview).  NULL: not recorded. */
     int rows; /* length of the three persistent arrays (rows); with segments every [dst_offset, dst_offset + count) must lie
                * inside [0, rows) and the destination ranges must be pairwise disjoint (two segments on the same rows would be
                * a racy read-modify-write) -- checked on the host, SGR_E_INVALID otherwise.  0 = unknown: not checked. */

@@ -70,7 +70,8 @@ class _StatSegment(C.Structure):  # sgr_stat_segment (include/sgr.h)
 
 class _BackwardExtras(C.Structure):  # sgr_backward_extras (include/sgr.h)
     _fields_ = [("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p), ("max_radii2D", C.c_void_p),
-                ("segments", C.POINTER(_StatSegment)), ("n_segments", C.c_int), ("rows", C.c_int)]
+                ("segments", C.POINTER(_StatSegment)), ("n_segments", C.c_int), ("color_ready_event", C.c_void_p),
+                ("rows", C.c_int)]
 
 
 MAX_STAT_SEGMENTS = 128  # SGR_MAX_STAT_SEGMENTS
@@ -159,16 +160,18 @@ def rasterize_gaussians(background, means3D, colors, semantics, opacity, scales,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                  dL_dout_alpha, dL_dout_semantic, sh, degree, campos, geomBuffer, R, binningBuffer,
-                                 imageBuffer, alphas, semantics, debug, stats=None):
+                                 imageBuffer, alphas, semantics, debug, stats=None, color_event=None):
     """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:126-220).  Returns
     (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dsemantic).
     stats (extension): (xyz_gradient_accum [P,2], denom [P,1], max_radii2D [P]) contiguous float32 tensors updated in
     place with this view's densification statistics (sgr_backward_ex); or a 4-tuple whose last element is a list of
     (src_start, count, dst_offset) segments mapping this call's Gaussians to rows of PERSISTENT statistics tensors of
-    any length (a frame renders a subset of the sub-models, street_gaussian_model.py:230-250)."""
+    any length (a frame renders a subset of the sub-models, street_gaussian_model.py:230-250).
+    color_event (extension): a torch.cuda.Event recorded on the current stream right after the row-sum stage, i.e. as
+    soon as dL_dcolors is final and before the per-Gaussian stage runs (sgr_backward_extras.color_ready_event)."""
     _dev_check(means3D, "means3D")
     ext = _pybind()
-    if ext is not None and stats is None:
+    if ext is not None and stats is None and color_event is None:
         e = torch.Tensor([])
         z = lambda t: e if t is None else t
         return _call_ext(ext.rasterize_gaussians_backward, z(background), means3D, radii, z(colors), z(scales), z(rotations),
@@ -224,7 +227,11 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                         raise SgrError("statistics segment outside the persistent tensors")
                     seg_arr[k] = _StatSegment(int(s0), int(cnt), int(d0))
                 keep.append(seg_arr)
-            extras = _BackwardExtras(acc.data_ptr(), den.data_ptr(), mr.data_ptr(), seg_arr, nseg, int(rows))
+            extras = _BackwardExtras(acc.data_ptr(), den.data_ptr(), mr.data_ptr(), seg_arr, nseg, None, int(rows))
+        if color_event is not None:
+            if extras is None:
+                extras = _BackwardExtras(None, None, None, None, 0, None, 0)
+            extras.color_ready_event = C.c_void_p(int(color_event.cuda_event))
         check(_native.lib().sgr_backward_ex(
             P, int(degree), M, int(R), S, p(background, "bg"), W, H, p(means3D, "means3D"), p(sh, "sh"),
             p(colors, "colors_precomp"), p(semantics, "semantics"), p(alphas, "alpha"), p(scales, "scales"),

@@ -43,7 +43,7 @@ void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, cons
                           const SgrGeomView& gv, const float* partials, int row_stride, const uint8_t* touched,
                           float4* cd, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dsemantic,
-                          const SgrStatSink& sink, int quad, int exact, int W, int H, hipStream_t s);
+                          const SgrStatSink& sink, int quad, int exact, int W, int H, hipEvent_t after_rows, hipStream_t s);
 void sgr_launch_blend_bwd_sw(bool exact, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W, int H,
                              const float* bg, const float4* rec, const uint32_t* u0, const float* alphas,
                              const uint32_t* n_contrib, const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth,
@@ -54,7 +54,7 @@ void sgr_launch_gauss_bwd_strict(int P, int D, int M, int S, const float* means3
                                  const SgrGeomView& gv, const float* partials, int row_stride, const uint8_t* touched,
                                  float4* cd, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                                  float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dsemantic,
-                                 const SgrStatSink& sink, int quad, int exact, int W, int H, hipStream_t s);
+                                 const SgrStatSink& sink, int quad, int exact, int W, int H, hipEvent_t after_rows, hipStream_t s);
 void sgr_launch_masked_color_grad(int P, const uint32_t* clamped, const float* dL_dcolor, float* out, hipStream_t s);
 void sgr_launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, size_t means_stride,
                                    const float* campos, size_t campos_stride, const float* drgb, size_t drgb_stride,
@@ -198,6 +198,11 @@ static hipError_t wait_for_readback(uint32_t* host_vals, hipEvent_t landed) {
     return hipEventSynchronize(landed);
 }
 
+static int pre_stage_min_p() {
+    static const int v = [] { const char* e = getenv("SGR_PRE_STAGE_MIN_P"); return e ? atoi(e) : 3000000; }();
+    return v;
+}
+
 // rasterizer_impl.cu:35-50
 static uint32_t getHigherMsb(uint32_t n) {
     uint32_t msb = sizeof(n) * 4;
@@ -331,7 +336,12 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     SGR_STAGE("pack_camera");
 
     sgr_launch_preprocess(P, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
-                          cam_slot(gv), gv, radii_ptr, prefiltered, (switches() & 64) != 0, stream);
+                          cam_slot(gv), gv, radii_ptr, prefiltered,
+                          // SH rows staged through LDS (half a wave's rows at a time) or read per lane: bit-identical forms
+                          // (tests); the staged one wins once the launch is deep enough to be throughput-bound -- measured
+                          // 346 vs 360 us at 5 M Gaussians, 98.8 vs 90.2 us at 1 M -- so it is chosen by P (switch bit 6
+                          // forces it, SGR_PRE_STAGE_MIN_P moves the threshold)
+                          (switches() & 64) != 0 || P >= pre_stage_min_p(), stream);
     SGR_STAGE("preprocess");
     prof_end(stream);
 
@@ -570,7 +580,7 @@ int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, 
     ((switches() & 128) ? sgr_launch_gauss_bwd_strict : sgr_launch_gauss_bwd)(
         P, D, M, S, means3D, radii_ptr, shs, scales, rotations, cov3D_precomp, cam_slot(gv), gv, partials, stride, touched, cd,
         dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, dL_dsemantic, sink, quad ? 1 : 0,
-        (switches() & 128) ? 1 : 0, W, H, stream);
+        (switches() & 128) ? 1 : 0, W, H, extras ? (hipEvent_t)extras->color_ready_event : nullptr, stream);
     SGR_STAGE("gauss_bwd");
     prof_end(stream);
     if (touched && ((switches() & (1 | 8)) != 0 || (S == 0 && !quad))) SGR_HIP(hipMemsetAsync(touched, 0, (size_t)R, stream));

@@ -368,7 +368,7 @@ void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, cons
                           const SgrGeomView& gv, const float* partials, int row_stride, const uint8_t* touched,
                           float4* cd, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dsemantic,
-                          const SgrStatSink& sink, int quad, int exact, int W, int H, hipStream_t s) {
+                          const SgrStatSink& sink, int quad, int exact, int W, int H, hipEvent_t after_rows, hipStream_t s) {
     if (P <= 0) return;
     const float lsc = exact ? 1.0f : SGR_LOG2E;
     const float kx = (0.5f * (float)W) / lsc, ky = (0.5f * (float)H) / lsc;
@@ -389,6 +389,7 @@ void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, cons
     else if (S <= 24) SGR_RS(24);
     else SGR_RS(32);
 #undef SGR_RS
+    if (after_rows) (void)hipEventRecord(after_rows, s);  // dL/dmean2D, dL/dopacity, dL/dcolour are final from here on
     sgr_gauss_bwd_kernel<<<nb, SGR_GB_THREADS, 0, s>>>(P, D, M, means3D, radii, shs, scales, rotations, cov3D_precomp, cam,
                                                        gv, cd, dL_dmean2D, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
                                                        dL_dscale, dL_drot);

@@ -350,7 +350,7 @@ class FactoredGradReducer:
         return sum(self.segments[m].n for m in self._frame[0])
 
     # -- rasterizer backward hook --
-    def _observe(self, grad_colors, geomBuffer, campos, sh_degree, num_points, means3D=None):
+    def _observe(self, grad_colors, geomBuffer, campos, sh_degree, num_points, means3D=None, color_ready=None):
         # the hook list is process-wide: passes over another Gaussian set (the reference's training step also renders
         # single objects, street_gaussian_renderer.render_object) are not this reducer's business
         models, idft = self._frame
@@ -358,6 +358,25 @@ class FactoredGradReducer:
             return
         if len(self._pending) >= self.k:
             raise RuntimeError(f"more than views_per_rank={self.k} rasterizer backward passes since the last exchange")
+        # dL/dcolour is final as soon as the backward's row-sum stage has run (`color_ready`, recorded between that stage
+        # and the per-Gaussian stage): the payload is packed on the exchange's side stream behind that event, so that the
+        # all-gather of begin() can start while the compute stream still runs K12 + K13 and whatever the caller queues next
+        side = self.dense._side
+        early = color_ready is not None and side is not None and (self.world > 1 or self.force)
+        if early:
+            side.wait_event(color_ready)
+            ctx = torch.cuda.stream(side)
+            for t in (grad_colors, geomBuffer, campos, means3D):
+                if t is not None and t.is_cuda:
+                    t.record_stream(side)
+        else:
+            import contextlib
+            ctx = contextlib.nullcontext()
+        self._packed_on_side = early
+        with ctx:
+            self._pack(grad_colors, geomBuffer, campos, sh_degree, num_points, means3D, models, idft)
+
+    def _pack(self, grad_colors, geomBuffer, campos, sh_degree, num_points, means3D, models, idft):
         if self._mask_fn is not None:
             drgb = self._mask_fn(geomBuffer, grad_colors, num_points)
         else:
@@ -426,11 +445,14 @@ class FactoredGradReducer:
         if self.world == 1 and not self.force:
             self._all.copy_(mine)  # one rank: its own views are all the views
             return
-        self.dense.begin()
+        side = self.dense._side
+        early = side is not None and getattr(self, "_packed_on_side", False)
+        if not early:
+            self.dense.begin()
         if self.world > 1 or dist.is_initialized():
-            side = self.dense._side
             if side is not None:
-                side.wait_stream(torch.cuda.current_stream(mine.device))
+                if not early:  # the payload was packed on the compute stream: order the gather behind it
+                    side.wait_stream(torch.cuda.current_stream(mine.device))
                 with torch.cuda.stream(side):
                     self._gather_works = [dist.all_gather_into_tensor(self._all, mine, group=self.group, async_op=True)]
                     for w in self._gather_works:
@@ -442,6 +464,10 @@ class FactoredGradReducer:
                 self._gather_works = [dist.all_gather_into_tensor(self._all, mine, group=self.group, async_op=True)]
         else:
             self._all.copy_(mine)
+        if early:
+            # the all-gather is already queued behind the packed payload; the dense bucket follows it on the side stream
+            # once the compute stream has produced every gradient
+            self.dense.begin()
 
     def _rebuild(self, n, means, means_stride, col0, V):
         """sum_v Y(dir_v) (x) dRGB_v for the n Gaussians whose dRGB sits at column col0 of the gathered rows -> [n, M, 3]."""

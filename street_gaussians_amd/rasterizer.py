@@ -39,6 +39,20 @@ def last_num_rendered() -> int:
 BACKWARD_OBSERVERS = []
 
 
+_COLOR_EVENTS = {}
+
+
+def _color_event(device):
+    """One event per device, created (first record) here so that the native side only re-records it."""
+    ev = _COLOR_EVENTS.get(device)
+    if ev is None:
+        ev = torch.cuda.Event()
+        with torch.cuda.device(device):
+            ev.record()
+        _COLOR_EVENTS[device] = ev
+    return ev
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, semantics, opacities, scales, rotations, cov3Ds_precomp,
@@ -95,22 +109,30 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raster_settings.sh_degree, raster_settings.campos, geomBuffer, num_rendered, binningBuffer, imgBuffer,
                 alpha, semantics, raster_settings.debug)
         stats = ctx.stats
+        # view-sharded training: the observers want dL/dcolour as early as it exists -- an event recorded between the row
+        # sum and the per-Gaussian stage (sgr_backward_extras.color_ready_event)
+        color_event = None
+        if BACKWARD_OBSERVERS and means3D.is_cuda:
+            color_event = _color_event(means3D.device)
         if raster_settings.debug:
             cpu_args = cpu_deep_copy_tuple(args)
             try:
                 (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
-                 grad_scales, grad_rotations, grad_semantics) = _C.rasterize_gaussians_backward(*args, stats=stats)
+                 grad_scales, grad_rotations, grad_semantics) = _C.rasterize_gaussians_backward(*args, stats=stats,
+                                                                                                 color_event=color_event)
             except Exception as ex:
                 torch.save(cpu_args, "snapshot_bw.dump")
                 print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise ex
         else:
             (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
-             grad_scales, grad_rotations, grad_semantics) = _C.rasterize_gaussians_backward(*args, stats=stats)
+             grad_scales, grad_rotations, grad_semantics) = _C.rasterize_gaussians_backward(*args, stats=stats,
+                                                                                             color_event=color_event)
 
         for observer in list(BACKWARD_OBSERVERS):  # view-sharded training (multiview.FactoredGradReducer)
             observer(grad_colors=grad_colors_precomp, geomBuffer=geomBuffer, campos=raster_settings.campos,
-                     sh_degree=raster_settings.sh_degree, num_points=means3D.shape[0], means3D=means3D)
+                     sh_degree=raster_settings.sh_degree, num_points=means3D.shape[0], means3D=means3D,
+                     color_ready=color_event)
 
         # same order as the reference (__init__.py:152-163); gradients of inputs that do not take part in
         # autograd (None / empty placeholders) are dropped instead of returned and ignored
