@@ -27,6 +27,14 @@ typedef int sgr_i16 __attribute__((ext_vector_type(16)));
 // whatever i is (hipcc, ROCm 7.2)
 __device__ __forceinline__ float sgr_sf(const int x) { return __builtin_bit_cast(float, x); }
 
+// lane-mask selects (m = all ones or zero): a & m, and (a & m) | (b & ~m) = v_bfi_b32
+__device__ __forceinline__ float sgr_and(const float a, const uint32_t m) {
+    return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, a) & m);
+}
+__device__ __forceinline__ float sgr_bfi(const uint32_t m, const float a, const float b) {
+    return __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, a) & m) | (__builtin_bit_cast(uint32_t, b) & ~m));
+}
+
 // One Gaussian record (64 bytes) into 16 SGPRs: `p` is wave-uniform and `rec` is read-only for the whole kernel, so
 // hipcc emits ONE s_load_dwordx16 for this load and keeps track of it itself (the s_waitcnt lgkmcnt(0) goes in front of
 // the first use).  (Issuing the load from an inline-asm statement and waiting in a second one does NOT work: the compiler
@@ -143,25 +151,36 @@ sgr_blend_bwd_sw_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
         // backward.cu:527-545.  No wave-wide early out: the hit record lists the visits that blended (plus the rare one
         // whose every passing pixel had finished on it; its row is flagged by the scan below and written as zeros here)
         const bool hit = (posj < lastc) && !(pw > 0.0f) && !(alpha < SGR_ALPHA_MIN);
-        float Gd = 0.0f, wm = 0.0f;
-        if (hit) {
+        // BRANCH-FREE: every lane runs the update and the per-pixel state is kept with selects.  An `if (hit)` costs
+        // nothing less on a SIMD (the other lanes idle) but splits the unit into basic blocks, and then the two visits of a
+        // unit cannot be interleaved: measured on MI355X (tools/ubench/valu_rates.hip) a wave's DEPENDENT plain VALU
+        // instructions issue every 4.3 cycles even with eight waves per SIMD, independent ones every 2.7.
+        float Gd, wm;
+        {
             const float oma = 1.0f - alpha;
             float inv1ma = __builtin_amdgcn_rcpf(oma);
             inv1ma = fmaf(fmaf(-oma, inv1ma, 1.0f), inv1ma, inv1ma);
-            T = EXACT ? sgr_div_by(T, oma, inv1ma) : T * inv1ma;  // backward.cu:547
-            wm = alpha * T;
+            const float Tn = EXACT ? sgr_div_by(T, oma, inv1ma) : T * inv1ma;  // backward.cu:547
             const float one_m_la = 1.0f - last_alpha;
-            Arec = fmaf(last_alpha, u_last, one_m_la * Arec);
+            const float An = fmaf(last_alpha, u_last, one_m_la * Arec);
             float u = fmaf(sgr_sf(R[8]), dLdC0, dLdA);
             u = fmaf(sgr_sf(R[9]), dLdC1, u);
             u = fmaf(sgr_sf(R[10]), dLdC2, u);
             u = fmaf(sgr_sf(R[11]), dLdD, u);
-            float d = u - Arec;
-            u_last = u;
-            last_alpha = alpha;
-            d *= T;
-            if (EXACT) Gd = bg_zero ? G * d : G * (d + sgr_div_by(-T_final, oma, inv1ma) * bgdot);
-            else Gd = G * fmaf(-T_final * inv1ma, bgdot, d);  // backward.cu:611-614
+            const float d = (u - An) * Tn;
+            float gd;
+            if (EXACT) gd = bg_zero ? G * d : G * (d + sgr_div_by(-T_final, oma, inv1ma) * bgdot);
+            else gd = G * fmaf(-T_final * inv1ma, bgdot, d);  // backward.cu:611-614
+            // selects as bit operations on an opaque lane mask: written as `hit ? a : b`, hipcc turns the six selects
+            // back into one branch over the whole block
+            uint32_t hm = hit ? 0xffffffffu : 0u;
+            asm volatile("" : "+v"(hm));
+            Gd = sgr_and(gd, hm);
+            wm = sgr_and(alpha * Tn, hm);
+            T = sgr_bfi(hm, Tn, T);
+            Arec = sgr_bfi(hm, An, Arec);
+            u_last = sgr_bfi(hm, u, u_last);
+            last_alpha = sgr_bfi(hm, alpha, last_alpha);
         }
         const float gxm = Gd * dx, gym = Gd * dy;
         float ax, ay;
@@ -266,6 +285,26 @@ sgr_blend_bwd_sw_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
                 left -= 2;
                 // first visit, then its record's registers take the next unit's first record (in flight under the second
                 // visit and the reduction); the same for the second
+#if SGR_SW_PREFETCH == 2
+                // both visits in ONE scheduling region (their arithmetic may interleave: independent instructions issue
+                // faster than dependent ones), both fetches behind it
+                pixel(RA, base - jA, v);
+                pixel(RB, base - jB, v + 12);
+                float* const rowA = rowptr(jA);
+                float* const rowB = rowptr(jB);
+                sgr_pin12a(v);
+                sgr_pin12b(v);
+                __builtin_amdgcn_sched_barrier(0);
+                sgr_keep(RA);
+                sgr_keep(RB);
+                if (left != 0) {
+                    jA = sgr_pop_lowest(m);
+                    jB = sgr_pop_lowest(m);
+                    issue(RA, jA);
+                    issue(RB, jB);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#else
                 pixel(RA, base - jA, v);
                 float* const rowA = rowptr(jA);
                 sgr_pin12a(v);
@@ -286,6 +325,7 @@ sgr_blend_bwd_sw_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
                     issue(RB, jB);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#endif
                 float g0, g1;
                 sgr_wave_reduce_fold24(v, g0, g1);
                 if (st_a) rowA[vidx] = g0;

@@ -14,7 +14,7 @@
 #define KERNEL(name, body)                                                                               \
     __global__ void __launch_bounds__(256) name(float* out, int iters) {                                \
         float a = threadIdx.x * 1e-3f + 1.0f, b = a + 0.5f, c = a + 0.25f, d = a + 0.125f;              \
-        for (int i = 0; i < iters; i++) { asm volatile(REP16(body) : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); } \
+        for (int i = 0; i < iters; i++) { asm volatile(REP16(body) : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "vcc", "scc"); } \
         out[blockIdx.x * 256 + threadIdx.x] = a + b + c + d;                                            \
     }
 
@@ -32,12 +32,12 @@ KERNEL(k_cndmask, "v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc
 KERNEL(k_cmp, "v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %2\n v_cmp_lt_f32 vcc, %2, %3\n v_cmp_lt_f32 vcc, %3, %0\n")
 // scalar side: s_nop and simple SALU, to see what a scalar instruction costs next to nothing else
 __global__ void __launch_bounds__(256) k_snop(float* out, int iters) {
-    for (int i = 0; i < iters; i++) asm volatile(REP64("s_nop 0\n"));
+    for (int i = 0; i < iters; i++) asm volatile(REP64("s_nop 0\n") ::: "scc");
     out[blockIdx.x * 256 + threadIdx.x] = 1.f;
 }
 __global__ void __launch_bounds__(256) k_salu(float* out, int iters) {
     int s = iters;
-    for (int i = 0; i < iters; i++) asm volatile(REP64("s_add_u32 %0, %0, 1\n") : "+s"(s));
+    for (int i = 0; i < iters; i++) asm volatile(REP64("s_add_u32 %0, %0, 1\n") : "+s"(s) : : "scc");
     out[blockIdx.x * 256 + threadIdx.x] = (float)s;
 }
 // dependent chains: ONE chain per wave (latency of back-to-back dependent issue)
@@ -58,7 +58,7 @@ static void run(const char* name, F kernel, float* out, int waves_per_simd, int 
     hipGetDeviceProperties(&p, 0);
     const int cus = p.multiProcessorCount;
     const int blocks = cus * waves_per_simd;  // 256 threads = 4 waves = one per SIMD
-    const int iters = 2000;
+    const int iters = 400;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -74,13 +74,14 @@ static void run(const char* name, F kernel, float* out, int waves_per_simd, int 
     const double cyc = ms * 1e-3 * clock_ghz * 1e9 / insts_per_simd;
     printf("{\"inst\": \"%s\", \"waves_per_simd\": %d, \"ms\": %.3f, \"simd_cycles_per_wave_inst_at_%.1fGHz\": %.2f}\n", name,
            waves_per_simd, ms, clock_ghz, cyc);
+    fflush(stdout);
 }
 
 int main() {
     float* out;
     hipMalloc(&out, 256 * 256 * 64 * sizeof(float));
     const double ghz = 2.4;
-    for (int w : {8, 2, 1}) {
+    for (int w : {8, 1}) {
         run("v_fma_f32", k_fma, out, w, 64, ghz);
         run("v_mul_f32", k_mul, out, w, 64, ghz);
         run("v_exp_f32", k_exp, out, w, 64, ghz);
