@@ -84,7 +84,7 @@ static int switches() {
     if (v < 0) {
         v = (env_flag("SGR_NO_CULL") ? 1 : 0) | (env_flag("SGR_NO_DPP") ? 2 : 0) | (env_flag("SGR_NO_DET") ? 4 : 0) |
             (env_flag("SGR_NO_HITS") ? 8 : 0) | (env_flag("SGR_V2") ? 16 : 0) | (env_flag("SGR_PRE_STAGE") ? 64 : 0) |
-            (env_flag("SGR_EXACT") ? 128 : 0) | ((env_flag("SGR_SW8") || env_flag("SGR_NO_SW")) ? 256 : 0) | (env_flag("SGR_SW9") ? 512 : 0);
+            (env_flag("SGR_EXACT") ? 128 : 0) | ((env_flag("SGR_SW8") || env_flag("SGR_SW")) ? 256 : 0) | (env_flag("SGR_SW9") ? 512 : 0);
         g_switches.store(v, std::memory_order_relaxed);
     }
     return v;
@@ -533,11 +533,13 @@ int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, 
     const SgrImgView iv = sgr_img_carve(image_buffer, N, T);
     const int* radii_ptr = radii ? radii : gv.internal_radii;
     const int stride = sgr_partial_row_stride(S);
-    // Which blend backward runs.  The scalar walk (sgr_blend_bwd_sw.hip; S = 0, the shipped switch settings: hit record,
-    // cull, DPP reduction, deterministic) writes FOUR rows per (tile, instance), one per quadrant; everything else goes
-    // through the LDS-staged kernel with its one combined row.  Switch bit 8 (SGR_NO_SW=1) forces the LDS kernel (A/B).
+    // Which blend backward runs.  Default: the LDS-staged kernel (sgr_blend_bwd.hip).  Switch bit 8 (SGR_SW=1) selects the
+    // scalar walk (sgr_blend_bwd_sw.hip; S = 0 with the hit record, cull, DPP reduction and deterministic combine on): it
+    // writes FOUR rows per (tile, instance), one per quadrant.  A second design that was built, is parity-tested and
+    // measured 11 % slower per step: both kernels sit at the VALU issue bound of the same per-visit
+    // arithmetic, and the per-quadrant rows cost the row sum more than the barriers cost the LDS kernel.
     const int sw_all = switches();
-    const bool quad = S == 0 && R > 0 && (sw_all & (1 | 2 | 4 | 8 | 16 | 256)) == 0;
+    const bool quad = S == 0 && R > 0 && (sw_all & 256) != 0 && (sw_all & (1 | 2 | 4 | 8 | 16)) == 0;
     // scratch = [P float4: conic + depth terms between the two per-Gaussian stages][R (or 4 R) partial rows]
     const size_t cd_bytes = sgr_align_up((size_t)P * sizeof(float4), 256);
     const size_t bytes = sgr_align_up((size_t)R * (quad ? 4u : 1u) * stride * sizeof(float), 256);
@@ -554,9 +556,9 @@ int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, 
         const SgrBinView bv = sgr_bin_carve(binning_buffer, (size_t)R);
         touched = bv.touched;
         const int cur = sorted_index(W, H);
-        // (S = 0: the scalar walk leaves quadrant MASKS in these bytes and the LDS kernel ones; any switch that routes an
-        // S = 0 backward through the LDS kernel therefore clears them before and after as well)
-        const bool odd_set = (switches() & (1 | 8)) != 0 || (S == 0 && !quad);
+        // (the scalar walk leaves quadrant MASKS in these bytes and the LDS kernel ones: a scalar-walk backward clears them
+        // before and after itself, so that the two kernels can follow each other over one forward)
+        const bool odd_set = (switches() & (1 | 8)) != 0 || quad;
         prof_begin(6, stream);
         if (odd_set) SGR_HIP(hipMemsetAsync(touched, 0, (size_t)R, stream));
         prof_end(stream);
@@ -583,7 +585,7 @@ int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, 
         (switches() & 128) ? 1 : 0, W, H, extras ? (hipEvent_t)extras->color_ready_event : nullptr, stream);
     SGR_STAGE("gauss_bwd");
     prof_end(stream);
-    if (touched && ((switches() & (1 | 8)) != 0 || (S == 0 && !quad))) SGR_HIP(hipMemsetAsync(touched, 0, (size_t)R, stream));
+    if (touched && ((switches() & (1 | 8)) != 0 || quad)) SGR_HIP(hipMemsetAsync(touched, 0, (size_t)R, stream));
     return 0;
 }
 

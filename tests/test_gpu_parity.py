@@ -145,6 +145,26 @@ def test_backward_matches_oracle(name):
     fw.free()
 
 
+@pytest.mark.parametrize("name", [n for n in CASES if n not in ILL_CONDITIONED and CASES[n][1].semantics.shape[1] == 0])
+def test_scalar_walk_backward_matches_oracle(name):
+    """The second blend-backward design (csrc/sgr_blend_bwd_sw.hip, switch USE_SW / SGR_SW=1: a wave owns its quadrant, records
+    through the scalar cache, four rows per instance) is held to the same gates as the shipped kernel, in both modes."""
+    cam, sc, kw = _kw(name)
+    wts = syn.loss_weights(cam, S=0)
+    fw = oracle.forward(**kw)
+    res, _ = raw_forward(kw)
+    with switches(_C.USE_SW):
+        g = raw_backward(kw, res, wts)
+    same = oracle_backward_same_state(oracle, fw, res, wts, 0)
+    for k in GRAD_KEYS:
+        grad_close(npy(g[k]).reshape(same[k].shape), same[k], name=f"scalar walk same-state {name}:{k}", **SAME_STATE_GATE)
+    fw.free()
+    from oracle import ref
+    if ref.available():
+        with switches(_C.USE_SW):
+            exact_mode_against_reference_kernels(kw, wts, 0, f"scalar walk {name}", allow=EXACT_ALLOW.get(name))
+
+
 def _color_mag(fw, wts):
     """sum_pix w*|dL/dC| per Gaussian = the sum of |terms| behind dL/drgb (and, through Y_k(dir), dL/dSH): the
     oracle's backward run with absolute-valued colour weights and nothing else."""
@@ -182,22 +202,22 @@ def test_culling_is_invisible_and_backward_is_deterministic(name):
     cam, sc, kw = _kw(name)
     wts = syn.loss_weights(cam, S=sc.semantics.shape[1])
     res_a, int_a = raw_forward(kw)
-    g_s = raw_backward(kw, res_a, wts)  # the shipped path (S = 0: the scalar-walk kernel)
-    g_s2 = raw_backward(kw, res_a, wts)
-    for k in g_s:
-        assert torch.equal(g_s[k], g_s2[k]), f"{k} not deterministic"
-    # the A/B switches below all run the LDS-staged kernel: it is their bit-for-bit baseline (switch NO_SW); the scalar walk
-    # sums the same terms in another order (per quadrant, moments -> gradients once per Gaussian): equal up to rounding
-    with switches(_C.NO_SW):
-        g_a = raw_backward(kw, res_a, wts)
-        g_a2 = raw_backward(kw, res_a, wts)
+    g_a = raw_backward(kw, res_a, wts)
+    g_a2 = raw_backward(kw, res_a, wts)
     for k in g_a:
-        assert torch.equal(g_a[k], g_a2[k]), f"{k} not deterministic (LDS-staged kernel)"
+        assert torch.equal(g_a[k], g_a2[k]), f"{k} not deterministic"
+    # the scalar-walk kernel (switch USE_SW; S = 0 only, other widths fall through to the LDS kernel): the same terms summed
+    # in another order (per quadrant, moments -> gradients once per Gaussian) -- deterministic, equal up to rounding, and
+    # the row flags of the two kernels do not leak into each other when they follow one another over one forward
+    with switches(_C.USE_SW):
+        g_s = raw_backward(kw, res_a, wts)
+        g_s2 = raw_backward(kw, res_a, wts)
+    g_a3 = raw_backward(kw, res_a, wts)
+    for k in g_a:
+        assert torch.equal(g_s[k], g_s2[k]), f"{k} not deterministic (scalar walk)"
+        assert torch.equal(g_a[k], g_a3[k]), f"{k} changed after a scalar-walk backward over the same forward"
         if name not in ILL_CONDITIONED:
             grad_close(npy(g_s[k]), npy(g_a[k]), rel=1e-4, abs_frac=2e-5, name=f"scalar walk vs LDS kernel:{k}", max_outlier_frac=0.0)
-    g_s3 = raw_backward(kw, res_a, wts)  # and back: the row flags of the two kernels do not leak into each other
-    for k in g_s:
-        assert torch.equal(g_s[k], g_s3[k]), f"{k} changed after an LDS-kernel backward over the same forward"
     with switches(_C.NO_HITS):  # geometric cull instead of the hit record: a superset of the same visits
         g_h = raw_backward(kw, res_a, wts)
     for k in g_a:
@@ -210,9 +230,13 @@ def test_culling_is_invisible_and_backward_is_deterministic(name):
         g_b = raw_backward(kw, res_b, wts)
     for k in g_a:  # same pairs, same order: the cull must not change the gradients at all
         assert torch.equal(g_a[k], g_b[k]), f"cull changed dL/d{k}"
-    g_b2 = raw_backward(kw, res_b, wts)  # hit record written by the un-culled forward, walked by the shipped kernel
+    g_b2 = raw_backward(kw, res_b, wts)  # hit record written by the un-culled forward
+    for k in g_a:
+        assert torch.equal(g_a[k], g_b2[k]), f"hit record of the un-culled forward changed dL/d{k}"
+    with switches(_C.USE_SW):  # ... and walked by the scalar-walk kernel
+        g_b3 = raw_backward(kw, res_b, wts)
     for k in g_s:
-        assert torch.equal(g_s[k], g_b2[k]), f"hit record of the un-culled forward changed dL/d{k}"
+        assert torch.equal(g_s[k], g_b3[k]), f"scalar walk: hit record of the un-culled forward changed dL/d{k}"
     with switches(_C.USE_ONESWEEP):  # the radix sorts in their one-sweep A/B form: the same order, bit for bit
         res_s, int_s = raw_forward(kw)
         for k in ["keys", "point_list", "ranges", "point_offsets"]:
