@@ -72,6 +72,11 @@ def parse():
                          "a side stream under the NEXT step's forward (gradients one step late).  With the default the overlap "
                          "schedule is measured as an extra region and printed under `exchange_overlap`")
     ap.add_argument("--densify-every", type=int, default=10, help="configs[4] loop: one densify_and_prune every k iterations")
+    ap.add_argument("--densify-loop", action="store_true",
+                    help="N > 1: also run BASELINE configs[4] as worded -- 5 M replicated Gaussians, one view per rank, "
+                         "gradient exchange every step, REPLICATED densify / prune every --densify-every steps -- and print it "
+                         "under `configs4_densify_loop` (every rank takes part; off by default so that a scaling run stays short)")
+    ap.add_argument("--densify-gaussians", type=int, default=5_000_000)
     ap.add_argument("--step-times", action="store_true", help="debug: also print 10 individually synchronised steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the 500k / 2M+S19 / 5M runs (N = 1 only)")
@@ -299,19 +304,26 @@ class DensifyLoop:
     and ~5 % pruned per step.  reset_opacity (train.py:207-208) is exercised by tests/test_gpu_densify_loop.py, not here:
     it makes every splat transparent, i.e. it would replace the stress workload by a trivial one."""
 
-    def __init__(self, args, P, dev, densify_every):
+    def __init__(self, args, P, dev, densify_every, dist=None, rank=0, force_dist=False):
+        """dist != None (N > 1, or a forced one-rank group): the configuration as BASELINE.json words it -- Gaussians
+        replicated, one camera view per rank, gradients exchanged every step, and the densify step REPLICATED: per-view
+        statistics combined across ranks, the same densify_and_prune with the same normals on every rank
+        (multiview.densify_replicated), reducers rebuilt for the new P."""
         from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
         self.args, self.dev, self.every = args, dev, max(1, densify_every)
+        self.dist, self.rank, self.force_dist = dist, rank, force_dist
+        self.reducer = self.normals = None
         W, H = args.width, args.height
-        cam = self.cam = syn.make_camera(W, H, fx=2050.0 * W / 1920.0)
-        sc = syn.make_scene(P, cam, sh_degree_max=3, S=0, seed=0)
+        cam0 = syn.make_camera(W, H, fx=2050.0 * W / 1920.0)
+        cam = self.cam = syn.make_camera(W, H, fx=2050.0 * W / 1920.0, yaw_deg=5.0 * rank)
+        sc = syn.make_scene(P, cam0, sh_degree_max=3, S=0, seed=0)  # identical Gaussians on every rank
         d = lambda t: t.to(dev).contiguous()
         op = sc.opacities.clamp(1e-6, 1 - 1e-6)
         # raw parameters as the reference's GaussianModel stores them (gaussian_model.py:120-127)
         self.params = {"xyz": d(sc.means3D), "f_dc": d(sc.shs[:, :1, :]), "f_rest": d(sc.shs[:, 1:, :]),
                        "opacity": d(torch.log(op / (1 - op))), "scaling": d(torch.log(sc.scales)), "rotation": d(sc.rotations)}
         self.states = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in self.params.items()}
-        self.w = {k: v.to(dev) for k, v in syn.loss_weights(cam, S=0, seed=1).items()}
+        self.w = {k: v.to(dev) for k, v in syn.loss_weights(cam, S=0, seed=1 + rank).items()}
         self.st = GaussianRasterizationSettings(
             image_height=H, image_width=W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=torch.zeros(3, device=dev),
             scale_modifier=1.0, viewmatrix=cam.viewmatrix.to(dev), projmatrix=cam.projmatrix.to(dev), sh_degree=3,
@@ -321,6 +333,13 @@ class DensifyLoop:
         self.log = []
         self.max_R = 0
         self._activate()
+        if dist is not None:
+            from street_gaussians_amd import multiview
+            i = self.inputs
+            self.reducer = multiview.FactoredGradReducer([i[k] for k in ("means3D", "scales", "rotations", "opacities")],
+                                                         i["shs"], i["means3D"], force=force_dist)
+            self.reducer.warm_up()
+            self.normals = multiview.ReplicatedNormals(seed=17)
 
     def _activate(self):
         from street_gaussians_amd import scene
@@ -343,6 +362,8 @@ class DensifyLoop:
         color, radii, depth, alpha, _ = self.rast(i["means3D"], self.means2D, i["opacities"], shs=i["shs"],
                                                   scales=i["scales"], rotations=i["rotations"])
         torch.autograd.backward([color, depth, alpha], [w["color"], w["depth"], w["alpha"]])
+        if self.reducer is not None:
+            self.reducer.all_reduce()  # blocking exchange: the step's summed gradients
         self.max_R = max(self.max_R, rasterizer.last_num_rendered())
 
     def calibrate(self):
@@ -361,20 +382,39 @@ class DensifyLoop:
     def densify(self):
         from street_gaussians_amd import densify
         torch.cuda.synchronize()
+        t_r = time.perf_counter()
+        if self.dist is not None:
+            # replicated densify, step 1: the per-view statistics of all ranks become one (sums / max) -- part of the path
+            from street_gaussians_amd import multiview
+            multiview.reduce_densification_stats(self.stats.xyz_gradient_accum, self.stats.denom, self.stats.max_radii2D)
+            torch.cuda.synchronize()
         t_c = time.perf_counter()
         self.calibrate()  # this synthetic schedule's thresholds (quantiles): not part of the path, excluded from the totals
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()     # (computed from the combined statistics: the same thresholds on every rank)
         t0 = time.perf_counter()
         self.calib_s += t0 - t_c
+        t0 -= t_c - t_r  # the statistics reduce counts as densify time
+        # step 2: the same densify_and_prune on every rank, with the same normals (multiview.ReplicatedNormals)
         new_p, new_s, scal, _ = densify.densify_and_prune(self.params, self.stats.xyz_gradient_accum, self.stats.denom,
-                                                          states=self.states, **self.kw)
+                                                          states=self.states, normal_source=self.normals, **self.kw)
         self.params, self.states = new_p, new_s
         self._activate()
+        if self.reducer is not None:
+            i = self.inputs
+            self.reducer.rebuild([i[k] for k in ("means3D", "scales", "rotations", "opacities")], i["shs"], i["means3D"])
         torch.cuda.synchronize()
         scal = dict(scal)
         scal["ms"] = round(1e3 * (time.perf_counter() - t0), 3)
         scal["gaussians_after"] = self.P
         self.log.append(scal)
+
+    def _replicas_identical(self):
+        """After the run: are the raw parameters and Adam moments bit-identical on all ranks?  (None with one process.)"""
+        if self.dist is None:
+            return None
+        from street_gaussians_amd import multiview
+        ts = [self.params[k] for k in sorted(self.params)] + [t for k in sorted(self.states) for t in self.states[k]]
+        return bool(multiview.replicas_identical(ts))
 
     def run(self, fence, n_densify=3):
         every = self.every
@@ -433,6 +473,8 @@ class DensifyLoop:
                 "allocator": {k: int(torch.cuda.memory_stats(self.dev).get(k, 0)) for k in
                               ("num_alloc_retries", "num_ooms", "num_device_free", "reserved_bytes.all.peak",
                                "allocated_bytes.all.peak")},
+                "ranks": (self.dist.get_world_size() if self.dist is not None else 1),
+                "replicas_identical": self._replicas_identical(),
                 "max_num_rendered_R": self.max_R, "thresholds_last": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in self.kw.items()},
                 "note": "rasterizer forward+backward every iteration with the fused densification-statistics sink; "
                         "densify_and_prune (plan + gather kernels, raw parameters + 12 Adam moment tensors) every "
@@ -664,6 +706,17 @@ def main():
             wl.step()
     R, V, pairs_blended = wl.counts()
     N = args.width * args.height
+    # N > 1 (or a forced one-rank group) with --densify-loop: configs[4] as BASELINE.json words it, every rank taking part
+    densify_multi = None
+    if args.densify_loop and dist is not None:
+        torch.cuda.empty_cache()
+        loop = DensifyLoop(args, args.densify_gaussians, dev, args.densify_every, dist=dist, rank=rank, force_dist=force_dist)
+        densify_multi = loop.run(fence)
+        t = torch.tensor([densify_multi["ms_per_step_amortised"]], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        densify_multi["ms_per_step_amortised_max_over_ranks"] = round(float(t.item()), 4)
+        densify_multi["views_per_s_whole_job"] = round(world * 1e3 / float(t.item()), 3)
+        del loop
 
     if rank == 0:
         bwd_ms = timed["blend_bwd"]
@@ -772,6 +825,8 @@ def main():
             line["exchange_overlap"] = exchange_overlap
         if world == 1 and dist is None and not args.no_other_configs and not args.scene:
             line["other_configs"] = other_configs(args, L, dev, fence)
+        if densify_multi is not None:
+            line["configs4_densify_loop"] = densify_multi
         if not args.no_cpu_baseline and world == 1:
             try:
                 rk = reference_kernels_on_gpu(args, wl.cam, wl.scene)

@@ -109,6 +109,28 @@ def test_bench_runs_the_rccl_exchange_on_one_rank():
         assert (mode == "blocking") == ("exchange_overlap" in line)
 
 
+def test_bench_runs_the_replicated_densify_loop_on_a_forced_group():
+    """bench.py --densify-loop with a forced one-rank RCCL group: BASELINE configs[4]'s multi-rank program (gradient exchange
+    every step, statistics reduce, replicated densify with ReplicatedNormals, reducer rebuild for the new P) end to end on
+    the GPU at a small size; the world-2 logic itself is tests/test_multiview_gloo.py."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SGR_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", RANK="0", WORLD_SIZE="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
+                          "--gaussians", "100000", "--no-cpu-baseline", "--no-other-configs", "--densify-loop",
+                          "--densify-gaussians", "200000", "--densify-every", "4"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().split("\n")[-1])
+    d = line["configs4_densify_loop"]
+    assert d["ranks"] == 1 and d["replicas_identical"] is True and d["densify_steps"] == 3
+    assert d["gaussians_end"] != d["gaussians_start"] and d["ms_per_step_amortised"] > 0
+    assert line["rccl_ranks"] == 1
+
+
 def test_async_exchange_matches_blocking_exchange():
     """GradReducer / FactoredGradReducer: begin() + wait() give the same gradients as all_reduce(), also when the next
     step's work is queued in between (one-rank RCCL group)."""

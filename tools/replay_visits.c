@@ -9,7 +9,8 @@
 // out[3]=sum over (wave,batch) max over 2 8x4 halves, out[4]=lane hits total, out[5]=sum of 4x4 block visits,
 // out[6]=sum over waves (no batching) of max over 4x4 blocks, out[7]=# (tile,batch) rounds,
 // out[8]=sum over (tile,batch) of max over 16 blocks (whole-WG lockstep), out[9]=sum 8x4 half visits,
-// out[10]=sum over rounds of the busiest quadrant's visits, out[11]=sum over rounds of the mean over the four quadrants
+// out[10]=sum over rounds of the busiest quadrant's visits, out[11]=sum over rounds of the mean over the four quadrants,
+// out[12]=quadrant visits whose hits lie in one 32-lane half, out[13]=... in one 16-lane row
 void replay(int W, int H, const uint32_t* ranges, const uint32_t* plist, const float* m2d, const float* co,
             const uint32_t* ncontrib, int batch, double* out, float* tile_cost) {
   int gx = (W + 15) / 16, gy = (H + 15) / 16;
@@ -52,7 +53,14 @@ void replay(int W, int H, const uint32_t* ranges, const uint32_t* plist, const f
           }
           a[4] += lanes;
           for (int q = 0; q < 4; ++q) {
-            if (hq >> q & 1) { a[0] += 1; cq[q]++; }
+            if (hq >> q & 1) {
+              a[0] += 1; cq[q]++;
+              // hits confined to one 32-lane half (pixel rows 0-3 or 4-7 of the quadrant) / to one 16-lane DPP row: the
+              // cross-half (cross-row) stage of the wave reduction would have nothing to add for such a visit
+              const uint32_t hv = h84 >> (q * 2) & 3u, rv = h82 >> (q * 4) & 15u;
+              if (hv == 1u || hv == 2u) a[12] += 1;
+              if ((rv & (rv - 1u)) == 0u) a[13] += 1;
+            }
             for (int k = 0; k < 4; ++k) { c44[q][k] += h44 >> (q * 4 + k) & 1; c82[q][k] += h82 >> (q * 4 + k) & 1; }
             for (int k = 0; k < 2; ++k) c84[q][k] += h84 >> (q * 2 + k) & 1;
           }

@@ -28,8 +28,11 @@ out = np.zeros(16); cost = np.zeros(gx * gy, np.float32)
 arrs = [np.ascontiguousarray(x) for x in (fw.ranges.astype(np.uint32), fw.point_list.astype(np.uint32), fw.means2D.astype(np.float32), fw.conic_opacity.astype(np.float32), fw.n_contrib.astype(np.uint32))]
 L.replay(1920, 1280, *[p(a) for a in arrs], 128, p(out), p(cost))
 names = ["quadrant_visits", "max4_4x4_per_batch", "max4_8x2_per_batch", "max2_8x4_per_batch", "lane_hits", "sum_4x4_visits",
-         "max4_4x4_nobatch", "rounds", "max16_per_batch", "sum_8x4_visits", "sum_round_max_quadrant", "sum_round_mean_quadrant"]
+         "max4_4x4_nobatch", "rounds", "max16_per_batch", "sum_8x4_visits", "sum_round_max_quadrant", "sum_round_mean_quadrant",
+         "visits_confined_to_one_half", "visits_confined_to_one_row"]
 print({n: float(out[i]) for i, n in enumerate(names)})
+if os.environ.get("SGR_SIM_STATS_ONLY"):
+    sys.exit(0)
 # barrier skew of the walk: a round ends when its busiest quadrant is done; the other three waves wait at the barrier
 for rb in (64, 128, 256, 512, 1 << 20):
     o2 = np.zeros(16); c2 = np.zeros(gx * gy, np.float32)
