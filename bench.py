@@ -527,6 +527,33 @@ def profiled_steps(L, wl, fence, steps, stage_mask, every=1):
     return dt, {STAGES[i]: (sums[i] / counts[i] if counts[i] else None) for i in range(9)}
 
 
+def count_visits(wl, R):
+    """Contributing (quadrant, instance) visits of this view = what the blend backward walks: the bits of the forward's hit
+    record at list positions below the tile's highest n_contrib (entries behind the last batch a tile processed are
+    undefined).  Untimed; torch ops on the exported internals."""
+    from street_gaussians_amd import _C as native
+    st, p = wl.st, wl.params
+    H, W = wl.args.height, wl.args.width
+    out = native.rasterize_gaussians(st.bg, p["means3D"].detach(), torch.Tensor([]), torch.zeros(wl.P, 0, device=wl.dev),
+                                     p["opacities"].detach(), p["scales"].detach(), p["rotations"].detach(), 1.0, torch.Tensor([]),
+                                     st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy, st.image_height, st.image_width,
+                                     p["shs"].detach(), 3, st.campos, False, False)
+    R = int(out[0])
+    exp = lambda name: native.export_internal(name, wl.P, R, H, W, out[6], out[7], out[8])
+    nc = exp("n_contrib").view(H, W).to(torch.int64)
+    gy, gx = (H + 15) // 16, (W + 15) // 16
+    pad = torch.zeros(gy * 16, gx * 16, dtype=torch.int64, device=nc.device)
+    pad[:H, :W] = nc
+    maxc = pad.view(gy, 16, gx, 16).amax(dim=(1, 3)).reshape(-1)
+    rg = exp("ranges").view(-1, 2).to(torch.int64)
+    cnt = rg[:, 1] - rg[:, 0]
+    tile = torch.repeat_interleave(torch.arange(gy * gx, device=nc.device), cnt)
+    pos = torch.arange(R, device=nc.device) - rg[tile, 0]
+    hit = exp("hits")[:R].to(torch.int64)
+    bits = (hit & 1) + ((hit >> 1) & 1) + ((hit >> 2) & 1) + ((hit >> 3) & 1)
+    return int(bits[pos < maxc[tile]].sum().item())
+
+
 def blend_bytes(S, R, N, V):
     """SURVEY 8d algorithmic bytes per launch: B_blend_b, B_blend_f."""
     return (44 + 4 * S) * R + (28 + 4 * S) * N + (48 + 4 * S) * V, (44 + 4 * S) * R + (24 + 4 * S) * N
@@ -760,6 +787,24 @@ def main():
                         "what": "exactly --steps steps between two fences (barrier + synchronize)"}
         if sustained is not None:
             value, ms_per_step = sustained["iters_per_s"], sustained["ms_per_step"]
+        # the bound the dominant kernel actually runs against: VALU issue.  Per-visit pipe cycles from the static model of the
+        # kernel's ISA priced with MEASURED instruction costs (tools/valu_model.py, tools/ubench/valu_rates.hip), times the
+        # visits of this frame, over the 1024 SIMDs
+        valu_issue = None
+        try:
+            vm = json.load(open(os.path.join(ROOT, "profiles", "r4", "valu_model.json")))
+            if S == 0 and bwd_ms and vm["default"].get("source_sha16") == sgr_build.source_sha16():
+                visits = count_visits(wl, R)
+                cyc = vm["default"]["valu_pipe_cycles_per_visit"]
+                bound_ms = visits * cyc / (1024 * 2.4e9) * 1e3
+                valu_issue = {"bound": "valu_issue", "visits": visits, "valu_pipe_cycles_per_visit": cyc,
+                              "bound_ms": round(bound_ms, 4), "kernel_ms": round(bwd_ms, 4), "frac": round(bound_ms / bwd_ms, 3),
+                              "source": "profiles/r4/valu_model.json (static ISA model x measured instruction costs, "
+                                        "profiles/r4/valu_rates.jsonl); time bound = visits * cycles / (1024 SIMDs * ubench clock)"}
+            elif S == 0:
+                valu_issue = {"note": "profiles/r4/valu_model.json was made for other kernel sources: re-run tools/valu_model.py"}
+        except Exception as ex:
+            valu_issue = {"note": f"unavailable: {ex}"[:160]}
         line = {
             "metric": "train iters/s (fwd+bwd) @1M Gaussians 1920x1280 SH3",
             "value": value,
@@ -799,7 +844,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernel_name,
                          "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": traffic,
-                         "traffic_note": traffic_note, "valu": valu, "pmc": pmc_derived,
+                         "traffic_note": traffic_note, "valu": valu, "valu_issue": valu_issue, "pmc": pmc_derived,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "kernel_ms": round(bwd_ms, 4) if bwd_ms else None,
                          "kernel_ms_source": f"HIP events around the kernel on its launch stream, mean over "
@@ -814,8 +859,9 @@ def main():
                          "stages_bytes_source": "SURVEY 8d algorithmic bytes (B_pre, B_scan, B_dup, B_sort = 24 R, B_rng, "
                                                 "B_blend_f, B_blend_b, B_pre_b); frac = bytes / stage time / 8 TB/s",
                          "sum_n_contrib_pairs": pairs_blended,
-                         "note": "blend kernels are VALU/exp/LDS bound (SURVEY 8d); HBM fraction is reported as the "
-                                 "metric demands"},
+                         "note": "the blend kernels are VALU-issue bound (SURVEY 8d; `valu_issue`: the backward runs at that "
+                                 "fraction of its pipes' capacity at measured instruction costs); the HBM fraction is reported "
+                                 "as the metric demands"},
         }
         if sustained is not None:
             line["sustained"] = sustained
