@@ -9,6 +9,8 @@
 // torch::zeros (rasterize_points.cu:166-176).
 #include "sgr_math.h"
 
+#include <cstdlib>
+
 #ifndef SGR_GB_THREADS
 #define SGR_GB_THREADS 256
 #endif
@@ -162,6 +164,144 @@ sgr_row_sum_kernel(int P, int S, const int* __restrict__ radii, SgrGeomView gv, 
 #pragma unroll
         for (int ch = 0; ch < SMAX; ch++)
             if (ch < S && (ch & 3) == (q & 3) && q < 4) dL_dsemantic[(size_t)idx * S + ch] = acc[SGR_ROW_BASE_N + ch];
+    }
+}
+
+// ---- stage 1, wave-cooperative form (default since round 4) -----------------------------------------------------------
+// The rows are in INDEX order (u0 = exclusive scan of tiles_touched over the Gaussians, culled ones contributing none), so
+// the 64 Gaussians of a wave own ONE contiguous row range [ua, ub).  The wave streams it 64 rows at a time -- lane l takes
+// row cbase + l: one coalesced flag-byte load, then (flag set) its row as float4s, 48..176 contiguous bytes per lane and a
+// contiguous run for the wave -- instead of every quad of lanes chasing its own Gaussian's {u0, n} -> flag -> row chain.
+// Which Gaussian a row belongs to: the wave's non-empty Gaussians are ranked (ballot), a Gaussian whose first row lies in
+// the chunk marks that position, and an inclusive max-scan over the lanes (carried from chunk to chunk) spreads the ranks.
+// The rows of a chunk are then summed per owner with a segmented Hillis-Steele scan across the lanes (six steps, a FIXED
+// tree: deterministic), and the last lane of every segment adds the segment's sum to its Gaussian's accumulator in LDS
+// (one writer per accumulator and chunk; chunks in order).  Same outputs as sgr_row_sum_kernel; the additions of a
+// Gaussian's rows happen in another (fixed) order.
+#ifndef SGR_RSW_WAVES
+#define SGR_RSW_WAVES 4
+#endif
+template <int SMAX>
+__global__ void __launch_bounds__(64 * SGR_RSW_WAVES)
+sgr_row_sum_wave_kernel(int P, int S, const int* __restrict__ radii, SgrGeomView gv, const float* __restrict__ partials,
+                        int row_stride, const uint8_t* __restrict__ touched, float* __restrict__ dL_dmean2D,
+                        float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dsemantic,
+                        float4* __restrict__ cd, SgrStatSink sink) {
+    constexpr int NV = (SGR_ROW_BASE_N + SMAX + 3) / 4, NF = 4 * NV;
+    constexpr int NVP = NV + ((NV & 1) ? 0 : 1);  // odd number of float4s per accumulator: rows spread over the banks
+    __shared__ float4 sAcc[SGR_RSW_WAVES][64][NVP];
+    __shared__ int sMark[SGR_RSW_WAVES][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = (blockIdx.x * SGR_RSW_WAVES + wave) * 64 + lane;
+    const bool live = g < P;
+    const uint32_t n = live ? gv.aux[g].x : 0u;
+    const uint32_t u0 = live ? gv.u0[g] : 0u;
+    const uint64_t nz = sgr_uniform_u64(__ballot(n != 0u));
+    const int rank = __popcll(nz & ((1ull << lane) - 1ull));
+    float acc[NF];
+#pragma unroll
+    for (int k = 0; k < NF; k++) acc[k] = 0.f;
+    if (nz != 0ull) {  // wave-uniform
+        const int first = __builtin_ctzll(nz), last = 63 - __builtin_clzll(nz);
+        const uint32_t ua = (uint32_t)__builtin_amdgcn_readlane((int)u0, first);
+        const uint32_t ub = (uint32_t)__builtin_amdgcn_readlane((int)(u0 + n), last);
+#pragma unroll
+        for (int k4 = 0; k4 < NV; k4++) sAcc[wave][lane][k4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        int kprev = 0;
+        for (uint32_t cbase = ua; cbase < ub; cbase += 64u) {
+            // owner rank of every row of the chunk
+            sMark[wave][lane] = -1;
+            __builtin_amdgcn_wave_barrier();
+            if (n != 0u && u0 >= cbase && u0 - cbase < 64u) sMark[wave][u0 - cbase] = rank;
+            __builtin_amdgcn_wave_barrier();
+            int k = sMark[wave][lane];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int t = __shfl_up(k, d, 64);
+                if (lane >= d) k = max(k, t);
+            }
+            k = max(k, kprev);
+            kprev = __builtin_amdgcn_readlane(k, 63);
+            // this lane's row
+            const uint32_t u = cbase + (uint32_t)lane;
+            const bool valid = u < ub;
+            float val[NF];
+#pragma unroll
+            for (int i = 0; i < NF; i++) val[i] = 0.f;
+            if (valid && touched[u]) {  // rows the blend backward did not write hold garbage
+                const float4* r = reinterpret_cast<const float4*>(partials + (size_t)u * row_stride);
+#pragma unroll
+                for (int k4 = 0; k4 < NV; k4++) {
+                    const float4 t = r[k4];
+                    val[4 * k4] = t.x; val[4 * k4 + 1] = t.y; val[4 * k4 + 2] = t.z; val[4 * k4 + 3] = t.w;
+                }
+            }
+            // segmented inclusive scan over the lanes (segments = runs of equal owner rank)
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int ko = __shfl_up(k, d, 64);
+                const bool same = lane >= d && ko == k;
+#pragma unroll
+                for (int i = 0; i < NF; i++) {
+                    const float t = __shfl_up(val[i], d, 64);
+                    val[i] += same ? t : 0.f;
+                }
+            }
+            const int knext = __shfl_down(k, 1, 64);
+            const bool tail = valid && (lane == 63 || knext != k || u + 1u >= ub);
+            if (tail) {
+                float4* a = sAcc[wave][k];
+#pragma unroll
+                for (int k4 = 0; k4 < NV; k4++) {
+                    float4 t = a[k4];
+                    t.x += val[4 * k4]; t.y += val[4 * k4 + 1]; t.z += val[4 * k4 + 2]; t.w += val[4 * k4 + 3];
+                    a[k4] = t;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (n != 0u) {
+#pragma unroll
+            for (int k4 = 0; k4 < NV; k4++) {
+                const float4 t = sAcc[wave][rank][k4];
+                acc[4 * k4] = t.x; acc[4 * k4 + 1] = t.y; acc[4 * k4 + 2] = t.z; acc[4 * k4 + 3] = t.w;
+            }
+        }
+    }
+    if (!live) return;
+    const int idx = g;
+    dL_dmean2D[3 * idx + 0] = acc[0];
+    dL_dmean2D[3 * idx + 1] = acc[1];
+    dL_dmean2D[3 * idx + 2] = acc[2];
+    dL_dopacity[idx] = acc[6];
+    dL_dcolor[3 * idx + 0] = acc[7];
+    dL_dcolor[3 * idx + 1] = acc[8];
+    dL_dcolor[3 * idx + 2] = acc[9];
+    cd[idx] = make_float4(acc[3], acc[4], acc[5], acc[10]);
+    if (SMAX > 0) {
+#pragma unroll
+        for (int ch = 0; ch < SMAX; ch++)
+            if (ch < S) dL_dsemantic[(size_t)idx * S + ch] = acc[SGR_ROW_BASE_N + ch];
+    }
+    // densification statistics of this view (see sgr_row_sum_kernel)
+    const int r = radii[idx];
+    if (sink.accum != nullptr && r > 0) {
+#pragma clang fp contract(off)
+        long row = idx;
+        if (sink.nseg > 0) {
+            int lo = 0, hi = sink.nseg - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (sink.start[mid] <= idx) lo = mid; else hi = mid - 1;
+            }
+            row = (idx >= sink.start[lo] && idx < sink.start[lo] + sink.count[lo]) ? (long)idx + sink.shift[lo] : -1;
+        }
+        if (row >= 0) {
+            sink.accum[2 * (size_t)row] += sqrtf(acc[0] * acc[0] + acc[1] * acc[1]);
+            sink.accum[2 * (size_t)row + 1] += fabsf(acc[2]);
+            sink.denom[row] += 1.0f;
+            sink.max_radii[row] = fmaxf(sink.max_radii[row], (float)r);
+        }
     }
 }
 
@@ -377,9 +517,24 @@ void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, cons
 #define SGR_RS(N)                                                                                                    \
     sgr_row_sum_kernel<N, false><<<nb4, SGR_GB_THREADS, 0, s>>>(P, S, radii, gv, partials, row_stride, touched, dL_dmean2D, \
                                                                dL_dopacity, dL_dcolor, dL_dsemantic, cd, sink, kx, ky, exact)
+    // SGR_RS_QUADS=1: the four-lanes-per-Gaussian row sum of rounds 1-3 instead of the wave-cooperative one (A/B)
+    static const bool quads = [] { const char* e = getenv("SGR_RS_QUADS"); return e && e[0] && e[0] != '0'; }();
+    const unsigned nbw = (unsigned)((P + 64 * SGR_RSW_WAVES - 1) / (64 * SGR_RSW_WAVES));
+#define SGR_RSW(N)                                                                                                   \
+    sgr_row_sum_wave_kernel<N><<<nbw, 64 * SGR_RSW_WAVES, 0, s>>>(P, S, radii, gv, partials, row_stride, touched, dL_dmean2D, \
+                                                                 dL_dopacity, dL_dcolor, dL_dsemantic, cd, sink)
     if (quad) {  // the scalar-walk blend backward's rows (S = 0 only)
         sgr_row_sum_kernel<0, true><<<nb4, SGR_GB_THREADS, 0, s>>>(P, S, radii, gv, partials, row_stride, touched, dL_dmean2D,
                                                                   dL_dopacity, dL_dcolor, dL_dsemantic, cd, sink, kx, ky, exact);
+    } else if (!quads) {
+        if (S == 0) SGR_RSW(0);
+        else if (S <= 4) SGR_RSW(4);
+        else if (S <= 8) SGR_RSW(8);
+        else if (S <= 12) SGR_RSW(12);
+        else if (S <= 16) SGR_RSW(16);
+        else if (S <= 20) SGR_RSW(20);
+        else if (S <= 24) SGR_RSW(24);
+        else SGR_RSW(32);
     } else if (S == 0) SGR_RS(0);
     else if (S <= 4) SGR_RS(4);
     else if (S <= 8) SGR_RS(8);
@@ -389,6 +544,7 @@ void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, cons
     else if (S <= 24) SGR_RS(24);
     else SGR_RS(32);
 #undef SGR_RS
+#undef SGR_RSW
     if (after_rows) (void)hipEventRecord(after_rows, s);  // dL/dmean2D, dL/dopacity, dL/dcolour are final from here on
     sgr_gauss_bwd_kernel<<<nb, SGR_GB_THREADS, 0, s>>>(P, D, M, means3D, radii, shs, scales, rotations, cov3D_precomp, cam,
                                                        gv, cd, dL_dmean2D, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
