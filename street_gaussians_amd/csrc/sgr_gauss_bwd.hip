@@ -167,7 +167,7 @@ sgr_row_sum_kernel(int P, int S, const int* __restrict__ radii, SgrGeomView gv, 
     }
 }
 
-// ---- stage 1, wave-cooperative form (default since round 4) -----------------------------------------------------------
+// ---- stage 1, wave-cooperative form (round 4; A/B behind SGR_RS_WAVE=1: measured slower, see the launcher) ----------------
 // The rows are in INDEX order (u0 = exclusive scan of tiles_touched over the Gaussians, culled ones contributing none), so
 // the 64 Gaussians of a wave own ONE contiguous row range [ua, ub).  The wave streams it 64 rows at a time -- lane l takes
 // row cbase + l: one coalesced flag-byte load, then (flag set) its row as float4s, 48..176 contiguous bytes per lane and a
@@ -517,8 +517,10 @@ void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, cons
 #define SGR_RS(N)                                                                                                    \
     sgr_row_sum_kernel<N, false><<<nb4, SGR_GB_THREADS, 0, s>>>(P, S, radii, gv, partials, row_stride, touched, dL_dmean2D, \
                                                                dL_dopacity, dL_dcolor, dL_dsemantic, cd, sink, kx, ky, exact)
-    // SGR_RS_QUADS=1: the four-lanes-per-Gaussian row sum of rounds 1-3 instead of the wave-cooperative one (A/B)
-    static const bool quads = [] { const char* e = getenv("SGR_RS_QUADS"); return e && e[0] && e[0] != '0'; }();
+    // SGR_RS_WAVE=1: the wave-cooperative row sum instead of the four-lanes-per-Gaussian one (A/B: measured SLOWER on MI355X --
+    // per-Gaussian backward stage 0.258 vs 0.213 ms at 1 M Gaussians, 1.14 vs 0.76 ms at 5 M, 0.83 vs 0.57 ms at 2 M + 19
+    // channels: its segmented scan is 13 ds_bpermute per step and row chunk, more than the gather chains it removes)
+    static const bool quads = [] { const char* e = getenv("SGR_RS_WAVE"); return !(e && e[0] && e[0] != '0'); }();
     const unsigned nbw = (unsigned)((P + 64 * SGR_RSW_WAVES - 1) / (64 * SGR_RSW_WAVES));
 #define SGR_RSW(N)                                                                                                   \
     sgr_row_sum_wave_kernel<N><<<nbw, 64 * SGR_RSW_WAVES, 0, s>>>(P, S, radii, gv, partials, row_stride, touched, dL_dmean2D, \
