@@ -190,7 +190,10 @@ int sgr_export_internal(int which, int P, int R, int width, int height, char* ge
  * bit 5 the radix sorts run in their one-sweep (decoupled look-back) form (A/B design, slower; SGR_ONESWEEP),
  * bit 7 (SGR_EXACT=1) PARITY MODE: the blend kernels evaluate the reference's own power expression, the device
  * library's expf and the IEEE quotient T / (1 - alpha), unfused -- alpha / depth / semantic images bit-identical to the
- * reference's kernels, gradients within rel 1e-4 end to end.
+ * reference's kernels, gradients within rel 1e-4 end to end,
+ * bit 8 (SGR_SW=1) the S = 0 blend backward runs its scalar-walk form (csrc/sgr_blend_bwd_sw.hip: A/B design, slower),
+ * bit 9 (SGR_RS_WAVE=1) the per-Gaussian row sum runs its wave-cooperative form (A/B design, slower),
+ * bit 6 (SGR_PRE_STAGE=1) the preprocess stages its SH rows through LDS whatever P is (default: from 3 M Gaussians).
  * mask >= 0 sets them process-wide, mask < 0 only queries; returns the previous mask.  The initial
  * value comes from the environment (SGR_NO_CULL, SGR_NO_DPP, SGR_NO_DET, SGR_NO_HITS, SGR_V2), read once. */
 int sgr_test_switches(int mask);

@@ -369,7 +369,7 @@ def sh_grad_from_rows(P, degree, M, V, means_ptr, means_stride, campos_ptr, camp
     return out
 
 
-NO_CULL, NO_DPP, NO_DET, NO_HITS, USE_V2, USE_ONESWEEP, PRE_STAGE_SH, EXACT, USE_SW = 1, 2, 4, 8, 16, 32, 64, 128, 256
+NO_CULL, NO_DPP, NO_DET, NO_HITS, USE_V2, USE_ONESWEEP, PRE_STAGE_SH, EXACT, USE_SW, USE_RS_WAVE = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 
 
 def test_switches(mask: int = -1) -> int:

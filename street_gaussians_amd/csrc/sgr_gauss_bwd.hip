@@ -508,7 +508,8 @@ void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, cons
                           const SgrGeomView& gv, const float* partials, int row_stride, const uint8_t* touched,
                           float4* cd, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dsemantic,
-                          const SgrStatSink& sink, int quad, int exact, int W, int H, hipEvent_t after_rows, hipStream_t s) {
+                          const SgrStatSink& sink, int quad, int exact, int W, int H, hipEvent_t after_rows, int rs_wave,
+                          hipStream_t s) {
     if (P <= 0) return;
     const float lsc = exact ? 1.0f : SGR_LOG2E;
     const float kx = (0.5f * (float)W) / lsc, ky = (0.5f * (float)H) / lsc;
@@ -517,10 +518,10 @@ void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, cons
 #define SGR_RS(N)                                                                                                    \
     sgr_row_sum_kernel<N, false><<<nb4, SGR_GB_THREADS, 0, s>>>(P, S, radii, gv, partials, row_stride, touched, dL_dmean2D, \
                                                                dL_dopacity, dL_dcolor, dL_dsemantic, cd, sink, kx, ky, exact)
-    // SGR_RS_WAVE=1: the wave-cooperative row sum instead of the four-lanes-per-Gaussian one (A/B: measured SLOWER on MI355X --
+    // switch bit 9 / SGR_RS_WAVE=1: the wave-cooperative row sum instead of the four-lanes-per-Gaussian one (A/B: measured SLOWER on MI355X --
     // per-Gaussian backward stage 0.258 vs 0.213 ms at 1 M Gaussians, 1.14 vs 0.76 ms at 5 M, 0.83 vs 0.57 ms at 2 M + 19
     // channels: its segmented scan is 13 ds_bpermute per step and row chunk, more than the gather chains it removes)
-    static const bool quads = [] { const char* e = getenv("SGR_RS_WAVE"); return !(e && e[0] && e[0] != '0'); }();
+    const bool quads = !rs_wave;  // (sgr_test_switches bit 9)
     const unsigned nbw = (unsigned)((P + 64 * SGR_RSW_WAVES - 1) / (64 * SGR_RSW_WAVES));
 #define SGR_RSW(N)                                                                                                   \
     sgr_row_sum_wave_kernel<N><<<nbw, 64 * SGR_RSW_WAVES, 0, s>>>(P, S, radii, gv, partials, row_stride, touched, dL_dmean2D, \

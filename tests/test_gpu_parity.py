@@ -218,6 +218,13 @@ def test_culling_is_invisible_and_backward_is_deterministic(name):
         assert torch.equal(g_a[k], g_a3[k]), f"{k} changed after a scalar-walk backward over the same forward"
         if name not in ILL_CONDITIONED:
             grad_close(npy(g_s[k]), npy(g_a[k]), rel=1e-4, abs_frac=2e-5, name=f"scalar walk vs LDS kernel:{k}", max_outlier_frac=0.0)
+    with switches(_C.USE_RS_WAVE):  # the wave-cooperative row sum (A/B form): another fixed summation order
+        g_w = raw_backward(kw, res_a, wts)
+        g_w2 = raw_backward(kw, res_a, wts)
+    for k in g_a:
+        assert torch.equal(g_w[k], g_w2[k]), f"{k} not deterministic (wave-cooperative row sum)"
+        if name not in ILL_CONDITIONED:
+            grad_close(npy(g_w[k]), npy(g_a[k]), rel=1e-4, abs_frac=2e-5, name=f"wave row sum vs quads:{k}", max_outlier_frac=0.0)
     with switches(_C.NO_HITS):  # geometric cull instead of the hit record: a superset of the same visits
         g_h = raw_backward(kw, res_a, wts)
     for k in g_a:
