@@ -4,8 +4,8 @@
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 E=$R/gpurun_out/ev_$1
-D=$R/profiles/${2:-r3}
-N=${2:-r3}
+D=$R/profiles/${2:-r4}
+N=${2:-r4}
 mkdir -p $D
 cp $E/pmc_blend_bwd.json $R/profiles/pmc_blend_bwd.json
 cp $E/pmc_blend_bwd.json $D/pmc_blend_bwd.json
