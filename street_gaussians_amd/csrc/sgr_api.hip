@@ -183,7 +183,7 @@ static hipError_t wait_for_readback(uint32_t* host_vals, hipEvent_t landed) {
         const auto t0 = std::chrono::steady_clock::now();
         for (;;) {
             for (int i = 0; i < 256; i++) {
-                if (hv[0] != SGR_READBACK_PENDING && hv[1] != SGR_READBACK_PENDING) {
+                if (hv[0] != SGR_READBACK_PENDING && hv[1] != SGR_READBACK_PENDING && hv[2] != SGR_READBACK_PENDING) {
                     std::atomic_thread_fence(std::memory_order_acquire);
                     return hipSuccess;
                 }
@@ -333,79 +333,97 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     const SgrImgView iv = sgr_img_carve(ibase, N, T);
     int* radii_ptr = radii ? radii : gv.internal_radii;  // rasterizer_impl.cu:232-235
 
-    prof_begin(0, stream);
-    pack_camera(gv, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, W, H, scale_modifier, iv.ranges, (int)T, stream);
-    SGR_STAGE("pack_camera");
-
-    sgr_launch_preprocess(P, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
-                          cam_slot(gv), gv, radii_ptr, prefiltered,
-                          // SH rows staged through LDS (half a wave's rows at a time) or read per lane: bit-identical forms
-                          // (tests); the staged one wins once the launch is deep enough to be throughput-bound -- measured
-                          // 346 vs 360 us at 5 M Gaussians, 98.8 vs 90.2 us at 1 M -- so it is chosen by P (switch bit 6
-                          // forces it, SGR_PRE_STAGE_MIN_P moves the threshold)
-                          (switches() & 64) != 0 || P >= pre_stage_min_p(), stream);
-    SGR_STAGE("preprocess");
-    prof_end(stream);
-
-    // K5 first: num_rendered (header[1], summed by the preprocess kernel) and the prefilter flag (header[0]) go to
-    // pinned host memory in ONE 8-byte copy.  The host only waits for THAT copy (an event), after the depth sort and
-    // the scan have been queued behind it: while it wakes up, allocates the binning buffer and queues the dozen short
-    // binning kernels, the GPU is busy with the ~0.15 ms of sort + scan instead of idling (rocprofv3 kernel trace:
-    // ~0.2 ms of gaps per forward with the wait placed after the scan, as rasterizer_impl.cu:281 has it).
-    uint32_t* host_vals = pinned_pair();
-    hipEvent_t landed = readback_event();
-    if (!host_vals || !landed) return fail(SGR_E_HIP, "pinned readback slot / event creation failed");
-    // both words carry a value the device never writes, so that the host can see them arrive (wait_for_readback)
-    host_vals[0] = host_vals[1] = SGR_READBACK_PENDING;
-    SGR_HIP(hipMemcpyAsync(host_vals, gv.header, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    SGR_HIP(hipEventRecord(landed, stream));
-    // an error return between here and the wait must not leave this copy in flight: the next forward of this thread would
-    // take its late arrival for its own read-back
-    struct ReadbackDrain {
-        hipEvent_t ev;
-        ~ReadbackDrain() { if (ev) (void)hipEventSynchronize(ev); }
-    } drain{landed};
-
-    // Depth pre-sort of the P Gaussians (32-bit keys, 4 passes over P elements), then K4: scan of tiles_touched in
-    // that order.
-    prof_begin(1, stream);
-    // (the ids are not materialised before the sort: its first pass takes the element index as the value; its last
-    // pass also carries every Gaussian's {tiles_touched, tile rect} into depth order -- ONE fused 8-byte gather instead
-    // of three per-stage gathers through `order`: at 5 M Gaussians those read 0.6 GB each, rocprofv3 FETCH_SIZE)
-    const int dcur = sgr_launch_sort_pairs32(gv.dkeys, gv.dvals, (uint32_t)P, 32, gv.dhist, gv.scan_tmp, stream, true, gv.aux,
-                                             gv.aux_sorted);
-    const uint32_t* order = gv.dvals[dcur];
-    // (second sequence of the same launches: the exclusive scan in index order = every Gaussian's first partial-gradient
-    // row of the backward, SgrGeomView::u0)
-    sgr_launch_scan(reinterpret_cast<const uint32_t*>(gv.aux_sorted), gv.tt_sorted, (size_t)P, gv.scan_tmp, true, stream,
-                    nullptr, nullptr, 2, reinterpret_cast<const uint32_t*>(gv.aux), gv.u0);
-    SGR_STAGE("depth_sort+scan");
-    prof_end(stream);
-    // The window between "R is known" and "the GPU runs out of queued work" is only the ~0.12 ms of sort + scan
-    // above, and the allocation callback (a Python call into the torch allocator in the shipped binding) is the
-    // slowest thing in it.  So the binning buffer is requested BEFORE the wait, sized for the previous forward's R
-    // + 25 % (per host thread); only if that turns out too small is it requested again with the exact size.  The
-    // carving below depends on R alone, so a larger buffer is simply partly unused.
-    static thread_local size_t r_hint = 0;
-    size_t have_bytes = 0;
+    // The front end (camera pack, preprocess, depth sort, scan) runs once -- or twice, the second time with a depth sort on
+    // all 32 key bits, when the preprocess reports a view depth beyond what the 27-bit keys order (>= 13 107: never seen in a
+    // street scene; the host thread then keeps the wide sort for its next 64 forwards before it tries the narrow one again,
+    // so a scene that really has such depths pays the repeat on one frame in 64).
+    static thread_local int wide_left = 0;
+    bool wide_depth = wide_left > 0;
+    if (wide_depth) wide_left--;
+    uint32_t* host_vals = nullptr;
+    const uint32_t* order = nullptr;
     char* bbase = nullptr;
-    if (r_hint > 0) {
-        // the hint decays a little every call; request sizes on a coarse ladder (steps of 1/16 of the next lower power of
-        // two) so that consecutive calls ask the caller's caching allocator for the SAME block size instead of a new,
-        // slightly smaller one each time (every new size is a device allocation: tens of ms on some hosts)
-        size_t hq = r_hint;
-        {
-            size_t step = 1;
-            while ((step << 1) <= hq) step <<= 1;
-            step = std::max<size_t>(step >> 4, 1024);
-            hq = (hq + step - 1) / step * step;
+    size_t have_bytes = 0;
+    static thread_local size_t r_hint = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        prof_begin(0, stream);
+        pack_camera(gv, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, W, H, scale_modifier, iv.ranges, (int)T, stream);
+        SGR_STAGE("pack_camera");
+
+        sgr_launch_preprocess(P, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
+                              cam_slot(gv), gv, radii_ptr, prefiltered,
+                              // SH rows staged through LDS (half a wave's rows at a time) or read per lane: bit-identical forms
+                              // (tests); the staged one wins once the launch is deep enough to be throughput-bound -- measured
+                              // 346 vs 360 us at 5 M Gaussians, 98.8 vs 90.2 us at 1 M -- so it is chosen by P (switch bit 6
+                              // forces it, SGR_PRE_STAGE_MIN_P moves the threshold)
+                              (switches() & 64) != 0 || P >= pre_stage_min_p(), stream);
+        SGR_STAGE("preprocess");
+        prof_end(stream);
+
+        // K5 first: num_rendered (header[1], summed by the preprocess kernel) and the prefilter flag (header[0]) go to
+        // pinned host memory in ONE 8-byte copy.  The host only waits for THAT copy (an event), after the depth sort and
+        // the scan have been queued behind it: while it wakes up, allocates the binning buffer and queues the dozen short
+        // binning kernels, the GPU is busy with the ~0.15 ms of sort + scan instead of idling (rocprofv3 kernel trace:
+        // ~0.2 ms of gaps per forward with the wait placed after the scan, as rasterizer_impl.cu:281 has it).
+        host_vals = pinned_pair();
+        hipEvent_t landed = readback_event();
+        if (!host_vals || !landed) return fail(SGR_E_HIP, "pinned readback slot / event creation failed");
+        // the words carry a value the device never writes, so that the host can see them arrive (wait_for_readback);
+        // header[2] = "a depth beyond the 27-bit sort keys" rides along
+        host_vals[0] = host_vals[1] = host_vals[2] = SGR_READBACK_PENDING;
+        SGR_HIP(hipMemcpyAsync(host_vals, gv.header, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        SGR_HIP(hipEventRecord(landed, stream));
+        // an error return between here and the wait must not leave this copy in flight: the next forward of this thread would
+        // take its late arrival for its own read-back
+        struct ReadbackDrain {
+            hipEvent_t ev;
+            ~ReadbackDrain() { if (ev) (void)hipEventSynchronize(ev); }
+        } drain{landed};
+
+        // Depth pre-sort of the P Gaussians (27 key bits: 3 passes of 9 bits over P elements; 32 bits = 4 passes of 8 when a
+        // depth beyond 13 107 has been seen), then K4: scan of tiles_touched in that order.
+        prof_begin(1, stream);
+        // (the ids are not materialised before the sort: its first pass takes the element index as the value; its last
+        // pass also carries every Gaussian's {tiles_touched, tile rect} into depth order -- ONE fused 8-byte gather instead
+        // of three per-stage gathers through `order`: at 5 M Gaussians those read 0.6 GB each, rocprofv3 FETCH_SIZE)
+        const int dcur = sgr_launch_sort_pairs32(gv.dkeys, gv.dvals, (uint32_t)P, wide_depth ? 32 : SGR_DEPTH_KEY_BITS, gv.dhist,
+                                                 gv.scan_tmp, stream, true, gv.aux, gv.aux_sorted);
+        order = gv.dvals[dcur];
+        // (second sequence of the same launches: the exclusive scan in index order = every Gaussian's first partial-gradient
+        // row of the backward, SgrGeomView::u0)
+        sgr_launch_scan(reinterpret_cast<const uint32_t*>(gv.aux_sorted), gv.tt_sorted, (size_t)P, gv.scan_tmp, true, stream,
+                        nullptr, nullptr, 2, reinterpret_cast<const uint32_t*>(gv.aux), gv.u0);
+        SGR_STAGE("depth_sort+scan");
+        prof_end(stream);
+        // The window between "R is known" and "the GPU runs out of queued work" is only the ~0.12 ms of sort + scan
+        // above, and the allocation callback (a Python call into the torch allocator in the shipped binding) is the
+        // slowest thing in it.  So the binning buffer is requested BEFORE the wait, sized for the previous forward's R
+        // + 25 % (per host thread); only if that turns out too small is it requested again with the exact size.  The
+        // carving below depends on R alone, so a larger buffer is simply partly unused.
+        have_bytes = 0;
+        bbase = nullptr;
+        if (r_hint > 0) {
+            // the hint decays a little every call; request sizes on a coarse ladder (steps of 1/16 of the next lower power of
+            // two) so that consecutive calls ask the caller's caching allocator for the SAME block size instead of a new,
+            // slightly smaller one each time (every new size is a device allocation: tens of ms on some hosts)
+            size_t hq = r_hint;
+            {
+                size_t step = 1;
+                while ((step << 1) <= hq) step <<= 1;
+                step = std::max<size_t>(step >> 4, 1024);
+                hq = (hq + step - 1) / step * step;
+            }
+            have_bytes = sgr_binning_bytes((int)std::min<size_t>(hq, 0x7fffffffu));
+            bbase = binning_buffer(have_bytes, binning_user);
+            if (!bbase) return fail(SGR_E_ALLOC, "binning buffer allocation failed");
         }
-        have_bytes = sgr_binning_bytes((int)std::min<size_t>(hq, 0x7fffffffu));
-        bbase = binning_buffer(have_bytes, binning_user);
-        if (!bbase) return fail(SGR_E_ALLOC, "binning buffer allocation failed");
+        SGR_HIP(wait_for_readback(host_vals, landed));  // the one host wait of the forward
+        drain.ev = nullptr;
+
+        if (!(host_vals[2] & 1u) || wide_depth) break;
+        wide_depth = true;
+        wide_left = 64;
     }
-    SGR_HIP(wait_for_readback(host_vals, landed));  // the one host wait of the forward
-    drain.ev = nullptr;
     if (host_vals[0] & 1u)
         return fail(SGR_E_PREFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
     if (host_vals[1] > 0x7fffffffu) return fail(SGR_E_INVALID, "more than 2^31 tile instances");
@@ -448,7 +466,7 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
 static int sorted_index(int width, int height) {
     const int gx = (width + SGR_BLOCK_X - 1) / SGR_BLOCK_X, gy = (height + SGR_BLOCK_Y - 1) / SGR_BLOCK_Y;
     const int end_bit = (int)getHigherMsb((uint32_t)(gx * gy));  // the tile sort only; depth order comes from the emission order
-    return ((end_bit + 7) / 8) & 1;
+    return sgr_sort_pass_count(end_bit) & 1;
 }
 
 int sgr_backward(int P, int D, int M, int R, int S, const float* background, int width, int height,

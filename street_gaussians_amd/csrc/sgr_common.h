@@ -32,6 +32,8 @@
 #define SGR_ROW_BASE_N 11      // non-semantic floats of a partial-gradient row (see sgr_blend_bwd.hip)
 
 #define SGR_ALPHA_MIN (1.0f / 255.0f)
+#define SGR_DEPTH_KEY_BIAS 0x3E4CCCCDu  // bits of 0.2f: the near-plane test of the preprocess (auxiliary.h:152)
+#define SGR_DEPTH_KEY_BITS 27           // key bits the depth sort looks at unless a depth >= 0.2 * 2^16 shows up
 #define SGR_LOG2E 1.4426950408889634f
 
 struct SgrGeomView {

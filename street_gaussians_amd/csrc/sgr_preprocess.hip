@@ -229,7 +229,13 @@ sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         rec[3] = make_float4(st.x, __uint_as_float(rect), st.y, st.z);
         gv.clamped[idx] = clamped;
         gv.aux[idx] = make_uint2(w * h, rect);
-        gv.dkeys[0][idx] = __float_as_uint(pr.depth);
+        // depth-sort key: the bits of the view depth minus the bits of 0.2 (every Gaussian that gets here has depth > 0.2):
+        // monotone in the depth, and below 2^27 for depths under 13 107 -- sixteen octaves -- so that the sort takes THREE 9-bit
+        // passes instead of four 8-bit ones.  A depth beyond that raises header[2]; the host reads it back together with
+        // num_rendered and repeats the forward's front end with a sort on all 32 bits (sgr_api.hip).  Culled: all ones.
+        const uint32_t dkey = __float_as_uint(pr.depth) - SGR_DEPTH_KEY_BIAS;
+        if (dkey >> SGR_DEPTH_KEY_BITS) atomicOr(&gv.header[2], 1u);
+        gv.dkeys[0][idx] = dkey;
         radii[idx] = pr.radius;
         n = w * h;
     }

@@ -143,9 +143,9 @@ __global__ void __launch_bounds__(256)
 sgr_sort_hist_kernel(const K* __restrict__ keys, uint32_t n, int shift, uint32_t mask, uint32_t nblocks,
                      uint32_t* __restrict__ hist) {
     // one private histogram per wave (a quarter of the same-address LDS atomics), merged at the end
-    __shared__ uint32_t h[4][256];
+    __shared__ uint32_t h[4][512];  // up to 9-bit digits
 #pragma unroll
-    for (int w = 0; w < 4; w++) h[w][threadIdx.x] = 0;
+    for (int w = 0; w < 4; w++) { h[w][threadIdx.x] = 0; h[w][256 + threadIdx.x] = 0; }
     __syncthreads();
     const int wave = threadIdx.x >> 6;
     const uint32_t base = blockIdx.x * (256u * IPT);
@@ -155,9 +155,8 @@ sgr_sort_hist_kernel(const K* __restrict__ keys, uint32_t n, int shift, uint32_t
         if (i < n) atomicAdd(&h[wave][(uint32_t)(keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
-    if (threadIdx.x <= mask)
-        hist[(size_t)threadIdx.x * nblocks + blockIdx.x] =
-            h[0][threadIdx.x] + h[1][threadIdx.x] + h[2][threadIdx.x] + h[3][threadIdx.x];  // [digit][block]
+    for (uint32_t d = threadIdx.x; d <= mask; d += 256)
+        hist[(size_t)d * nblocks + blockIdx.x] = h[0][d] + h[1][d] + h[2][d] + h[3][d];  // [digit][block]
 }
 
 // workgroup d: exclusive scan of row d of the [digit][block] table in place; totals[d] = row sum
@@ -211,6 +210,8 @@ sgr_sort_scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ 
                         unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket, uint32_t* __restrict__ err,
                         uint32_t pass_tag, const uint2* __restrict__ aux_in, uint2* __restrict__ aux_out) {
     constexpr int NB = 1 << BITS;
+    constexpr int BPT = NB > 256 ? NB / 256 : 1;  // bins per thread in the prefix section (9-bit digits: 2)
+    static_assert(!(ONE && NB > 256), "the one-sweep form has one status word per thread");
     constexpr uint32_t ITEMS = 256u * IPT;
     __shared__ uint32_t cnt[4][NB];    // per wave: count of each digit, then its block-local start for that wave
     __shared__ uint32_t lstart[NB];    // block-local start of each digit
@@ -220,9 +221,9 @@ sgr_sort_scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ 
     __shared__ uint32_t sV[ITEMS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (ONE && tid == 0) lds4[0] = atomicAdd(ticket, 1u);  // block id in start order: every lower id is already running
-    if (tid < NB) {
+    for (int b = tid; b < NB; b += 256) {
 #pragma unroll
-        for (int w = 0; w < 4; w++) cnt[w][tid] = 0;
+        for (int w = 0; w < 4; w++) cnt[w][b] = 0;
     }
     __syncthreads();
     const uint32_t block = ONE ? lds4[0] : blockIdx.x;
@@ -258,7 +259,7 @@ sgr_sort_scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ 
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    {
+    if constexpr (BPT == 1) {
         const bool bin = tid < NB;
         const uint32_t c0 = bin ? cnt[0][tid] : 0u, c1 = bin ? cnt[1][tid] : 0u, c2 = bin ? cnt[2][tid] : 0u,
                        c3 = bin ? cnt[3][tid] : 0u;
@@ -300,6 +301,36 @@ sgr_sort_scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ 
             cnt[1][tid] = ls + c0;
             cnt[2][tid] = ls + c0 + c1;
             cnt[3][tid] = ls + c0 + c1 + c2;
+        }
+    } else {
+        // more bins than threads (9-bit digits): every thread owns BPT CONSECUTIVE bins, the two block scans run over the
+        // threads' sums and the bins of a thread are prefixed in order
+        uint32_t c[BPT][4], tot[BPT], gt[BPT], before[BPT];
+        uint32_t sum_t = 0, sum_g = 0, all;
+#pragma unroll
+        for (int j = 0; j < BPT; j++) {
+            const int bin = tid * BPT + j;
+#pragma unroll
+            for (int w = 0; w < 4; w++) c[j][w] = cnt[w][bin];
+            tot[j] = c[j][0] + c[j][1] + c[j][2] + c[j][3];
+            gt[j] = totals[bin];
+            before[j] = hist_scanned[(size_t)bin * nblocks + block];
+            sum_t += tot[j];
+            sum_g += gt[j];
+        }
+        uint32_t g = sgr_block_excl_scan256(sum_g, lds4, all);
+        uint32_t ls = sgr_block_excl_scan256(sum_t, lds4, all);
+#pragma unroll
+        for (int j = 0; j < BPT; j++) {
+            const int bin = tid * BPT + j;
+            gbase[bin] = before[j] + g;
+            lstart[bin] = ls;
+            cnt[0][bin] = ls;
+            cnt[1][bin] = ls + c[j][0];
+            cnt[2][bin] = ls + c[j][0] + c[j][1];
+            cnt[3][bin] = ls + c[j][0] + c[j][1] + c[j][2];
+            g += gt[j];
+            ls += tot[j];
         }
     }
     __syncthreads();
@@ -378,10 +409,17 @@ int sgr_sort_get_one_sweep() {
 // one sweep -- [control: 8 x 256 digit counts, 8 tickets, error flag | status table, 256 x 64 bit per block].
 // Digit schedule of a sort on key bits [0, end_bit): npass = ceil(end_bit / 8) passes of ceil(end_bit / npass) bits each
 // (14 tile bits -> 2 x 7 instead of 8 + 6: half the bins, twice the run length in the first pass).
-static inline int sort_pass_bits(int end_bit) {
+// 32-bit keys, round 4: digits of up to NINE bits, so that the 27 key bits of the forward's depth sort (depth bits minus the
+// bits of 0.2, sgr_preprocess.hip) take three passes instead of four: npass = ceil(end_bit / 9) passes of ceil(end_bit / npass)
+// bits (32 -> 4 x 8, 27 -> 3 x 9, 14 -> 2 x 7).  64-bit keys (simple-knn's Morton sort) keep 8-bit digits.
+#define SGR_SORT_MAX_BITS32 9
+static inline int sort_passes32(int end_bit) {
     static const int forced = [] { const char* e = getenv("SGR_SORT_BITS"); return e ? atoi(e) : 0; }();  // A/B only
-    const int npass = (end_bit + 7) / 8;
-    if (forced == 8) return 8;
+    const int maxb = forced == 8 ? 8 : SGR_SORT_MAX_BITS32;
+    return (end_bit + maxb - 1) / maxb;
+}
+static inline int sort_pass_bits(int end_bit) {
+    const int npass = sort_passes32(end_bit);
     return npass ? (end_bit + npass - 1) / npass : 8;
 }
 // Keys per thread: large inputs use 4096-key blocks (longer store runs); small ones keep 2048 so that the launch
@@ -396,7 +434,8 @@ static inline int sort_ipt(uint32_t n) {
     return 8;
 }
 
-int sgr_sort_pass_count(int end_bit) { return (end_bit + 7) / 8; }
+// passes (= buffer flips) of a 32-bit-key sort on bits [0, end_bit) in the form that is switched on
+int sgr_sort_pass_count(int end_bit) { return sgr_sort_get_one_sweep() ? (end_bit + 7) / 8 : sort_passes32(end_bit); }
 
 template <typename K, int BITS, int IPT>
 static void sort_pass(const K* kin, const uint32_t* vin, K* kout, uint32_t* vout, uint32_t n, int shift, uint32_t* hist,
@@ -421,7 +460,7 @@ static int sort_pairs_impl(K* const keys[2], uint32_t* const vals[2], uint32_t n
                            uint32_t* scan_tmp, hipStream_t s, bool iota = false, const uint2* aux_in = nullptr,
                            uint2* aux_out = nullptr) {
     if (n == 0) return 0;
-    const int npass = (end_bit + 7) / 8;
+    int npass = (end_bit + 7) / 8;
     int cur = 0;
     if (sgr_sort_get_one_sweep() && npass <= SGR_SORT_MAX_PASS && !iota && !aux_in) {
         const uint32_t nblocks = (n + SGR_SORT_ITEMS - 1) / SGR_SORT_ITEMS;
@@ -443,6 +482,7 @@ static int sort_pairs_impl(K* const keys[2], uint32_t* const vals[2], uint32_t n
     }
     const int bits = sizeof(K) == 8 ? 8 : sort_pass_bits(end_bit);
     const int ipt = sizeof(K) == 8 ? 8 : sort_ipt(n);
+    if (sizeof(K) == 4) npass = sort_passes32(end_bit);
     for (int p = 0; p < npass; p++) {
         const uint32_t* vin = (iota && p == 0) ? nullptr : vals[cur];
         const bool last = p == npass - 1;
@@ -451,10 +491,11 @@ static int sort_pairs_impl(K* const keys[2], uint32_t* const vals[2], uint32_t n
         const int shift = bits * p;
 #define SGR_PASS(B, I) sort_pass<K, B, I>(keys[cur], vin, keys[cur ^ 1], vals[cur ^ 1], n, shift, hist, ai, ao, s)
         if constexpr (sizeof(K) == 8) { SGR_PASS(8, 8); }
-        else if (ipt == 16) {
+        else if (ipt == 16 && bits <= 8) {
             if (bits <= 5) SGR_PASS(5, 16); else if (bits == 6) SGR_PASS(6, 16); else if (bits == 7) SGR_PASS(7, 16); else SGR_PASS(8, 16);
         } else {
-            if (bits <= 5) SGR_PASS(5, 8); else if (bits == 6) SGR_PASS(6, 8); else if (bits == 7) SGR_PASS(7, 8); else SGR_PASS(8, 8);
+            if (bits <= 5) SGR_PASS(5, 8); else if (bits == 6) SGR_PASS(6, 8); else if (bits == 7) SGR_PASS(7, 8);
+            else if (bits == 8) SGR_PASS(8, 8); else SGR_PASS(9, 8);
         }
 #undef SGR_PASS
         cur ^= 1;

@@ -571,6 +571,29 @@ def test_autograd_api_and_error_behaviour():
     fw.free()
 
 
+def test_far_depths_fall_back_to_the_32_bit_depth_sort():
+    """The depth sort orders 27 key bits (depth bits minus the bits of 0.2: below 2^27 for depths under 13 107) in three
+    passes.  A scene with a Gaussian farther away than that raises a device flag that comes back with num_rendered, and the
+    forward repeats its front end with a sort on all 32 bits: the order must be the oracle's either way."""
+    cam = syn.make_camera(160, 96, fx=170.0)
+    sc = syn.make_scene(400, cam, S=0, seed=31, scale_px=0.02, zmin=1.0, zmax=8.0)
+    far = sc.means3D.clone()
+    far[::7, :] = far[::7, :] * torch.tensor([1.0, 1.0, 0.0]) * 3000.0 + torch.tensor([0.0, 0.0, 1.0]) * torch.linspace(13000.0, 90000.0, far[::7].shape[0])[:, None]
+    sc.means3D.copy_(far)
+    sc.scales[::7] *= 4000.0  # so that the far ones still cover pixels
+    kw = oracle_kwargs(cam, sc)
+    fw = oracle.forward(**kw)
+    assert (fw.depths[fw.radii > 0] > 13107.2).sum() >= 3 and (fw.depths[fw.radii > 0] < 13107.2).sum() > 100
+    for _ in range(2):  # the first call takes the repeat, the second starts with the wide sort (kept for the next 64 forwards)
+        res, internal = raw_forward(kw)
+        assert res["R"] == fw.num_rendered
+        assert (npy(internal("keys")).view(np.uint64) == fw.keys).all()
+        assert (npy(internal("point_list")).view(np.uint32) == fw.point_list).all()
+        assert (npy(internal("point_offsets")).view(np.uint32) == fw.point_offsets).all()
+        image_close(npy(res["color"]), fw.color, name="far color")
+    fw.free()
+
+
 def test_prefiltered_raises_instead_of_trapping():
     from diff_gaussian_rasterization import GaussianRasterizer
     from street_gaussians_amd._native import SgrError

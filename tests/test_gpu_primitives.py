@@ -68,8 +68,11 @@ def test_sort_pairs_stable(n, end_bit, dup, one_sweep, sort_mode):
     assert (vs == vals[order]).all()
 
 
+# end_bit 27 / 18 / 9: digits of NINE bits (512 bins, two per thread in the scatter's prefix section) -- the forward's depth
+# sort runs on 27 key bits in three such passes
 @pytest.mark.parametrize("n,end_bit,dup", [(1, 14, False), (4097, 14, True), (2_500_000, 14, True), (1_000_000, 32, False),
-                                           (20_000_003, 15, False)])
+                                           (20_000_003, 15, False), (1_000_001, 27, False), (300_000, 27, True), (70_001, 18, True),
+                                           (5000, 9, False)])
 @pytest.mark.parametrize("one_sweep", [False, True])
 def test_sort_pairs32_stable(n, end_bit, dup, one_sweep, sort_mode):
     L, check = _lib()
