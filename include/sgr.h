@@ -203,9 +203,10 @@ int sgr_test_scan(const uint32_t* in, uint32_t* out, size_t n, int inclusive, ui
 /* keys0/vals0 hold the input; returns 0 or 1 = which of (keys0,vals0)/(keys1,vals1) holds the sorted result */
 int sgr_test_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_t* vals1, uint32_t n, int end_bit,
                   uint32_t* hist, uint32_t* scan_tmp, void* stream);
-/* same with 32-bit keys (the tile sort and the depth pre-sort of the forward use this instantiation) */
+/* same with 32-bit keys (the tile sort and the depth pre-sort of the forward use this instantiation); max_bits = 8 or 9:
+ * the widest digit (9 is what the depth pre-sort asks for below 750 k Gaussians: 27 key bits in three passes) */
 int sgr_test_sort32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, uint32_t n, int end_bit,
-                    uint32_t* hist, uint32_t* scan_tmp, void* stream);
+                    int max_bits, uint32_t* hist, uint32_t* scan_tmp, void* stream);
 size_t sgr_test_sort_hist_words(uint32_t n);
 size_t sgr_test_scan_tmp_words(size_t n);
 int sgr_test_wave_sum(const float* in, float* out_dpp, float* out_shfl, int nwaves, void* stream);

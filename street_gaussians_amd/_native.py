@@ -126,7 +126,7 @@ def lib():
         L.sgr_test_sort.restype = i
         L.sgr_test_sort.argtypes = [vp, vp, vp, vp, C.c_uint32, i, vp, vp, vp]
         L.sgr_test_sort32.restype = i
-        L.sgr_test_sort32.argtypes = [vp, vp, vp, vp, C.c_uint32, i, vp, vp, vp]
+        L.sgr_test_sort32.argtypes = [vp, vp, vp, vp, C.c_uint32, i, i, vp, vp, vp]
         L.sgr_test_wave_sum.restype = i
         L.sgr_test_wave_sum.argtypes = [vp, vp, vp, i, vp]
         L.sgr_test_exact_math.restype = i

@@ -380,14 +380,16 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
             ~ReadbackDrain() { if (ev) (void)hipEventSynchronize(ev); }
         } drain{landed};
 
-        // Depth pre-sort of the P Gaussians (27 key bits: 3 passes of 9 bits over P elements; 32 bits = 4 passes of 8 when a
+        // Depth pre-sort of the P Gaussians (27 key bits: 3 x 9 or 4 x 7 bits over P elements; 32 bits = 4 passes of 8 when a
         // depth beyond 13 107 has been seen), then K4: scan of tiles_touched in that order.
         prof_begin(1, stream);
         // (the ids are not materialised before the sort: its first pass takes the element index as the value; its last
         // pass also carries every Gaussian's {tiles_touched, tile rect} into depth order -- ONE fused 8-byte gather instead
         // of three per-stage gathers through `order`: at 5 M Gaussians those read 0.6 GB each, rocprofv3 FETCH_SIZE)
+        // (27 bits: 3 passes of 9 bits while the launches are latency-bound, 4 passes of 7 bits -- longer store runs -- from
+        // 750 k Gaussians on: sgr_scan_sort.hip)
         const int dcur = sgr_launch_sort_pairs32(gv.dkeys, gv.dvals, (uint32_t)P, wide_depth ? 32 : SGR_DEPTH_KEY_BITS, gv.dhist,
-                                                 gv.scan_tmp, stream, true, gv.aux, gv.aux_sorted);
+                                                 gv.scan_tmp, stream, true, gv.aux, gv.aux_sorted, P < 750000 ? 9 : 8);
         order = gv.dvals[dcur];
         // (second sequence of the same launches: the exclusive scan in index order = every Gaussian's first partial-gradient
         // row of the backward, SgrGeomView::u0)
@@ -847,12 +849,13 @@ int sgr_test_sort(uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_t* v
     return cur;
 }
 int sgr_test_sort32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, uint32_t n, int end_bit,
-                    uint32_t* hist, uint32_t* scan_tmp, void* stream_) {
+                    int max_bits, uint32_t* hist, uint32_t* scan_tmp, void* stream_) {
+    if (max_bits != 8 && max_bits != 9) return sgr_set_error(SGR_E_INVALID, "sgr_test_sort32: max_bits must be 8 or 9");
     hipStream_t stream = (hipStream_t)stream_;
     const int debug = 1;
     uint32_t* keys[2] = {keys0, keys1};
     uint32_t* vals[2] = {vals0, vals1};
-    const int cur = sgr_launch_sort_pairs32(keys, vals, n, end_bit, hist, scan_tmp, stream);
+    const int cur = sgr_launch_sort_pairs32(keys, vals, n, end_bit, hist, scan_tmp, stream, false, nullptr, nullptr, max_bits);
     SGR_STAGE("sort32");
     if (sgr_sort_get_one_sweep() && n) {  // one-sweep form: a look-back that gave up leaves its mark in the control block
         uint32_t e = 0;

@@ -201,7 +201,7 @@ int sgr_launch_sort_pairs(uint64_t* const keys[2], uint32_t* const vals[2], uint
 // into sorted order, aux_out[sorted position] = aux_in[value]
 int sgr_launch_sort_pairs32(uint32_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
                             uint32_t* scan_tmp, hipStream_t s, bool iota = false, const uint2* aux_in = nullptr,
-                            uint2* aux_out = nullptr);
+                            uint2* aux_out = nullptr, int max_bits = 8);  // max_bits: digit width cap, 8 or 9
 int sgr_sort_pass_count(int end_bit);  // passes (= buffer flips) of a sort on key bits [0, end_bit)
 
 // XCD-aware workgroup -> tile map.  The dispatcher places workgroup b on XCD b % 8 (observed, used for speed only),

@@ -402,24 +402,20 @@ int sgr_sort_get_one_sweep() {
     return v;
 }
 
-// Sorts n pairs on key bits [0, end_bit).  keys[0]/vals[0] hold the input; returns the index (0/1)
-// of the pair of buffers that holds the sorted output.  hist: sgr_sort_hist_words(n) dwords (scan_tmp is unused):
-// three launches -- the [digit][block] table + 256 totals, recomputed before every scatter pass (the per-block digit
-// histogram depends on where the previous pass left the keys);
-// one sweep -- [control: 8 x 256 digit counts, 8 tickets, error flag | status table, 256 x 64 bit per block].
-// Digit schedule of a sort on key bits [0, end_bit): npass = ceil(end_bit / 8) passes of ceil(end_bit / npass) bits each
-// (14 tile bits -> 2 x 7 instead of 8 + 6: half the bins, twice the run length in the first pass).
-// 32-bit keys, round 4: digits of up to NINE bits, so that the 27 key bits of the forward's depth sort (depth bits minus the
-// bits of 0.2, sgr_preprocess.hip) take three passes instead of four: npass = ceil(end_bit / 9) passes of ceil(end_bit / npass)
-// bits (32 -> 4 x 8, 27 -> 3 x 9, 14 -> 2 x 7).  64-bit keys (simple-knn's Morton sort) keep 8-bit digits.
-#define SGR_SORT_MAX_BITS32 9
-static inline int sort_passes32(int end_bit) {
+// Digit schedule of a sort on key bits [0, end_bit) with digits of at most `max_bits` bits: npass = ceil(end_bit / max_bits)
+// passes of ceil(end_bit / npass) bits each (14 tile bits -> 2 x 7 instead of 8 + 6: half the bins, twice the run length).
+// max_bits is 8 everywhere (so that the number of buffer flips of the tile sort is the same in the three-launch and in the
+// one-sweep form: sgr_sort_pass_count) except in the forward's depth sort, which may ask for 9 (512 bins, two per thread in
+// the scatter's prefix section): its 27 key bits then take three passes.  Measured on MI355X (tools/gpu_r4_g.sh, depth sort +
+// scan): 3 x 9 bits 0.079 / 0.109 / 0.402 ms at 500 k / 1 M / 5 M Gaussians, 4 x 7 bits 0.085 / 0.109 / 0.348 ms -- nine-bit
+// digits leave 4-key store runs, which only pays while the launches are latency-bound: chosen by n (sgr_api.hip).
+static inline int sort_passes(int end_bit, int max_bits) {
     static const int forced = [] { const char* e = getenv("SGR_SORT_BITS"); return e ? atoi(e) : 0; }();  // A/B only
-    const int maxb = forced == 8 ? 8 : SGR_SORT_MAX_BITS32;
+    const int maxb = forced == 8 ? 8 : max_bits;
     return (end_bit + maxb - 1) / maxb;
 }
-static inline int sort_pass_bits(int end_bit) {
-    const int npass = sort_passes32(end_bit);
+static inline int sort_pass_bits(int end_bit, int max_bits) {
+    const int npass = sort_passes(end_bit, max_bits);
     return npass ? (end_bit + npass - 1) / npass : 8;
 }
 // Keys per thread: large inputs use 4096-key blocks (longer store runs); small ones keep 2048 so that the launch
@@ -434,8 +430,7 @@ static inline int sort_ipt(uint32_t n) {
     return 8;
 }
 
-// passes (= buffer flips) of a 32-bit-key sort on bits [0, end_bit) in the form that is switched on
-int sgr_sort_pass_count(int end_bit) { return sgr_sort_get_one_sweep() ? (end_bit + 7) / 8 : sort_passes32(end_bit); }
+int sgr_sort_pass_count(int end_bit) { return (end_bit + 7) / 8; }  // buffer flips of a sort with the default 8-bit cap
 
 template <typename K, int BITS, int IPT>
 static void sort_pass(const K* kin, const uint32_t* vin, K* kout, uint32_t* vout, uint32_t n, int shift, uint32_t* hist,
@@ -458,7 +453,7 @@ static void sort_pass(const K* kin, const uint32_t* vin, K* kout, uint32_t* vout
 template <typename K>
 static int sort_pairs_impl(K* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
                            uint32_t* scan_tmp, hipStream_t s, bool iota = false, const uint2* aux_in = nullptr,
-                           uint2* aux_out = nullptr) {
+                           uint2* aux_out = nullptr, int max_bits = 8) {
     if (n == 0) return 0;
     int npass = (end_bit + 7) / 8;
     int cur = 0;
@@ -480,9 +475,9 @@ static int sort_pairs_impl(K* const keys[2], uint32_t* const vals[2], uint32_t n
         }
         return cur;
     }
-    const int bits = sizeof(K) == 8 ? 8 : sort_pass_bits(end_bit);
+    const int bits = sizeof(K) == 8 ? 8 : sort_pass_bits(end_bit, max_bits);
     const int ipt = sizeof(K) == 8 ? 8 : sort_ipt(n);
-    if (sizeof(K) == 4) npass = sort_passes32(end_bit);
+    if (sizeof(K) == 4) npass = sort_passes(end_bit, max_bits);
     for (int p = 0; p < npass; p++) {
         const uint32_t* vin = (iota && p == 0) ? nullptr : vals[cur];
         const bool last = p == npass - 1;
@@ -507,6 +502,6 @@ int sgr_launch_sort_pairs(uint64_t* const keys[2], uint32_t* const vals[2], uint
     return sort_pairs_impl<uint64_t>(keys, vals, n, end_bit, hist, scan_tmp, s);
 }
 int sgr_launch_sort_pairs32(uint32_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
-                            uint32_t* scan_tmp, hipStream_t s, bool iota, const uint2* aux_in, uint2* aux_out) {
-    return sort_pairs_impl<uint32_t>(keys, vals, n, end_bit, hist, scan_tmp, s, iota, aux_in, aux_out);
+                            uint32_t* scan_tmp, hipStream_t s, bool iota, const uint2* aux_in, uint2* aux_out, int max_bits) {
+    return sort_pairs_impl<uint32_t>(keys, vals, n, end_bit, hist, scan_tmp, s, iota, aux_in, aux_out, max_bits);
 }

@@ -68,13 +68,15 @@ def test_sort_pairs_stable(n, end_bit, dup, one_sweep, sort_mode):
     assert (vs == vals[order]).all()
 
 
-# end_bit 27 / 18 / 9: digits of NINE bits (512 bins, two per thread in the scatter's prefix section) -- the forward's depth
-# sort runs on 27 key bits in three such passes
-@pytest.mark.parametrize("n,end_bit,dup", [(1, 14, False), (4097, 14, True), (2_500_000, 14, True), (1_000_000, 32, False),
-                                           (20_000_003, 15, False), (1_000_001, 27, False), (300_000, 27, True), (70_001, 18, True),
-                                           (5000, 9, False)])
+# max_bits 9: digits of NINE bits (512 bins, two per thread in the scatter's prefix section) -- the forward's depth sort runs
+# on 27 key bits in three such passes below 750 k Gaussians and in four 7-bit passes above
+@pytest.mark.parametrize("n,end_bit,dup,max_bits", [(1, 14, False, 8), (4097, 14, True, 8), (2_500_000, 14, True, 8),
+                                                    (1_000_000, 32, False, 8), (20_000_003, 15, False, 8),
+                                                    (1_000_001, 27, False, 8), (1_000_001, 27, False, 9),
+                                                    (300_000, 27, True, 9), (70_001, 18, True, 9), (5000, 9, False, 9),
+                                                    (5000, 9, False, 8), (40_000, 32, False, 9)])
 @pytest.mark.parametrize("one_sweep", [False, True])
-def test_sort_pairs32_stable(n, end_bit, dup, one_sweep, sort_mode):
+def test_sort_pairs32_stable(n, end_bit, dup, max_bits, one_sweep, sort_mode):
     L, check = _lib()
     sort_mode(one_sweep)
     rng = np.random.default_rng(n + 1)
@@ -89,8 +91,8 @@ def test_sort_pairs32_stable(n, end_bit, dup, one_sweep, sort_mode):
     if n > 1:  # a first sort of other data leaves its look-back table behind: the second must not read it as its own
         kk = torch.from_numpy(np.roll(keys, 1).view(np.int32)).cuda()
         check(L.sgr_test_sort32(_vp(kk), _vp(torch.zeros_like(kk)), _vp(v0.clone()), _vp(torch.zeros_like(v0)), n, end_bit,
-                                _vp(hist), _vp(tmp), None))
-    cur = check(L.sgr_test_sort32(_vp(k0), _vp(k1), _vp(v0), _vp(v1), n, end_bit, _vp(hist), _vp(tmp), None))
+                                max_bits, _vp(hist), _vp(tmp), None))
+    cur = check(L.sgr_test_sort32(_vp(k0), _vp(k1), _vp(v0), _vp(v1), n, end_bit, max_bits, _vp(hist), _vp(tmp), None))
     torch.cuda.synchronize()
     ks = (k1 if cur else k0).cpu().numpy().view(np.uint32)
     vs = (v1 if cur else v0).cpu().numpy().view(np.uint32)
