@@ -273,7 +273,8 @@ class Workload:
 
     def counts(self):
         """R (tile instances), V (visible Gaussians) and the sum of n_contrib of this view (R/P and V/P are
-        reported with every number)."""
+        reported with every number).  R is the REFERENCE's num_rendered -- the unit SURVEY 8d's byte formulas are written in;
+        the library emits fewer instances (tile rects cut down to where alpha >= 1/255 is possible): self.R_emitted."""
         from street_gaussians_amd import _C as native
         st, p = self.st, self.params
         V = int((self.radii > 0).sum().item())
@@ -282,8 +283,10 @@ class Workload:
                                          p["scales"].detach(), p["rotations"].detach(), 1.0, torch.Tensor([]),
                                          st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy, st.image_height,
                                          st.image_width, p["shs"].detach(), 3, st.campos, False, False)
-        R = int(out[0])
-        n_contrib = native.export_internal("n_contrib", self.P, R, self.args.height, self.args.width, out[6], out[7], out[8])
+        self.R_emitted = int(out[0])
+        exp = lambda name: native.export_internal(name, self.P, self.R_emitted, self.args.height, self.args.width, out[6], out[7], out[8])
+        n_contrib = exp("n_contrib")
+        R = int(exp("num_rendered_reference")[0].item())
         self.V_in = int(native.mark_visible(p["means3D"].detach(), st.viewmatrix, st.projmatrix).sum().item())
         return R, V, int(n_contrib.to(torch.int64).sum().item())
 
@@ -833,6 +836,11 @@ def main():
                        "gaussians": args.gaussians, "width": args.width, "height": args.height, "sh_degree": 3,
                        "semantic_channels": S, "loss": args.loss, "views_per_step": world, "num_rendered_R": R, "visible_V": V,
                        "R_over_P": round(R / args.gaussians, 3), "V_over_P": round(V / args.gaussians, 3),
+                       "instances_emitted": wl.R_emitted,
+                       "instances_note": "num_rendered_R = the reference's num_rendered (3-sigma squares, auxiliary.h getRect), the "
+                                         "unit of SURVEY 8d's byte formulas; instances_emitted = what this library duplicates, sorts "
+                                         "and blends (rects cut down to the tiles where the Gaussian can reach alpha >= 1/255; "
+                                         "bit-identical images, SGR_REF_RECT=1 restores the reference's rects)",
                        "parallelism": f"view-dp{world}" + ((" + RCCL all-reduce of Gaussian grads" + (
                            " (dense 44 B/Gaussian; SH gradient rebuilt from an all-gather of per-view dRGB, 12 B/Gaussian/view)"
                            if args.reduce == "factored" else " (one 236 B/Gaussian bucket)")) if world > 1 else ""),
@@ -923,7 +931,7 @@ def other_configs(args, L, dev, fence):
             sb = stage_bytes(P, wl.V_in, V, R, args.width * args.height, ((args.width + 15) // 16) * ((args.height + 15) // 16), S)
             out.append({"config": name, "gaussians": P, "semantic_channels": S, "steps": steps,
                         "ms_per_step": round(1e3 * dt / steps, 4), "iters_per_s": round(steps / dt, 3),
-                        "num_rendered_R": R, "visible_V": V, "stages_hbm_frac": stage_hbm_frac(st, sb),
+                        "num_rendered_R": R, "instances_emitted": wl.R_emitted, "visible_V": V, "stages_hbm_frac": stage_hbm_frac(st, sb),
                         "blend_bwd_ms": round(st["blend_bwd"], 4) if st["blend_bwd"] else None,
                         "blend_fwd_ms": round(st["blend_fwd"], 4) if st["blend_fwd"] else None,
                         "blend_bwd_hbm_frac": round(bb / (st["blend_bwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if st["blend_bwd"] else None,

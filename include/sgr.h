@@ -180,7 +180,12 @@ int sgr_profile_sample(int every);
  *        5 rgb f32[3P] | 6 tiles_touched u32[P] | 7 point_offsets u32[P] | 8 point_list u32[R]
  *        9 sorted keys u64[R] | 12 ranges u32[2T] | 13 n_contrib u32[H*W] | 14 extents f32[2P]
  *        15 hit record u8[R] (bit q: the forward blended the instance into quadrant q of its tile; entries behind the
- *           last batch a tile processed are undefined)                                                     */
+ *           last batch a tile processed are undefined)
+ *        16 tile rect u32[4P] {x0, y0, x1, y1}, upper corner exclusive (zeros for a culled Gaussian): the tiles the
+ *           Gaussian was emitted for -- the reference's getRect square cut down to the tiles in which it can reach
+ *           alpha >= 1/255 (switch bit 10: the reference's own rect); 6, 7, 8, 9, 12, 13 are the reference's arrays
+ *           restricted to these rects
+ *        17 u32[1]: what num_rendered is with the reference's rects (reporting)                            */
 int sgr_export_internal(int which, int P, int R, int width, int height, char* geom_buffer, char* binning_buffer,
                         char* image_buffer, void* dst, void* stream);
 
@@ -193,7 +198,10 @@ int sgr_export_internal(int which, int P, int R, int width, int height, char* ge
  * reference's kernels, gradients within rel 1e-4 end to end,
  * bit 8 (SGR_SW=1) the S = 0 blend backward runs its scalar-walk form (csrc/sgr_blend_bwd_sw.hip: A/B design, slower),
  * bit 9 (SGR_RS_WAVE=1) the per-Gaussian row sum runs its wave-cooperative form (A/B design, slower),
- * bit 6 (SGR_PRE_STAGE=1) the preprocess stages its SH rows through LDS whatever P is (default: from 3 M Gaussians).
+ * bit 6 (SGR_PRE_STAGE=1) the preprocess stages its SH rows through LDS whatever P is (default: from 3 M Gaussians),
+ * bit 10 (SGR_REF_RECT=1) every Gaussian is emitted for the reference's whole tile rect (auxiliary.h getRect), so that
+ * num_rendered, point_list, the sorted keys and the ranges are the reference's arrays entry for entry; default: the rect
+ * cut down to the tiles where the Gaussian can pass the alpha >= 1/255 test -- fewer instances, bit-identical images (gradients: same terms, the row sum groups its additions differently).
  * mask >= 0 sets them process-wide, mask < 0 only queries; returns the previous mask.  The initial
  * value comes from the environment (SGR_NO_CULL, SGR_NO_DPP, SGR_NO_DET, SGR_NO_HITS, SGR_V2), read once. */
 int sgr_test_switches(int mask);

@@ -20,7 +20,7 @@ void sgr_launch_mark_visible(int P, const float* means3D, const float* viewmatri
 void sgr_launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, const float* rotations,
                            const float* opacities, const float* shs, const float* cov3D_precomp,
                            const float* colors_precomp, const SgrCam* cam, const SgrGeomView& gv, int* radii,
-                           int prefiltered, bool stage_sh, hipStream_t s);
+                           int prefiltered, bool stage_sh, bool tight, hipStream_t s);
 void sgr_launch_filter(int P, const float* means3D, const float* scales, const float* rotations,
                        const float* cov3D_precomp, const SgrCamArgs& ca, const SgrGeomView& gv, int* radii,
                        float* means2D, int prefiltered, hipStream_t s);
@@ -86,7 +86,8 @@ static int switches() {
     if (v < 0) {
         v = (env_flag("SGR_NO_CULL") ? 1 : 0) | (env_flag("SGR_NO_DPP") ? 2 : 0) | (env_flag("SGR_NO_DET") ? 4 : 0) |
             (env_flag("SGR_NO_HITS") ? 8 : 0) | (env_flag("SGR_V2") ? 16 : 0) | (env_flag("SGR_PRE_STAGE") ? 64 : 0) |
-            (env_flag("SGR_EXACT") ? 128 : 0) | ((env_flag("SGR_SW8") || env_flag("SGR_SW")) ? 256 : 0) | ((env_flag("SGR_SW9") || env_flag("SGR_RS_WAVE")) ? 512 : 0);
+            (env_flag("SGR_EXACT") ? 128 : 0) | ((env_flag("SGR_SW8") || env_flag("SGR_SW")) ? 256 : 0) | ((env_flag("SGR_SW9") || env_flag("SGR_RS_WAVE")) ? 512 : 0) |
+            (env_flag("SGR_REF_RECT") ? 1024 : 0);
         g_switches.store(v, std::memory_order_relaxed);
     }
     return v;
@@ -171,7 +172,7 @@ static hipEvent_t readback_event() {
 // The forward's one host wait.  hipEventSynchronize() parks the thread on an interrupt, and how long it takes to come
 // back is a property of the host (tens of microseconds on some boxes) -- time in which the GPU works off the ~0.12 ms of
 // depth sort + scan queued behind the read-back and then idles until the rest of the forward is queued.  So the thread
-// watches the pinned landing zone itself: both words were set to a value the device never writes (flag is 0 / 1,
+// watches the pinned landing zone itself: its words were set to a value the device never writes (flags are 0 / 1,
 // num_rendered < 2^31).  Bounded: after SGR_SPIN_US microseconds (default 2 ms -- the copy lands within ~0.2 ms of being
 // queued; 0 = never spin) it falls back to the
 // event, which is also what orders everything else behind the copy.
@@ -183,7 +184,8 @@ static hipError_t wait_for_readback(uint32_t* host_vals, hipEvent_t landed) {
         const auto t0 = std::chrono::steady_clock::now();
         for (;;) {
             for (int i = 0; i < 256; i++) {
-                if (hv[0] != SGR_READBACK_PENDING && hv[1] != SGR_READBACK_PENDING && hv[2] != SGR_READBACK_PENDING) {
+                if (hv[0] != SGR_READBACK_PENDING && hv[2] != SGR_READBACK_PENDING && hv[4] != SGR_READBACK_PENDING &&
+                    hv[5] != SGR_READBACK_PENDING) {
                     std::atomic_thread_fence(std::memory_order_acquire);
                     return hipSuccess;
                 }
@@ -356,12 +358,15 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
                               // (tests); the staged one wins once the launch is deep enough to be throughput-bound -- measured
                               // 346 vs 360 us at 5 M Gaussians, 98.8 vs 90.2 us at 1 M -- so it is chosen by P (switch bit 6
                               // forces it, SGR_PRE_STAGE_MIN_P moves the threshold)
-                              (switches() & 64) != 0 || P >= pre_stage_min_p(), stream);
+                              (switches() & 64) != 0 || P >= pre_stage_min_p(),
+                              // tile rects: the reference's 3-sigma squares cut down to the tiles the Gaussian can reach
+                              // alpha >= 1/255 in (sgr_preprocess.hip); switch bit 10 keeps the reference's rects
+                              (switches() & 1024) == 0, stream);
         SGR_STAGE("preprocess");
         prof_end(stream);
 
-        // K5 first: num_rendered (header[1], summed by the preprocess kernel) and the prefilter flag (header[0]) go to
-        // pinned host memory in ONE 8-byte copy.  The host only waits for THAT copy (an event), after the depth sort and
+        // K5 first: num_rendered (header[4], summed by the preprocess kernel) and the prefilter flag (header[0]) go to
+        // pinned host memory in ONE 24-byte copy.  The host only waits for THAT copy (an event), after the depth sort and
         // the scan have been queued behind it: while it wakes up, allocates the binning buffer and queues the dozen short
         // binning kernels, the GPU is busy with the ~0.15 ms of sort + scan instead of idling (rocprofv3 kernel trace:
         // ~0.2 ms of gaps per forward with the wait placed after the scan, as rasterizer_impl.cu:281 has it).
@@ -370,8 +375,8 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
         if (!host_vals || !landed) return fail(SGR_E_HIP, "pinned readback slot / event creation failed");
         // the words carry a value the device never writes, so that the host can see them arrive (wait_for_readback);
         // header[2] = "a depth beyond the 27-bit sort keys" rides along
-        host_vals[0] = host_vals[1] = host_vals[2] = SGR_READBACK_PENDING;
-        SGR_HIP(hipMemcpyAsync(host_vals, gv.header, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        host_vals[0] = host_vals[2] = host_vals[4] = host_vals[5] = SGR_READBACK_PENDING;
+        SGR_HIP(hipMemcpyAsync(host_vals, gv.header, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         SGR_HIP(hipEventRecord(landed, stream));
         // an error return between here and the wait must not leave this copy in flight: the next forward of this thread would
         // take its late arrival for its own read-back
@@ -428,8 +433,8 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     }
     if (host_vals[0] & 1u)
         return fail(SGR_E_PREFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
-    if (host_vals[1] > 0x7fffffffu) return fail(SGR_E_INVALID, "more than 2^31 tile instances");
-    const int R = (int)host_vals[1];
+    if (host_vals[4] > 0x7fffffffu || host_vals[5] > 0x7fffffffu) return fail(SGR_E_INVALID, "more than 2^31 tile instances");
+    const int R = (int)host_vals[4];
 
     if (!bbase || sgr_binning_bytes(R) > have_bytes) {
         bbase = binning_buffer(sgr_binning_bytes(R), binning_user);
@@ -786,6 +791,11 @@ __global__ void sgr_export_kernel(int which, int P, SgrGeomView gv, void* dst) {
         case 6: ((uint32_t*)dst)[i] = gv.aux[i].x; break;
         case 7: ((uint32_t*)dst)[i] = gv.u0[i] + gv.aux[i].x; break;  // the reference's inclusive index-order scan
         case 14: { const float4 a = gv.rec[4 * (size_t)i]; ((float*)dst)[2 * i] = a.z; ((float*)dst)[2 * i + 1] = a.w; } break;
+        case 16: {  // tile rect {x0, y0, x1, y1} (exclusive upper corner); all zero for a culled Gaussian
+            const uint2 a = gv.aux[i];
+            const uint32_t x0 = a.y & 1023u, y0 = (a.y >> 10) & 1023u, w = a.y >> 20, h = w ? a.x / w : 0u;
+            ((uint4*)dst)[i] = a.x ? make_uint4(x0, y0, x0 + w, y0 + h) : make_uint4(0u, 0u, 0u, 0u);
+        } break;
     }
 }
 
@@ -795,9 +805,10 @@ int sgr_export_internal(int which, int P, int R, int width, int height, char* ge
     const int debug = 1;
     const int gx = (width + SGR_BLOCK_X - 1) / SGR_BLOCK_X, gy = (height + SGR_BLOCK_Y - 1) / SGR_BLOCK_Y;
     const size_t N = (size_t)width * height, T = (size_t)gx * gy;
-    if (which <= 7 || which == 14) {
+    if (which <= 7 || which == 14 || which == 16 || which == 17) {
         if (P <= 0) return 0;
         const SgrGeomView gv = sgr_geom_carve(geom_buffer, (size_t)P);
+        if (which == 17) { SGR_HIP(hipMemcpyAsync(dst, gv.header + 5, 4, hipMemcpyDeviceToDevice, stream)); return 0; }
         if (which == 3) return fail(SGR_E_INVALID, "cov3D is not materialised (the backward recomputes it)");
         sgr_export_kernel<<<(P + 255) / 256, 256, 0, stream>>>(which, P, gv, dst);
         SGR_STAGE("export");

@@ -52,7 +52,7 @@ struct SgrGeomView {
     uint32_t* clamped;  // 3-bit mask per Gaussian, one u32 each (keeps stores simple and aligned)
     int* internal_radii;
     uint32_t* scan_tmp;   // block sums of the device-wide scan
-    uint32_t* header;     // [0]=error flag, [1]=num_rendered
+    uint32_t* header;     // [0]=error flag, [2]=depth beyond the 27-bit sort keys, [4]=num_rendered, [5]=num_rendered with the reference rects (one u64 counter), [16..]=SgrCam
 };
 
 struct SgrBinView {

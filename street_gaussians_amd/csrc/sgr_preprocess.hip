@@ -88,18 +88,18 @@ sgr_filter_kernel(int P, const float* __restrict__ means3D, const float* __restr
 // extra phases lengthen a launch that is only three rounds of workgroups deep) and 0.346 vs 0.360 ms at 5 M: not the
 // default.
 // num_rendered = sum of tiles_touched does not depend on the depth order, so it is accumulated here (one atomic per
-// workgroup into header[1]) and the host can read it back while the depth sort and the offset scan are still running.
+// workgroup into header[4]) and the host can read it back while the depth sort and the offset scan are still running.
 __global__ void __launch_bounds__(SGR_PRE_THREADS)
 sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
                       const float* __restrict__ rotations, const float* __restrict__ opacities,
                       const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
                       const float* __restrict__ colors_precomp, const SgrCam* __restrict__ camp, SgrGeomView gv,
-                      int* __restrict__ radii, int prefiltered, int stage_sh) {
+                      int* __restrict__ radii, int prefiltered, int stage_sh, int tight) {
     // rows padded to 13 float4 (52 dwords): the per-lane float4 reads of 16 consecutive rows then fall on 16 disjoint
     // 4-bank groups (a 48-dword stride puts them on 4).  Dynamic LDS: none when the rows are read directly.
     extern __shared__ float4 sSHdyn[];
     float4 (*sSH)[32 * 13] = reinterpret_cast<float4 (*)[32 * 13]>(sSHdyn);
-    __shared__ uint32_t wave_sum[SGR_PRE_THREADS / 64];
+    __shared__ uint32_t wave_sum[2 * (SGR_PRE_THREADS / 64)];
     const SgrCam& cam = *camp;
     const int gidx = blockIdx.x * SGR_PRE_THREADS + threadIdx.x;
     const bool live = gidx < P;
@@ -157,7 +157,7 @@ sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         }
     }
 
-    uint32_t n = 0;
+    uint32_t n = 0, nref = 0;
     if (live && !ok) {
         radii[idx] = 0;
         gv.aux[idx] = make_uint2(0u, 0u);
@@ -217,8 +217,31 @@ sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         const float opacity = opacities[idx];
         float hx, hy;
         sgr_extent(opacity, pr.cov_a, pr.cov_c, pr.con_x, pr.con_y, pr.con_z, hx, hy);
-        const uint32_t w = pr.rx1 - pr.rx0, h = pr.ry1 - pr.ry0;
-        const uint32_t rect = sgr_pack_rect(pr.rx0, pr.ry0, w);
+        // Tile rect of the Gaussian.  The reference takes the square of ceil(3 sigma_max) pixels around the centre
+        // (auxiliary.h:46-57 getRect) and so emits a (tile, Gaussian) instance for many tiles in which the Gaussian cannot pass
+        // the alpha >= 1/255 test of the blend (forward.cu:428-430): low opacity, anisotropy.  Those instances change nothing in
+        // any output (the blend skips them) but are duplicated, sorted, staged and given a partial-gradient row.  `tight`
+        // intersects the reference rect with the tiles of the box [px -+ hx] x [py -+ hy] outside of which alpha < 1/255
+        // (sgr_extent: conservative, the box the quadrant cull of the blend kernels has used since round 1): 0.72 of the
+        // reference's instances on the benchmark scene; every image bit-identical, the gradients equal up to the grouping of the
+        // row sum's additions (tests).  A Gaussian keeps at
+        // least one tile, so that "radius > 0" still implies "owns a row".  rn = the reference's count (reported, header[5]).
+        uint32_t x0 = pr.rx0, x1 = pr.rx1, y0 = pr.ry0, y1 = pr.ry1;
+        const uint32_t rn = (x1 - x0) * (y1 - y0);
+        if (tight) {
+            // pixel x of tile t: 16 t .. 16 t + 15; pixels that can pass lie in [px - hx, px + hx]  (NaN extents: fmaxf / fminf
+            // return the other operand = the reference rect)
+            const float inv = 1.0f / SGR_BLOCK_X;
+            static_assert(SGR_BLOCK_X == SGR_BLOCK_Y, "square tiles");
+            float fx0 = fmaxf(floorf((pr.px - hx) * inv), (float)x0), fx1 = fminf(floorf((pr.px + hx) * inv) + 1.0f, (float)x1);
+            float fy0 = fmaxf(floorf((pr.py - hy) * inv), (float)y0), fy1 = fminf(floorf((pr.py + hy) * inv) + 1.0f, (float)y1);
+            if (!(fx0 < fx1)) { fx0 = fminf(fmaxf(floorf(pr.px * inv), (float)x0), (float)(x1 - 1)); fx1 = fx0 + 1.0f; }
+            if (!(fy0 < fy1)) { fy0 = fminf(fmaxf(floorf(pr.py * inv), (float)y0), (float)(y1 - 1)); fy1 = fy0 + 1.0f; }
+            x0 = (uint32_t)fx0; x1 = (uint32_t)fx1; y0 = (uint32_t)fy0; y1 = (uint32_t)fy1;
+        }
+        const uint32_t w = x1 - x0, h = y1 - y0;
+        const uint32_t rect = sgr_pack_rect(x0, y0, w);
+        nref = rn;
         float4* rec = gv.rec + 4 * (size_t)idx;
         rec[0] = make_float4(pr.px, pr.py, hx, hy);
         rec[1] = make_float4(pr.con_x, pr.con_y, pr.con_z, opacity);
@@ -242,14 +265,16 @@ sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     // device-scope atomics on one address are resolved beyond the per-XCD L2s (~6 ns each, serialised): one per
     // workgroup, not one per wave (16k of them cost 0.1 ms at P = 1M)
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) n += __shfl_xor(n, m, 64);
-    if (lane == 0) wave_sum[wave] = n;
+    for (int m = 32; m >= 1; m >>= 1) { n += __shfl_xor(n, m, 64); nref += __shfl_xor(nref, m, 64); }
+    if (lane == 0) { wave_sum[wave] = n; wave_sum[SGR_PRE_THREADS / 64 + wave] = nref; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t t = 0;
+        uint32_t t = 0, tr = 0;
 #pragma unroll
-        for (int i = 0; i < SGR_PRE_THREADS / 64; i++) t += wave_sum[i];
-        if (t) atomicAdd(&gv.header[1], t);
+        for (int i = 0; i < SGR_PRE_THREADS / 64; i++) { t += wave_sum[i]; tr += wave_sum[SGR_PRE_THREADS / 64 + i]; }
+        // ONE 64-bit atomic for both sums (header[4] = num_rendered, header[5] = what it is with the reference's rects, reported
+        // only): a second 32-bit atomic per workgroup cost 0.03 ms at 1 M Gaussians and 0.18 ms at 5 M (measured)
+        if (tr) atomicAdd(reinterpret_cast<unsigned long long*>(gv.header + 4), (unsigned long long)t | ((unsigned long long)tr << 32));
     }
 }
 
@@ -346,13 +371,13 @@ void sgr_launch_mark_visible(int P, const float* means3D, const float* viewmatri
 void sgr_launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, const float* rotations,
                            const float* opacities, const float* shs, const float* cov3D_precomp,
                            const float* colors_precomp, const SgrCam* cam, const SgrGeomView& gv, int* radii,
-                           int prefiltered, bool stage_sh, hipStream_t s) {
+                           int prefiltered, bool stage_sh, bool tight, hipStream_t s) {
     if (P <= 0) return;
     const bool stage = stage_sh && shs != nullptr && colors_precomp == nullptr && M == 16;
     const size_t lds = stage ? (size_t)(SGR_PRE_THREADS / 64) * 32 * 13 * sizeof(float4) : 0;
     sgr_preprocess_kernel<<<(P + SGR_PRE_THREADS - 1) / SGR_PRE_THREADS, SGR_PRE_THREADS, lds, s>>>(
         P, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, cam, gv, radii, prefiltered,
-        stage ? 1 : 0);
+        stage ? 1 : 0, tight ? 1 : 0);
 }
 
 void sgr_launch_filter(int P, const float* means3D, const float* scales, const float* rotations,

@@ -225,19 +225,23 @@ def exact_mode_against_reference_kernels(kw, wts, S, label, rf=None, gref=None, 
     golden = isinstance(rf, dict)
     get = (lambda k: np.asarray(rf[k])) if golden else (lambda k: npy(getattr(rf, k)))
     R = int(rf["num_rendered"]) if golden else rf.num_rendered
-    assert res["R"] == R, label
+    assert int(internal("num_rendered_reference")[0]) == R, label
+    # the binning arrays: the reference's, restricted to the tile rects the HIP path emits (restrict_binning)
+    if golden:
+        b = restrict_binning(internal, rf["point_list"], rf["ranges"], int(kw["image_width"]), int(kw["image_height"]))
+    else:
+        b = restrict_oracle(internal, rf, kw)
+    assert res["R"] == b.num_rendered, label
     assert (npy(res["radii"]) == get("radii")).all(), label
     if R:
-        pl = np.asarray(rf["point_list"]) if golden else npy(rf.internal("point_list")).view(np.uint32)
-        assert (npy(internal("point_list")).view(np.uint32) == pl).all(), label
+        assert (npy(internal("point_list")).view(np.uint32) == b.point_list).all(), label
         if not golden:
-            assert (npy(internal("keys")).view(np.uint64) == npy(rf.internal("keys")).view(np.uint64)).all(), label
-    rg = np.asarray(rf["ranges"]) if golden else npy(rf.internal("ranges")).view(np.uint32)
-    assert (npy(internal("ranges")).view(np.uint32).reshape(-1) == rg.reshape(-1)).all(), label
+            assert (npy(internal("keys")).view(np.uint64) == b.keys).all(), label
+    assert (npy(internal("ranges")).view(np.uint32).reshape(-1) == b.ranges.reshape(-1)).all(), label
     for k in ["alpha", "depth"] + (["semantic"] if S else []):
         assert np.array_equal(npy(res[k]).reshape(-1), get(k).reshape(-1)), f"{label}: {k} image not bit-identical"
     if not golden:
-        assert torch.equal(internal("n_contrib").view(torch.int32).reshape(-1), rf.internal("n_contrib").reshape(-1)), label
+        assert np.array_equal(npy(internal("n_contrib")).view(np.uint32).reshape(-1), b.n_contrib.reshape(-1)), label
     image_close(npy(res["color"]).reshape(-1), get("color").reshape(-1), rel=color_rel, name=f"exact {label}: color", max_outliers=0)
     for k in GRAD_NAMES:
         if k == "semantics" and not S:
@@ -248,3 +252,60 @@ def exact_mode_against_reference_kernels(kw, wts, S, label, rf=None, gref=None, 
     if own:
         rf.free()
     return res, g
+
+
+def restrict_binning(internal, point_list, ranges, W, H, keys=None, n_contrib=None):
+    """The reference's binning arrays RESTRICTED to the tile rects the HIP path emitted its Gaussians for.
+
+    The reference emits a (tile, Gaussian) instance for every tile of the square getRect gives (auxiliary.h:46-57); the HIP
+    path cuts that rect down to the tiles in which the Gaussian can reach alpha >= 1/255 (sgr_preprocess.hip; with
+    sgr_test_switches bit 10 it keeps the reference's rect and this function is the identity).  What it must hold is then:
+    its sorted list is the reference's sorted list with the instances outside the rects REMOVED and nothing else changed --
+    same order, same ranges after the removal, n_contrib counting only the instances that stayed.  (That the removed
+    instances change no output is what the image / gradient gates and test_tight_rects_are_invisible check.)
+
+    point_list [R], ranges [T, 2] (, keys [R], n_contrib [H, W]): the reference's arrays (oracle, oracle/_ref or golden file).
+    -> namespace(num_rendered, point_list, ranges, tiles_touched, point_offsets, keys, n_contrib, rect)."""
+    from types import SimpleNamespace
+    rect = npy(internal("tile_rect")).astype(np.int64)
+    P = rect.shape[0]
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    T = gx * gy
+    pl = np.asarray(point_list).astype(np.int64).reshape(-1)
+    rg = np.asarray(ranges).astype(np.int64).reshape(T, 2)
+    tile_of = np.repeat(np.arange(T, dtype=np.int64), rg[:, 1] - rg[:, 0])  # the list is sorted by tile, ranges are contiguous
+    assert tile_of.shape[0] == pl.shape[0]
+    tx, ty = tile_of % gx, tile_of // gx
+    r = rect[pl] if pl.size else np.zeros((0, 4), np.int64)
+    keep = (tx >= r[:, 0]) & (tx < r[:, 2]) & (ty >= r[:, 1]) & (ty < r[:, 3])
+    cum = np.concatenate([[0], np.cumsum(keep)])
+    new_rg = np.stack([cum[rg[:, 0]], cum[rg[:, 1]]], axis=1)
+    new_rg[new_rg[:, 0] == new_rg[:, 1]] = 0  # a tile nothing was emitted for keeps its memset (rasterizer_impl.cu:313)
+    tt = (rect[:, 2] - rect[:, 0]) * (rect[:, 3] - rect[:, 1])
+    # every rect lies inside the reference's: the reference has an instance for each of its tiles
+    assert (np.bincount(pl[keep], minlength=P) == tt).all(), "a HIP tile rect is not inside the reference's"
+    out = SimpleNamespace(num_rendered=int(keep.sum()), point_list=pl[keep].astype(np.uint32), ranges=new_rg.astype(np.uint32),
+                          tiles_touched=tt.astype(np.uint32), point_offsets=np.cumsum(tt).astype(np.uint32), keys=None,
+                          n_contrib=None, rect=rect, removed=int((~keep).sum()))
+    if keys is not None:
+        out.keys = np.asarray(keys).reshape(-1)[keep]
+    if n_contrib is not None:
+        nc = np.asarray(n_contrib).astype(np.int64).reshape(H, W)
+        ys, xs = np.mgrid[0:H, 0:W]
+        s = rg[(ys // 16) * gx + xs // 16, 0]
+        out.n_contrib = (cum[s + nc] - cum[s]).astype(np.uint32)
+    return out
+
+
+def restrict_oracle(internal, fw, kw):
+    """restrict_binning for a forward result of the C oracle (oracle.ForwardResult) / of oracle/_ref (ref.RefForward)."""
+    W, H = int(kw["image_width"]), int(kw["image_height"])
+    if hasattr(fw, "internal"):  # the reference's kernels: device tensors behind internal(name)
+        g = lambda k, dt: npy(fw.internal(k)).view(dt)
+        return restrict_binning(internal, g("point_list", np.uint32), g("ranges", np.uint32), W, H, keys=g("keys", np.uint64),
+                                n_contrib=g("n_contrib", np.uint32))
+    if fw.num_rendered == 0:
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        return restrict_binning(internal, np.zeros(0, np.uint32), np.zeros((T, 2), np.uint32), W, H, keys=np.zeros(0, np.uint64),
+                                n_contrib=np.zeros((H, W), np.uint32))
+    return restrict_binning(internal, fw.point_list, fw.ranges, W, H, keys=fw.keys, n_contrib=fw.n_contrib)

@@ -49,7 +49,7 @@ def test_replay_reference_call_site(path):
                         sh_degree=st["sh_degree"], scale_modifier=st["scale_modifier"], shs=kw["shs"],
                         colors_precomp=kw["colors_precomp"], scales=kw["scales"], rotations=kw["rotations"],
                         cov3D_precomp=kw["cov3D_precomp"], semantics=kw["semantics"])
-    assert rast_mod.last_num_rendered() == fw.num_rendered
+    assert 0 < rast_mod.last_num_rendered() <= fw.num_rendered  # (tile rects cut down to where alpha >= 1/255 is possible)
     assert (npy(radii) == fw.radii).all()
     S = 0 if kw["semantics"] is None else kw["semantics"].shape[1]
     assert semantic.shape == (S, st["image_height"], st["image_width"])

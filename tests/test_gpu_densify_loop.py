@@ -18,7 +18,7 @@ import pytest
 import torch
 
 import torch_ref_densify as ref
-from gpu_utils import grad_close, image_close, npy, raw_forward, settings
+from gpu_utils import grad_close, image_close, npy, raw_forward, restrict_oracle, settings
 from helpers import oracle_kwargs
 from oracle import oracle
 from street_gaussians_amd import densify, rasterizer, scene
@@ -63,12 +63,13 @@ def _check_against_oracle(cam, sc, wts, S):
     kw = oracle_kwargs(cam, sc, bg=torch.tensor([0.1, 0.2, 0.3]))
     fw = oracle.forward(**kw)
     res, internal = raw_forward(kw)
-    assert res["R"] == fw.num_rendered
+    b = restrict_oracle(internal, fw, kw)  # the oracle's binning arrays restricted to the emitted tile rects
+    assert res["R"] == b.num_rendered
     assert (npy(res["radii"]) == fw.radii).all()
-    assert (npy(internal("tiles_touched")).view(np.uint32) == fw.tiles_touched).all()
-    assert (npy(internal("keys")).view(np.uint64) == fw.keys).all()
-    assert (npy(internal("point_list")).view(np.uint32) == fw.point_list).all()
-    assert (npy(internal("ranges")).view(np.uint32) == fw.ranges).all()
+    assert (npy(internal("tiles_touched")).view(np.uint32) == b.tiles_touched).all()
+    assert (npy(internal("keys")).view(np.uint64) == b.keys).all()
+    assert (npy(internal("point_list")).view(np.uint32) == b.point_list).all()
+    assert (npy(internal("ranges")).view(np.uint32) == b.ranges).all()
     for k in ["color", "depth", "alpha"] + (["semantic"] if S else []):
         image_close(npy(res[k]), getattr(fw, k), name=f"post-densify {k}")
     out, t, radii = _render(cam, sc, wts, S=S)

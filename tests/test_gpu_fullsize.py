@@ -25,7 +25,7 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_utils import npy, raw_backward, raw_forward
+from gpu_utils import npy, raw_backward, raw_forward, restrict_oracle
 from helpers import oracle_kwargs
 from oracle import oracle
 from street_gaussians_amd import synthetic as syn
@@ -118,21 +118,24 @@ def test_baseline_size_matches_oracle(name, P, S):
     ref = oracle.backward(fw, wts["color"], wts["depth"], wts["alpha"], gsem, parallel="exact")
     fw.alpha = own_alpha
 
-    rec = dict(P=P, S=S, R=int(fw.num_rendered), V=int((fw.radii > 0).sum()), images={}, grads={}, grads_end_to_end={})
-    # ---- integer / index outputs: bit exact
-    assert res["R"] == fw.num_rendered
+    # ---- integer / index outputs: bit exact (binning arrays: the oracle's restricted to the emitted tile rects)
+    b = restrict_oracle(internal, fw, kw)
+    rec = dict(P=P, S=S, R=int(fw.num_rendered), R_emitted=b.num_rendered, V=int((fw.radii > 0).sum()), images={}, grads={},
+               grads_end_to_end={})
+    assert res["R"] == b.num_rendered and int(internal("num_rendered_reference")[0]) == fw.num_rendered
     assert (npy(res["radii"]) == fw.radii).all()
-    assert (npy(internal("tiles_touched")).view(np.uint32) == fw.tiles_touched).all()
-    assert (npy(internal("point_offsets")).view(np.uint32) == fw.point_offsets).all()
-    assert (npy(internal("keys")).view(np.uint64) == fw.keys).all()
-    assert (npy(internal("point_list")).view(np.uint32) == fw.point_list).all()
-    assert (npy(internal("ranges")).view(np.uint32) == fw.ranges).all()
+    assert (npy(internal("tiles_touched")).view(np.uint32) == b.tiles_touched).all()
+    assert (npy(internal("point_offsets")).view(np.uint32) == b.point_offsets).all()
+    assert (npy(internal("keys")).view(np.uint64) == b.keys).all()
+    assert (npy(internal("point_list")).view(np.uint32) == b.point_list).all()
+    assert (npy(internal("ranges")).view(np.uint32) == b.ranges).all()
     vis = fw.radii > 0
     assert (npy(internal("depths"))[vis] == fw.depths[vis]).all()
     assert (npy(internal("means2D"))[vis] == fw.means2D[vis]).all()
     assert (npy(internal("conic_opacity"))[vis] == fw.conic_opacity[vis]).all()
     nc = npy(internal("n_contrib")).view(np.uint32).reshape(H, W)
-    rec["n_contrib_diff_frac"] = float((nc != fw.n_contrib).mean())
+    rec["n_contrib_diff_frac"] = float((nc != b.n_contrib).mean())
+    del b
     # ---- images
     for k in ["color", "depth", "alpha", "semantic"]:
         rec["images"][k] = _image_stats(npy(res[k]), getattr(fw, k))
@@ -248,16 +251,19 @@ def test_threeway_against_reference_kernels_at_baseline_size(name, P, S):
     g = raw_backward(kw, res, wts)
     torch.cuda.synchronize()
 
-    # integers: all three identical
-    assert ref_int["R"] == fw.num_rendered == res["R"]
+    # integers: the reference's kernels and the C oracle identical; the HIP path = the same arrays restricted to the tile
+    # rects it emits (gpu_utils.restrict_binning)
+    b = restrict_oracle(internal, fw, kw)
+    assert ref_int["R"] == fw.num_rendered == int(internal("num_rendered_reference")[0]) and res["R"] == b.num_rendered
     assert (ref_int["radii"] == fw.radii).all() and (npy(res["radii"]) == fw.radii).all()
-    assert (ref_int["keys"] == fw.keys).all() and (npy(internal("keys")).view(np.uint64) == fw.keys).all()
+    assert (ref_int["keys"] == fw.keys).all() and (npy(internal("keys")).view(np.uint64) == b.keys).all()
     assert (ref_int["point_list"] == fw.point_list).all()
-    assert (npy(internal("point_list")).view(np.uint32) == fw.point_list).all()
+    assert (npy(internal("point_list")).view(np.uint32) == b.point_list).all()
     assert (ref_int["ranges"].reshape(-1) == fw.ranges.reshape(-1)).all()
-    assert (npy(internal("ranges")).view(np.uint32).reshape(-1) == fw.ranges.reshape(-1)).all()
+    assert (npy(internal("ranges")).view(np.uint32).reshape(-1) == b.ranges.reshape(-1)).all()
 
-    rec = dict(P=P, S=S, R=int(fw.num_rendered), images={}, grads={})
+    rec = dict(P=P, S=S, R=int(fw.num_rendered), R_emitted=b.num_rendered, images={}, grads={})
+    del b
     if gfmad is not None:
         rec["fmad_build_integers"] = fmad_int
     for k in ["color", "depth", "alpha"] + (["semantic"] if S else []):

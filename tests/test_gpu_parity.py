@@ -15,7 +15,8 @@ import pytest
 import torch
 
 from gpu_utils import (conditioned_allowance, dev, exact_mode_against_reference_kernels, grad_close, image_close, npy,
-                       oracle_backward_same_state, raw_backward, raw_forward, settings, strict_gate, switches)
+                       oracle_backward_same_state, raw_backward, raw_forward, restrict_binning, restrict_oracle, settings,
+                       strict_gate, switches)
 from street_gaussians_amd import _C
 from helpers import oracle_kwargs, small_case
 from oracle import oracle
@@ -97,14 +98,26 @@ def test_forward_matches_oracle(name):
     fw = oracle.forward(**kw)
     res, internal = raw_forward(kw)
     P, H, W = sc.P, cam.image_height, cam.image_width
-    # ---- integer / index outputs: bit exact
-    assert res["R"] == fw.num_rendered
+    # ---- integer / index outputs: bit exact (the binning arrays = the oracle's restricted to the emitted tile rects)
+    b = restrict_oracle(internal, fw, kw)
+    assert res["R"] == b.num_rendered
     assert (npy(res["radii"]) == fw.radii).all()
-    assert (npy(internal("tiles_touched")).view(np.uint32) == fw.tiles_touched).all()
-    assert (npy(internal("point_offsets")).view(np.uint32) == fw.point_offsets).all()
-    assert (npy(internal("keys")).view(np.uint64) == fw.keys).all()
-    assert (npy(internal("point_list")).view(np.uint32) == fw.point_list).all()
-    assert (npy(internal("ranges")).view(np.uint32) == fw.ranges).all()
+    assert (npy(internal("tiles_touched")).view(np.uint32) == b.tiles_touched).all()
+    assert (npy(internal("point_offsets")).view(np.uint32) == b.point_offsets).all()
+    assert (npy(internal("keys")).view(np.uint64) == b.keys).all()
+    assert (npy(internal("point_list")).view(np.uint32) == b.point_list).all()
+    assert (npy(internal("ranges")).view(np.uint32) == b.ranges).all()
+    with switches(_C.test_switches(-1) | _C.REF_RECT):  # with the reference's rects: the oracle's arrays entry for entry
+        res_r, int_r = raw_forward(kw)
+        assert res_r["R"] == fw.num_rendered and int(int_r("num_rendered_reference")[0]) == fw.num_rendered
+        assert (npy(int_r("tiles_touched")).view(np.uint32) == fw.tiles_touched).all()
+        assert (npy(int_r("point_offsets")).view(np.uint32) == fw.point_offsets).all()
+        assert (npy(int_r("keys")).view(np.uint64) == fw.keys).all()
+        assert (npy(int_r("point_list")).view(np.uint32) == fw.point_list).all()
+        assert (npy(int_r("ranges")).view(np.uint32) == fw.ranges).all()
+        for k in ["color", "depth", "alpha", "semantic"]:  # the instances the tight rects leave out change no pixel
+            assert torch.equal(res[k], res_r[k]), f"tile rects changed {k}"
+    assert int(internal("num_rendered_reference")[0]) == fw.num_rendered
     vis = fw.radii > 0
     # ---- preprocess floats (contraction off on both sides -> exact)
     assert (npy(internal("depths"))[vis] == fw.depths[vis]).all()
@@ -118,7 +131,7 @@ def test_forward_matches_oracle(name):
     image_close(npy(res["alpha"]), fw.alpha, name="alpha")
     image_close(npy(res["semantic"]), fw.semantic, name="semantic")
     nc = npy(internal("n_contrib")).view(np.uint32).reshape(H, W)
-    assert (nc != fw.n_contrib).mean() <= 1e-3, "n_contrib differs beyond exp-ulp flips"
+    assert (nc != b.n_contrib).mean() <= 1e-3, "n_contrib differs beyond exp-ulp flips"
     fw.free()
 
 
@@ -272,6 +285,54 @@ def test_culling_is_invisible_and_backward_is_deterministic(name):
 
 
 @pytest.mark.parametrize("mode", ["default", "exact"])
+@pytest.mark.parametrize("name", list(CASES))
+def test_tight_rects_are_invisible(name, mode):
+    """The forward emits a Gaussian only for the tiles of the reference's rect (auxiliary.h:46-57) in which it can reach
+    alpha >= 1/255 (sgr_preprocess.hip; sgr_test_switches bit 10 = the reference's whole rect).  The instances left out are
+    ones the blend skips (forward.cu:428-430): every image must be bit-identical between the two forms -- including the
+    ill-conditioned splats, whose conic cancels in fp32 --, the gradients equal up to the grouping of the row sum's additions,
+    and the emitted list must be the full list with exactly those instances removed."""
+    cam, sc, kw = _kw(name)
+    S = sc.semantics.shape[1]
+    wts = syn.loss_weights(cam, S=S)
+    base = _C.test_switches(-1) | (_C.EXACT if mode == "exact" else 0)
+    with switches(base | _C.REF_RECT):
+        res_r, int_r = raw_forward(kw)
+        g_r = raw_backward(kw, res_r, wts)
+        full = dict(point_list=npy(int_r("point_list")).view(np.uint32), ranges=npy(int_r("ranges")).view(np.uint32),
+                    keys=npy(int_r("keys")).view(np.uint64), n_contrib=npy(int_r("n_contrib")).view(np.uint32))
+        rect_r = npy(int_r("tile_rect"))
+    with switches(base):
+        res, internal = raw_forward(kw)
+        g = raw_backward(kw, res, wts)
+        torch.cuda.synchronize()
+        assert int(internal("num_rendered_reference")[0]) == res_r["R"]
+        b = restrict_binning(internal, full["point_list"], full["ranges"], cam.image_width, cam.image_height, keys=full["keys"],
+                             n_contrib=full["n_contrib"])
+        assert res["R"] == b.num_rendered <= res_r["R"]
+        assert (npy(internal("point_list")).view(np.uint32) == b.point_list).all()
+        assert (npy(internal("keys")).view(np.uint64) == b.keys).all()
+        assert (npy(internal("ranges")).view(np.uint32) == b.ranges).all()
+        assert (npy(internal("n_contrib")).view(np.uint32).reshape(-1) == b.n_contrib.reshape(-1)).all()
+        rect = npy(internal("tile_rect"))
+        vis = npy(res["radii"]) > 0
+        assert (rect[vis, 0] >= rect_r[vis, 0]).all() and (rect[vis, 2] <= rect_r[vis, 2]).all()
+        assert (rect[vis, 1] >= rect_r[vis, 1]).all() and (rect[vis, 3] <= rect_r[vis, 3]).all()
+        assert ((rect[vis, 2] > rect[vis, 0]) & (rect[vis, 3] > rect[vis, 1])).all(), "a visible Gaussian without a tile"
+        assert (rect[~vis] == 0).all()
+    assert torch.equal(res["radii"], res_r["radii"])
+    for k in ["color", "depth", "alpha", "semantic"]:
+        assert torch.equal(res[k], res_r[k]), f"tile rects changed {k}"
+    # gradients: the same (pixel, Gaussian) terms; a Gaussian's partial rows are numbered inside its rect and the row sum adds
+    # rows q, q + 4, ... per lane, so removing rows regroups the fp32 additions -- equal up to that rounding
+    if name not in ILL_CONDITIONED:
+        for k in g:
+            grad_close(npy(g[k]), npy(g_r[k]), rel=1e-4, abs_frac=2e-5, name=f"tile rects:{k}", max_outlier_frac=0.0)
+    if name == "mid_20k_sem3":
+        assert res["R"] < 0.9 * res_r["R"]  # the point of it: far fewer instances to duplicate, sort, stage and reduce
+
+
+@pytest.mark.parametrize("mode", ["default", "exact"])
 @pytest.mark.parametrize("P,S,scale_px", [(1, 0, 0.8), (2, 20, 0.3), (65, 1, 0.05), (129, 7, 0.02)])
 def test_edge_sizes(P, S, scale_px, mode):
     """Ragged sizes: fewer Gaussians than a wave, one Gaussian covering the whole tile grid (a single owner of every
@@ -288,10 +349,11 @@ def test_edge_sizes(P, S, scale_px, mode):
     fw = oracle.forward(**kw)
     ref = oracle.backward(fw, wts["color"], wts["depth"], wts["alpha"], wts["semantic"] if S else None)
     res, internal = raw_forward(kw)
-    assert res["R"] == fw.num_rendered and fw.num_rendered > 0
+    b = restrict_oracle(internal, fw, kw)
+    assert res["R"] == b.num_rendered and b.num_rendered > 0
     assert (npy(res["radii"]) == fw.radii).all()
-    assert (npy(internal("point_list")).view(np.uint32) == fw.point_list).all()
-    assert (npy(internal("ranges")).view(np.uint32) == fw.ranges).all()
+    assert (npy(internal("point_list")).view(np.uint32) == b.point_list).all()
+    assert (npy(internal("ranges")).view(np.uint32) == b.ranges).all()
     image_close(npy(res["color"]), fw.color, name="color")
     image_close(npy(res["alpha"]), fw.alpha, name="alpha")
     image_close(npy(res["semantic"]), fw.semantic, name="semantic")
@@ -368,12 +430,13 @@ def test_random_scenes_against_oracle(seed, mode):
     fw = oracle.forward(**kw)
     ref = oracle.backward(fw, wts["color"], wts["depth"], wts["alpha"], wts["semantic"] if S else None)
     res, internal = raw_forward(kw)
-    assert res["R"] == fw.num_rendered
+    b = restrict_oracle(internal, fw, kw)
+    assert res["R"] == b.num_rendered
     assert (npy(res["radii"]) == fw.radii).all()
-    if fw.num_rendered:
-        assert (npy(internal("point_list")).view(np.uint32) == fw.point_list).all()
-        assert (npy(internal("keys")).view(np.uint64) == fw.keys).all()
-    assert (npy(internal("ranges")).view(np.uint32) == fw.ranges).all()
+    if b.num_rendered:
+        assert (npy(internal("point_list")).view(np.uint32) == b.point_list).all()
+        assert (npy(internal("keys")).view(np.uint64) == b.keys).all()
+    assert (npy(internal("ranges")).view(np.uint32) == b.ranges).all()
     image_close(npy(res["color"]), fw.color, name="color")
     image_close(npy(res["depth"]), fw.depth, name="depth")
     image_close(npy(res["alpha"]), fw.alpha, name="alpha")
@@ -396,7 +459,7 @@ def test_every_channel_width_against_oracle(S):
     wts = syn.loss_weights(cam, S=S, seed=S)
     fw = oracle.forward(**kw)
     res, internal = raw_forward(kw)
-    assert res["R"] == fw.num_rendered
+    assert res["R"] == restrict_oracle(internal, fw, kw).num_rendered
     image_close(npy(res["semantic"]), fw.semantic, name="semantic")
     image_close(npy(res["color"]), fw.color, name="color")
     g = raw_backward(kw, res, wts)
@@ -458,7 +521,8 @@ def test_precomputed_colors_and_cov3D():
     wts = syn.loss_weights(cam, S=3)
     ref = oracle.backward(fw, wts["color"], wts["depth"], wts["alpha"], wts["semantic"])
     res, internal = raw_forward(kw)
-    assert res["R"] == fw.num_rendered and (npy(internal("point_list")).view(np.uint32) == fw.point_list).all()
+    b = restrict_oracle(internal, fw, kw)
+    assert res["R"] == b.num_rendered and (npy(internal("point_list")).view(np.uint32) == b.point_list).all()
     image_close(npy(res["color"]), fw.color, name="color")
     gr = raw_backward(kw, res, wts)
     for k in ["means2D", "colors", "opacity", "means3D", "cov3D", "semantics"]:
@@ -586,10 +650,11 @@ def test_far_depths_fall_back_to_the_32_bit_depth_sort():
     assert (fw.depths[fw.radii > 0] > 13107.2).sum() >= 3 and (fw.depths[fw.radii > 0] < 13107.2).sum() > 100
     for _ in range(2):  # the first call takes the repeat, the second starts with the wide sort (kept for the next 64 forwards)
         res, internal = raw_forward(kw)
-        assert res["R"] == fw.num_rendered
-        assert (npy(internal("keys")).view(np.uint64) == fw.keys).all()
-        assert (npy(internal("point_list")).view(np.uint32) == fw.point_list).all()
-        assert (npy(internal("point_offsets")).view(np.uint32) == fw.point_offsets).all()
+        b = restrict_oracle(internal, fw, kw)
+        assert res["R"] == b.num_rendered
+        assert (npy(internal("keys")).view(np.uint64) == b.keys).all()
+        assert (npy(internal("point_list")).view(np.uint32) == b.point_list).all()
+        assert (npy(internal("point_offsets")).view(np.uint32) == b.point_offsets).all()
         image_close(npy(res["color"]), fw.color, name="far color")
     fw.free()
 
@@ -633,12 +698,16 @@ def test_against_reference_kernels(name):
     fw = oracle.forward(**kw)
     res, internal = raw_forward(kw)
     # the reference build, the C oracle and the HIP path agree on every integer output
-    assert rf.num_rendered == fw.num_rendered == res["R"]
+    # (the HIP path: the same arrays restricted to the tile rects it emits -- gpu_utils.restrict_binning)
+    b = restrict_oracle(internal, rf, kw)
+    assert rf.num_rendered == fw.num_rendered and res["R"] == b.num_rendered
     assert (npy(rf.radii) == fw.radii).all() and (npy(res["radii"]) == fw.radii).all()
     assert (npy(rf.internal("point_list")).view(np.uint32) == fw.point_list).all()
     assert (npy(rf.internal("keys")).view(np.uint64) == fw.keys).all()
     assert (npy(rf.internal("ranges")).view(np.uint32) == fw.ranges).all()
-    assert (npy(internal("point_list")).view(np.uint32) == fw.point_list).all()
+    assert (npy(internal("point_list")).view(np.uint32) == b.point_list).all()
+    assert (npy(internal("keys")).view(np.uint64) == b.keys).all()
+    assert (npy(internal("ranges")).view(np.uint32) == b.ranges).all()
     for k in ["color", "depth", "alpha", "semantic"]:
         image_close(npy(res[k]), npy(getattr(rf, k)), name=f"hip vs ref {k}")
         image_close(getattr(fw, k), npy(getattr(rf, k)), name=f"oracle vs ref {k}")
@@ -678,10 +747,11 @@ def test_golden_fixture(path, mode):
         exact_mode_against_reference_kernels(kw, wts, S, "golden " + os.path.basename(path), rf=gold, gref=gold)
         return
     res, internal = raw_forward(kw)
-    assert res["R"] == int(gold["num_rendered"])
+    b = restrict_binning(internal, gold["point_list"], gold["ranges"], int(kw["image_width"]), int(kw["image_height"]))
+    assert res["R"] == b.num_rendered and int(internal("num_rendered_reference")[0]) == int(gold["num_rendered"])
     assert (npy(res["radii"]) == gold["radii"]).all()
-    assert (npy(internal("point_list")).view(np.uint32) == gold["point_list"]).all()
-    assert (npy(internal("ranges")).view(np.uint32) == gold["ranges"]).all()
+    assert (npy(internal("point_list")).view(np.uint32) == b.point_list).all()
+    assert (npy(internal("ranges")).view(np.uint32) == b.ranges).all()
     for k in ["color", "depth", "alpha", "semantic"]:
         image_close(npy(res[k]), gold[k], name=f"golden {k}")
     g = raw_backward(kw, res, wts)
@@ -741,6 +811,16 @@ def test_full_size_properties(P, S):
     lhs = npy(g["colors"]).astype(np.float64).sum(0)
     rhs = (wts["color"].numpy().astype(np.float64) * a.astype(np.float64)).sum((1, 2))
     assert np.abs(lhs - rhs).max() <= 1e-3 * np.abs(rhs).max() + 1e-2
+    # ... and so are the tile rects (the reference's 3-sigma squares against the ones cut down to where alpha >= 1/255 is
+    # possible): the same images bit for bit, the same gradients, from three quarters of the instances
+    with switches(_C.REF_RECT):
+        res3, _ = raw_forward(kw)
+        g3 = raw_backward(kw, res3, wts)
+    assert int(internal("num_rendered_reference")[0]) == res3["R"] and R < 0.8 * res3["R"]
+    for k in ["color", "depth", "alpha", "semantic"]:
+        assert torch.equal(res[k], res3[k]), k
+    for k in g:  # (the row sum groups its additions by row number: equal up to fp32 rounding)
+        grad_close(npy(g[k]), npy(g3[k]), rel=1e-4, abs_frac=2e-5, name=f"tile rects, full size:{k}", max_outlier_frac=0.0)
 
 
 def test_pybind_and_ctypes_bindings_agree():
@@ -844,7 +924,8 @@ def test_exact_parity_mode_is_bit_faithful_to_the_reference_kernels(S):
         torch.cuda.synchronize()
     for k in ["alpha", "depth"] + (["semantic"] if S else []):
         assert torch.equal(res[k], getattr(rf, k)), k
-    assert torch.equal(internal("n_contrib").view(torch.int32).reshape(-1), rf.internal("n_contrib").reshape(-1))
+    b = restrict_oracle(internal, rf, kw)  # (n_contrib counts the instances of the emitted tile rects)
+    assert np.array_equal(npy(internal("n_contrib")).view(np.uint32).reshape(-1), b.n_contrib.reshape(-1))
     image_close(npy(res["color"]), npy(rf.color), rel=1e-6, name="exact color vs ref", max_outliers=0)
     image_close(npy(res["alpha"]), fw.alpha, rel=2e-6, name="exact alpha vs oracle", max_outliers=0)
     names = {"means2D": "means2D", "colors": "colors", "opacity": "opacity", "means3D": "means3D", "cov3D": "cov3D", "sh": "sh",
