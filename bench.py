@@ -854,6 +854,13 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": traffic,
                          "traffic_note": traffic_note, "valu": valu, "valu_issue": valu_issue, "pmc": pmc_derived,
                          "algorithmic_bytes_per_launch": algo_bytes,
+                         "algorithmic_bytes_note": "SURVEY 8d: (44+4S) R + (28+4S) N + (48+4S) V with R = the REFERENCE's num_rendered "
+                                                   "(config.num_rendered_R) -- the work the reference's kernel does for this frame",
+                         # the same formula on the instances this library actually emits (tile rects cut down)
+                         "on_emitted_instances": (lambda be: {"instances": wl.R_emitted, "algorithmic_bytes_per_launch": be,
+                                                              "achieved": round(be / (bwd_ms * 1e-3) / 1e9, 2) if bwd_ms else None,
+                                                              "frac": round(be / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if bwd_ms else None})(
+                             blend_bytes(S, wl.R_emitted, N, V)[0]),
                          "kernel_ms": round(bwd_ms, 4) if bwd_ms else None,
                          "kernel_ms_source": f"HIP events around the kernel on its launch stream, mean over "
                                              f"{kernel_samples} launches of {kernel_region} "
@@ -864,6 +871,8 @@ def main():
                          "stages_ms": {k: (round(v, 4) if v is not None else None) for k, v in stage_ms.items()},
                          "stages_ms_source": "extra pass after the timed region, every stage bracketed by HIP events",
                          "stages_bytes": sb, "stages_hbm_frac": stage_hbm_frac(stage_ms, sb),
+                         "stages_hbm_frac_on_emitted_instances": stage_hbm_frac(
+                             stage_ms, stage_bytes(args.gaussians, wl.V_in, V, wl.R_emitted, N, T_tiles, S)),
                          "stages_bytes_source": "SURVEY 8d algorithmic bytes (B_pre, B_scan, B_dup, B_sort = 24 R, B_rng, "
                                                 "B_blend_f, B_blend_b, B_pre_b); frac = bytes / stage time / 8 TB/s",
                          "sum_n_contrib_pairs": pairs_blended,

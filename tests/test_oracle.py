@@ -166,3 +166,66 @@ def test_knn_matches_bruteforce():
     D.fill_diagonal_(float("inf"))
     ref = D.topk(3, largest=False).values.mean(1).numpy()
     assert np.abs(d - ref).max() <= 1e-4 * ref.max()
+
+
+def test_restrict_binning_restates_the_reference_lists_on_smaller_rects():
+    """tests/gpu_utils.restrict_binning (what the -m gpu tests compare the HIP path's binning arrays with: the reference's
+    arrays restricted to the tile rects the library emits) on the oracle alone: with the reference's own rects it is the
+    identity; with rects cut down by a tile column / row it removes exactly the instances of those tiles, keeps the order,
+    re-bases the ranges and re-counts n_contrib."""
+    import torch as _t
+    from gpu_utils import restrict_binning
+    cam = syn.make_camera(200, 120, fx=150.0)
+    sc = syn.make_scene(400, cam, S=0, seed=3, scale_px=0.03, zmin=2.0, zmax=6.0)
+    kw = oracle_kwargs(cam, sc)
+    fw = oracle.forward(**kw)
+    W, H = cam.image_width, cam.image_height
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    P = sc.P
+    # the reference's rects, recovered from its own list: bounding box of the tiles of each Gaussian (getRect gives a rectangle)
+    tile = (fw.keys >> np.uint64(32)).astype(np.int64)
+    tx, ty = tile % gx, tile // gx
+    rect = np.zeros((P, 4), np.int64)
+    for g in np.unique(fw.point_list):
+        m = fw.point_list == g
+        rect[g] = [tx[m].min(), ty[m].min(), tx[m].max() + 1, ty[m].max() + 1]
+    assert ((rect[:, 2] - rect[:, 0]) * (rect[:, 3] - rect[:, 1]) == fw.tiles_touched).all()
+
+    def internal_for(r):
+        return lambda name: _t.from_numpy(r.astype(np.int32)) if name == "tile_rect" else None
+
+    same = restrict_binning(internal_for(rect), fw.point_list, fw.ranges, W, H, keys=fw.keys, n_contrib=fw.n_contrib)
+    assert same.num_rendered == fw.num_rendered and same.removed == 0
+    assert (same.point_list == fw.point_list).all() and (same.keys == fw.keys).all() and (same.ranges == fw.ranges).all()
+    assert (same.tiles_touched == fw.tiles_touched).all() and (same.point_offsets == fw.point_offsets).all()
+    assert (same.n_contrib == fw.n_contrib).all()
+    # cut the first tile column off every rect wider than one tile, the last row off every rect higher than one
+    cut = rect.copy()
+    wide = (rect[:, 2] - rect[:, 0]) > 1
+    high = (rect[:, 3] - rect[:, 1]) > 1
+    cut[wide, 0] += 1
+    cut[high, 3] -= 1
+    assert wide.sum() > 20 and high.sum() > 20
+    sub = restrict_binning(internal_for(cut), fw.point_list, fw.ranges, W, H, keys=fw.keys, n_contrib=fw.n_contrib)
+    keep = np.array([cut[g, 0] <= x < cut[g, 2] and cut[g, 1] <= y < cut[g, 3] for g, x, y in zip(fw.point_list, tx, ty)])
+    assert sub.num_rendered == keep.sum() == fw.num_rendered - sub.removed and sub.removed > 0
+    assert (sub.point_list == fw.point_list[keep]).all() and (sub.keys == fw.keys[keep]).all()
+    for t in range(gx * gy):  # ranges: the kept entries of each tile, contiguous, in the old order; (0, 0) for an emptied tile
+        a, b = fw.ranges[t]
+        k = keep[a:b]
+        if k.sum() == 0:
+            assert tuple(sub.ranges[t]) == (0, 0)
+        else:
+            a2, b2 = sub.ranges[t]
+            assert b2 - a2 == k.sum() and (sub.point_list[a2:b2] == fw.point_list[a:b][k]).all()
+    # n_contrib: a pixel whose last contributor was entry number n of its tile now has as many entries before it as were kept
+    y, x = 37, 101
+    t = (y // 16) * gx + x // 16
+    a = fw.ranges[t][0]
+    assert sub.n_contrib[y, x] == keep[a:a + fw.n_contrib[y, x]].sum()
+    with pytest.raises(AssertionError, match="not inside"):  # a rect that sticks out of the reference's is refused
+        bad = rect.copy()
+        g0 = int(fw.point_list[0])
+        bad[g0, 2] += 1
+        restrict_binning(internal_for(bad), fw.point_list, fw.ranges, W, H)
+    fw.free()
