@@ -333,6 +333,55 @@ def test_tight_rects_are_invisible(name, mode):
 
 
 @pytest.mark.parametrize("mode", ["default", "exact"])
+def test_tight_rects_are_invisible_random_sweep(mode):
+    """The same statement over 32 random scenes that stress the box the rects are cut to: opacities around the 1/255 threshold
+    (where the box collapses) and near 1 (where it is wider than the reference's 3-sigma square), needle-shaped and huge
+    splats, scale modifiers, odd image sizes, off-screen centres.  Images bit-identical, the list = the full list minus the
+    outside instances, n_contrib re-counted."""
+    base = _C.test_switches(-1) | (_C.EXACT if mode == "exact" else 0)
+    removed = total = 0
+    for seed in range(32):
+        rng = np.random.default_rng(7000 + seed)
+        W, H = int(rng.integers(17, 500)), int(rng.integers(17, 320))
+        cam = syn.make_camera(W, H, fx=float(rng.uniform(0.4, 1.6)) * W, yaw_deg=float(rng.uniform(-8, 8)))
+        S = int(rng.choice([0, 0, 2, 5]))
+        P = int(rng.integers(1, 6000))
+        sc = syn.make_scene(P, cam, S=S, seed=seed, margin=float(rng.uniform(0.8, 1.8)), scale_px=float(rng.uniform(0.002, 0.05)),
+                            zmin=float(rng.uniform(0.15, 2.0)), zmax=float(rng.uniform(5, 60)))
+        kind = seed % 4
+        if kind == 1:  # opacities straddling 1/255 = 0.00392 (the box is empty below 0.0039 and tiny just above)
+            sc.opacities.copy_(torch.from_numpy(rng.uniform(0.0030, 0.0060, (P, 1)).astype(np.float32)))
+        elif kind == 2:  # saturated opacities: the alpha >= 1/255 ellipse reaches 3.33 sigma, beyond the reference's square
+            sc.opacities.copy_(torch.from_numpy(rng.uniform(0.9, 1.0, (P, 1)).astype(np.float32)))
+        elif kind == 3:  # needles
+            sc.scales[:, 0] *= float(rng.uniform(20, 300))
+            sc.scales[:, 1:] *= 0.05
+        kw = oracle_kwargs(cam, sc, deg=int(rng.integers(0, 4)), bg=torch.tensor(rng.uniform(0, 1, 3), dtype=torch.float32))
+        kw["scale_modifier"] = float(rng.choice([1.0, 0.6, 1.5]))
+        with switches(base | _C.REF_RECT):
+            res_r, int_r = raw_forward(kw)
+            full = [npy(int_r(k)) for k in ("point_list", "ranges", "keys", "n_contrib")]
+        with switches(base):
+            res, internal = raw_forward(kw)
+            assert torch.equal(res["radii"], res_r["radii"]), seed
+            for k in ["color", "depth", "alpha", "semantic"]:
+                assert torch.equal(res[k], res_r[k]), (seed, k)
+            if res_r["R"] == 0:
+                assert res["R"] == 0
+                continue
+            b = restrict_binning(internal, full[0].view(np.uint32), full[1].view(np.uint32), W, H, keys=full[2].view(np.uint64),
+                                 n_contrib=full[3].view(np.uint32))
+            assert res["R"] == b.num_rendered, seed
+            if b.num_rendered:
+                assert (npy(internal("point_list")).view(np.uint32) == b.point_list).all(), seed
+            assert (npy(internal("ranges")).view(np.uint32) == b.ranges).all(), seed
+            assert (npy(internal("n_contrib")).view(np.uint32).reshape(-1) == b.n_contrib.reshape(-1)).all(), seed
+            removed += b.removed
+            total += res_r["R"]
+    assert removed > 0.1 * total
+
+
+@pytest.mark.parametrize("mode", ["default", "exact"])
 @pytest.mark.parametrize("P,S,scale_px", [(1, 0, 0.8), (2, 20, 0.3), (65, 1, 0.05), (129, 7, 0.02)])
 def test_edge_sizes(P, S, scale_px, mode):
     """Ragged sizes: fewer Gaussians than a wave, one Gaussian covering the whole tile grid (a single owner of every

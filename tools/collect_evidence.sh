@@ -11,6 +11,7 @@ cp $E/pmc_blend_bwd.json $R/profiles/pmc_blend_bwd.json
 cp $E/pmc_blend_bwd.json $D/pmc_blend_bwd.json
 cp $E/bench.json $D/bench_$N.json
 cp $E/stats/*kernel_stats.csv $D/bench_kernel_stats_$N.csv 2>/dev/null || cp $E/stats/*/*kernel_stats.csv $D/bench_kernel_stats_$N.csv
+for c in 5m 2m; do f=$(ls $E/stats$c/*kernel_stats.csv $E/stats$c/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $D/bench_kernel_stats_${N}_$c.csv; done
 cp $E/pytest_gpu.log $D/pytest_gpu_$N.log
 cp $E/pmc_table_1M.json $E/pmc_table_5M.json $E/fullsize_parity.json $E/parity_measured.jsonl $D/
 [ -f $E/threeway_fullsize.json ] && cp $E/threeway_fullsize.json $D/ || cp $R/gpurun_out/threeway_fullsize.json $D/

@@ -12,6 +12,9 @@ echo "== full gpu suite"; timeout 1500 python -m pytest tests -q --tb=short -m g
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -v amdgpu.ids | tail -2 | tee $E/smoke.log
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $E/stats -o bench -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > $E/stats.log 2>&1
+# per-kernel averages at the other single-GPU configurations too (5 M Gaussians; 2 M + 19 semantic channels)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $E/stats5m -o bench -- python $R/bench.py --gaussians 5000000 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > $E/stats5m.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $E/stats2m -o bench -- python $R/bench.py --gaussians 2000000 --semantics 19 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > $E/stats2m.log 2>&1
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $E/fetch -o fetch -- python $R/profiles/pmc_workload.py > $E/fetch.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $E/write -o write -- python $R/profiles/pmc_workload.py > $E/write.log 2>&1
 timeout 900 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $E/sq -o sq -- python $R/profiles/pmc_workload.py > $E/sq.log 2>&1
