@@ -30,6 +30,21 @@ KERNEL(k_dpp_ror, "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf
 KERNEL(k_dpp_bcast, "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n v_add_f32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf\n")
 KERNEL(k_cndmask, "v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %0, vcc\n")
 KERNEL(k_cmp, "v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %2\n v_cmp_lt_f32 vcc, %2, %3\n v_cmp_lt_f32 vcc, %3, %0\n")
+// packed f32 (two floats per lane in a VGPR pair): does one v_pk_* cost what one plain f32 instruction costs?
+typedef float f2 __attribute__((ext_vector_type(2)));
+#define KERNEL2(name, body)                                                                              \
+    __global__ void __launch_bounds__(256) name(float* out, int iters) {                                \
+        f2 a = {threadIdx.x * 1e-3f + 1.0f, 0.5f}, b = a + 0.5f, c = a + 0.25f, d = a + 0.125f;         \
+        for (int i = 0; i < iters; i++) { asm volatile(REP16(body) : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "vcc", "scc"); } \
+        out[blockIdx.x * 256 + threadIdx.x] = a.x + b.x + c.x + d.x + a.y + b.y + c.y + d.y;           \
+    }
+KERNEL2(k_pk_fma, "v_pk_fma_f32 %0, %0, %0, %0\n v_pk_fma_f32 %1, %1, %1, %1\n v_pk_fma_f32 %2, %2, %2, %2\n v_pk_fma_f32 %3, %3, %3, %3\n")
+KERNEL2(k_pk_mul, "v_pk_mul_f32 %0, %0, %0\n v_pk_mul_f32 %1, %1, %1\n v_pk_mul_f32 %2, %2, %2\n v_pk_mul_f32 %3, %3, %3\n")
+KERNEL2(k_pk_add, "v_pk_add_f32 %0, %0, %0\n v_pk_add_f32 %1, %1, %1\n v_pk_add_f32 %2, %2, %2\n v_pk_add_f32 %3, %3, %3\n")
+// the same cndmask without a register chain between the four (the first version's 23 cycles: chain or VCC read?)
+KERNEL(k_cndmask2, "v_cndmask_b32 %0, %0, %0, vcc\n v_cndmask_b32 %1, %1, %1, vcc\n v_cndmask_b32 %2, %2, %2, vcc\n v_cndmask_b32 %3, %3, %3, vcc\n")
+KERNEL(k_add, "v_add_f32 %0, %0, %0\n v_add_f32 %1, %1, %1\n v_add_f32 %2, %2, %2\n v_add_f32 %3, %3, %3\n")
+KERNEL(k_mov_dpp, "v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n")
 // scalar side: s_nop and simple SALU, to see what a scalar instruction costs next to nothing else
 __global__ void __launch_bounds__(256) k_snop(float* out, int iters) {
     for (int i = 0; i < iters; i++) asm volatile(REP64("s_nop 0\n") ::: "scc");
@@ -93,6 +108,12 @@ int main() {
         run("v_add_f32_dpp row_bcast", k_dpp_bcast, out, w, 64, ghz);
         run("v_cndmask_b32", k_cndmask, out, w, 64, ghz);
         run("v_cmp_lt_f32", k_cmp, out, w, 64, ghz);
+        run("v_pk_fma_f32", k_pk_fma, out, w, 64, ghz);
+        run("v_pk_mul_f32", k_pk_mul, out, w, 64, ghz);
+        run("v_pk_add_f32", k_pk_add, out, w, 64, ghz);
+        run("v_cndmask_b32 no chain", k_cndmask2, out, w, 64, ghz);
+        run("v_add_f32", k_add, out, w, 64, ghz);
+        run("v_mov_b32_dpp quad_perm", k_mov_dpp, out, w, 64, ghz);
         run("s_nop 0", k_snop, out, w, 64, ghz);
         run("s_add_u32", k_salu, out, w, 64, ghz);
         run("v_fma_f32 dependent chain", k_fma_dep, out, w, 64, ghz);
