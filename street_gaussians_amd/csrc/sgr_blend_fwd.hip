@@ -14,6 +14,15 @@
 #include "sgr_math.h"
 
 #define SGR_TILE_THREADS 256
+#ifndef SGR_FWD_SEL
+#define SGR_FWD_SEL 1  // selects of the blend step on an SGPR-pair lane mask (0: plain ?: -- the compiler's v_cndmask on VCC)
+#endif
+// lane in m ? a : b, the lane mask in a scalar register pair
+__device__ __forceinline__ float sgr_sel_mask(uint64_t m, float a, float b) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
 #ifndef SGR_EXACT_TRIM
 #define SGR_EXACT_TRIM 1  // parity mode: sgr_expf_ref instead of the library's expf (same bits, sgr_math.h)
 #endif
@@ -136,12 +145,23 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                     if (hm == 0) return;
                     const float test_T = T * (1.0f - alpha);
                     const bool k3 = test_T < 0.0001f;  // forward.cu:431-436
+#if SGR_FWD_SEL
+                    // the three selects on "this lane blends" take their lane mask from a scalar register pair
+                    // (v_cndmask_b32_e64 with an SGPR-pair mask: 4.6 cycles per wave instruction measured, against 23 for
+                    // back-to-back selects on VCC, tools/ubench/valu_rates.hip): the mask is a by-product of the ballots
+                    // the walk needs anyway
+                    const uint64_t k3m = __builtin_amdgcn_ballot_w64(k3);
+                    const uint64_t bm = hm & ~k3m;
+#define SGR_BLEND_SEL(a, b) sgr_sel_mask(bm, (a), (b))
+#else
                     const bool blend = k1 && k2 && !k3;
+#define SGR_BLEND_SEL(a, b) (blend ? (a) : (b))
+#endif
                     const float4 c = sC[j];
-                    const float w = blend ? alpha * T : 0.0f;
+                    const float w = SGR_BLEND_SEL(alpha * T, 0.0f);
                     if (EXACT) {
                         // the reference's association, unfused: C[ch] += features[ch] * alpha * T (forward.cu:438-441)
-                        const float ae = blend ? alpha : 0.0f;
+                        const float ae = SGR_BLEND_SEL(alpha, 0.0f);
                         C0 = C0 + (c.x * ae) * T;
                         C1 = C1 + (c.y * ae) * T;
                         C2 = C2 + (c.z * ae) * T;
@@ -155,7 +175,7 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                     Wt += w;
                     if (SMAX > 0) {
                         const float4* sj = reinterpret_cast<const float4*>(&sSem[j * SMAX]);
-                        const float ae = blend ? alpha : 0.0f;
+                        const float ae = SGR_BLEND_SEL(alpha, 0.0f);
 #pragma unroll
                         for (int c4 = 0; c4 < SMAX / 4; c4++) {
                             const float4 sv = sj[c4];
@@ -172,13 +192,18 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                             }
                         }
                     }
-                    T = blend ? test_T : T;
-                    last = blend ? (pos0 + (uint32_t)j + 1u) : last;
+                    T = SGR_BLEND_SEL(test_T, T);
+                    last = __float_as_uint(SGR_BLEND_SEL(__uint_as_float(pos0 + (uint32_t)j + 1u), __uint_as_float(last)));
+#undef SGR_BLEND_SEL
                     // Some lane passed the alpha test: the backward has to visit (quadrant, instance).  (A superset of
                     // the visits that blend: if every passing lane finishes on this very instance nothing is blended, and
                     // the backward's own per-pixel test -- list position < n_contrib -- skips it.)
                     hb = sgr_bitset1(hb, bit);
+#if SGR_FWD_SEL
+                    const uint64_t sm = hm & k3m;
+#else
                     const uint64_t sm = hm & __builtin_amdgcn_ballot_w64(k3);
+#endif
                     if (sm != 0) {
                         thr = (k1 && k2 && k3) ? __builtin_inff() : thr;
                         done_mask |= sm;

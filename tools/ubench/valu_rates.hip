@@ -43,6 +43,25 @@ KERNEL2(k_pk_mul, "v_pk_mul_f32 %0, %0, %0\n v_pk_mul_f32 %1, %1, %1\n v_pk_mul_
 KERNEL2(k_pk_add, "v_pk_add_f32 %0, %0, %0\n v_pk_add_f32 %1, %1, %1\n v_pk_add_f32 %2, %2, %2\n v_pk_add_f32 %3, %3, %3\n")
 // the same cndmask without a register chain between the four (the first version's 23 cycles: chain or VCC read?)
 KERNEL(k_cndmask2, "v_cndmask_b32 %0, %0, %0, vcc\n v_cndmask_b32 %1, %1, %1, vcc\n v_cndmask_b32 %2, %2, %2, vcc\n v_cndmask_b32 %3, %3, %3, vcc\n")
+// cndmask with an initialised, lane-varying mask: in VCC (e32) and in another SGPR pair (e64)
+__global__ void __launch_bounds__(256) k_cndmask_vcc(float* out, int iters) {
+    float a = threadIdx.x * 1e-3f + 1.0f, b = a + 0.5f, c = a + 0.25f, d = a + 0.125f;
+    asm volatile("v_cmp_gt_f32 vcc, 1.1, %0\n" : : "v"(a) : "vcc");
+    for (int i = 0; i < iters; i++) {
+        asm volatile(REP16("v_cndmask_b32 %0, %1, %2, vcc\n v_cndmask_b32 %1, %2, %3, vcc\n v_cndmask_b32 %2, %3, %0, vcc\n v_cndmask_b32 %3, %0, %1, vcc\n")
+                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "scc");
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a + b + c + d;
+}
+__global__ void __launch_bounds__(256) k_cndmask_sgpr(float* out, int iters) {
+    float a = threadIdx.x * 1e-3f + 1.0f, b = a + 0.5f, c = a + 0.25f, d = a + 0.125f;
+    unsigned long long m = __ballot(a < 1.1f);
+    for (int i = 0; i < iters; i++) {
+        asm volatile(REP16("v_cndmask_b32_e64 %0, %1, %2, %4\n v_cndmask_b32_e64 %1, %2, %3, %4\n v_cndmask_b32_e64 %2, %3, %0, %4\n v_cndmask_b32_e64 %3, %0, %1, %4\n")
+                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "s"(m) : "scc");
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a + b + c + d;
+}
 KERNEL(k_add, "v_add_f32 %0, %0, %0\n v_add_f32 %1, %1, %1\n v_add_f32 %2, %2, %2\n v_add_f32 %3, %3, %3\n")
 KERNEL(k_mov_dpp, "v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n")
 // scalar side: s_nop and simple SALU, to see what a scalar instruction costs next to nothing else
@@ -112,6 +131,8 @@ int main() {
         run("v_pk_mul_f32", k_pk_mul, out, w, 64, ghz);
         run("v_pk_add_f32", k_pk_add, out, w, 64, ghz);
         run("v_cndmask_b32 no chain", k_cndmask2, out, w, 64, ghz);
+        run("v_cndmask_b32 vcc initialised", k_cndmask_vcc, out, w, 64, ghz);
+        run("v_cndmask_b32_e64 sgpr mask", k_cndmask_sgpr, out, w, 64, ghz);
         run("v_add_f32", k_add, out, w, 64, ghz);
         run("v_mov_b32_dpp quad_perm", k_mov_dpp, out, w, 64, ghz);
         run("s_nop 0", k_snop, out, w, 64, ghz);
