@@ -185,7 +185,9 @@ int sgr_profile_sample(int every);
  *           Gaussian was emitted for -- the reference's getRect square cut down to the tiles in which it can reach
  *           alpha >= 1/255 (switch bit 10: the reference's own rect); 6, 7, 8, 9, 12, 13 are the reference's arrays
  *           restricted to these rects
- *        17 u32[1]: what num_rendered is with the reference's rects (reporting)                            */
+ *        17 u32[1]: what num_rendered is with the reference's rects (reporting)
+ *        18 tile mask u64[P]: for rects of 2..64 tiles, bit j = tile (x0 + j % w, y0 + j / w) of the rect is emitted
+ *           (inside the bounding box only the tiles the alpha >= 1/255 ellipse reaches); 0 = every tile of the rect  */
 int sgr_export_internal(int which, int P, int R, int width, int height, char* geom_buffer, char* binning_buffer,
                         char* image_buffer, void* dst, void* stream);
 
@@ -201,7 +203,8 @@ int sgr_export_internal(int which, int P, int R, int width, int height, char* ge
  * bit 6 (SGR_PRE_STAGE=1) the preprocess stages its SH rows through LDS whatever P is (default: from 3 M Gaussians),
  * bit 10 (SGR_REF_RECT=1) every Gaussian is emitted for the reference's whole tile rect (auxiliary.h getRect), so that
  * num_rendered, point_list, the sorted keys and the ranges are the reference's arrays entry for entry; default: the rect
- * cut down to the tiles where the Gaussian can pass the alpha >= 1/255 test -- fewer instances, bit-identical images (gradients: same terms, the row sum groups its additions differently).
+ * cut down to the tiles where the Gaussian can pass the alpha >= 1/255 test -- fewer instances, bit-identical images (gradients: same terms, the row sum groups its additions differently),
+ * bit 11 (SGR_NO_TILE_MASK=1) the cut-down rect is the bounding box of those tiles without the per-tile mask (A/B).
  * mask >= 0 sets them process-wide, mask < 0 only queries; returns the previous mask.  The initial
  * value comes from the environment (SGR_NO_CULL, SGR_NO_DPP, SGR_NO_DET, SGR_NO_HITS, SGR_V2), read once. */
 int sgr_test_switches(int mask);

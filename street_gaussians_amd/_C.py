@@ -326,7 +326,8 @@ _EXPORT = {"depths": (0, torch.float32, lambda P, R, N, T: (P,)), "clamped": (1,
            "ranges": (12, torch.int32, lambda P, R, N, T: (T, 2)), "n_contrib": (13, torch.int32, lambda P, R, N, T: (N,)),
            "extents": (14, torch.float32, lambda P, R, N, T: (P, 2)), "hits": (15, torch.uint8, lambda P, R, N, T: (R,)),
            "tile_rect": (16, torch.int32, lambda P, R, N, T: (P, 4)),
-           "num_rendered_reference": (17, torch.int32, lambda P, R, N, T: (1,))}
+           "num_rendered_reference": (17, torch.int32, lambda P, R, N, T: (1,)),
+           "tile_mask": (18, torch.int64, lambda P, R, N, T: (P,))}
 
 
 def masked_color_grad(geomBuffer, grad_colors, P):
@@ -372,6 +373,7 @@ def sh_grad_from_rows(P, degree, M, V, means_ptr, means_stride, campos_ptr, camp
 
 
 NO_CULL, NO_DPP, NO_DET, NO_HITS, USE_V2, USE_ONESWEEP, PRE_STAGE_SH, EXACT, USE_SW, USE_RS_WAVE = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
+NO_TILE_MASK = 2048  # bounding-box rects without the per-tile mask (A/B)
 REF_RECT = 1024  # emit every Gaussian for the reference's whole tile rect (default: cut down to where alpha >= 1/255 is possible)
 
 

@@ -20,7 +20,7 @@ void sgr_launch_mark_visible(int P, const float* means3D, const float* viewmatri
 void sgr_launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, const float* rotations,
                            const float* opacities, const float* shs, const float* cov3D_precomp,
                            const float* colors_precomp, const SgrCam* cam, const SgrGeomView& gv, int* radii,
-                           int prefiltered, bool stage_sh, bool tight, hipStream_t s);
+                           int prefiltered, bool stage_sh, int tight, hipStream_t s);
 void sgr_launch_filter(int P, const float* means3D, const float* scales, const float* rotations,
                        const float* cov3D_precomp, const SgrCamArgs& ca, const SgrGeomView& gv, int* radii,
                        float* means2D, int prefiltered, hipStream_t s);
@@ -35,7 +35,7 @@ void sgr_launch_blend_fwd(bool cull, bool exact, int gx, int gy, const uint2* ra
                           hipStream_t s);
 int sgr_partial_row_stride(int S);
 void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, bool v2, bool exact, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
-                          int H, int S, const float* bg, const float4* rec, const uint32_t* u0, const float* semantics, const float* alphas,
+                          int H, int S, const float* bg, const float4* rec, const uint32_t* u0, const uint64_t* tmask, const float* semantics, const float* alphas,
                           const uint32_t* n_contrib, const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth,
                           const float* dL_dalpha, const float* dL_dsem, float* partials, uint8_t* touched, hipStream_t s);
 void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const int* radii, const float* shs,
@@ -46,7 +46,7 @@ void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, cons
                           const SgrStatSink& sink, int quad, int exact, int W, int H, hipEvent_t after_rows, int rs_wave,
                           hipStream_t s);
 void sgr_launch_blend_bwd_sw(bool exact, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W, int H,
-                             const float* bg, const float4* rec, const uint32_t* u0, const float* alphas,
+                             const float* bg, const float4* rec, const uint32_t* u0, const uint64_t* tmask, const float* alphas,
                              const uint32_t* n_contrib, const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth,
                              const float* dL_dalpha, float* partials, int row_stride, uint8_t* touched, hipStream_t s);
 // the same compiled with FP contraction off (sgr_gauss_bwd_strict.hip): parity mode
@@ -87,7 +87,7 @@ static int switches() {
         v = (env_flag("SGR_NO_CULL") ? 1 : 0) | (env_flag("SGR_NO_DPP") ? 2 : 0) | (env_flag("SGR_NO_DET") ? 4 : 0) |
             (env_flag("SGR_NO_HITS") ? 8 : 0) | (env_flag("SGR_V2") ? 16 : 0) | (env_flag("SGR_PRE_STAGE") ? 64 : 0) |
             (env_flag("SGR_EXACT") ? 128 : 0) | ((env_flag("SGR_SW8") || env_flag("SGR_SW")) ? 256 : 0) | ((env_flag("SGR_SW9") || env_flag("SGR_RS_WAVE")) ? 512 : 0) |
-            (env_flag("SGR_REF_RECT") ? 1024 : 0);
+            (env_flag("SGR_REF_RECT") ? 1024 : 0) | (env_flag("SGR_NO_TILE_MASK") ? 2048 : 0);
         g_switches.store(v, std::memory_order_relaxed);
     }
     return v;
@@ -360,8 +360,9 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
                               // forces it, SGR_PRE_STAGE_MIN_P moves the threshold)
                               (switches() & 64) != 0 || P >= pre_stage_min_p(),
                               // tile rects: the reference's 3-sigma squares cut down to the tiles the Gaussian can reach
-                              // alpha >= 1/255 in (sgr_preprocess.hip); switch bit 10 keeps the reference's rects
-                              (switches() & 1024) == 0, stream);
+                              // alpha >= 1/255 in (sgr_preprocess.hip: 2 = bounding box + tile mask, 1 = bounding box only,
+                              // switch bit 11); switch bit 10 keeps the reference's rects
+                              (switches() & 1024) ? 0 : ((switches() & 2048) ? 1 : 2), stream);
         SGR_STAGE("preprocess");
         prof_end(stream);
 
@@ -596,10 +597,10 @@ int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, 
         // geometric cull instead (A/B and tests: the two walks must give bit-identical gradients)
         const uint8_t* hits = (sw & 8) ? nullptr : bv.hit4;
         if (quad)
-            sgr_launch_blend_bwd_sw((sw & 128) != 0, gx, gy, iv.ranges, bv.vals[cur], W, H, background, gv.rec, gv.u0, alphas,
+            sgr_launch_blend_bwd_sw((sw & 128) != 0, gx, gy, iv.ranges, bv.vals[cur], W, H, background, gv.rec, gv.u0, gv.tmask, alphas,
                                     iv.n_contrib, bv.hit4, dL_dpix, dL_dpix_depth, dL_dalphas, partials, stride, touched, stream);
         else
-            sgr_launch_blend_bwd(cull, dpp, det, (sw & 16) != 0, (sw & 128) != 0, gx, gy, iv.ranges, bv.vals[cur], W, H, S, background, gv.rec, gv.u0, semantics,
+            sgr_launch_blend_bwd(cull, dpp, det, (sw & 16) != 0, (sw & 128) != 0, gx, gy, iv.ranges, bv.vals[cur], W, H, S, background, gv.rec, gv.u0, gv.tmask, semantics,
                                  alphas, iv.n_contrib, hits, dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, partials,
                                  touched, stream);
         SGR_STAGE("blend_bwd");
@@ -793,9 +794,16 @@ __global__ void sgr_export_kernel(int which, int P, SgrGeomView gv, void* dst) {
         case 14: { const float4 a = gv.rec[4 * (size_t)i]; ((float*)dst)[2 * i] = a.z; ((float*)dst)[2 * i + 1] = a.w; } break;
         case 16: {  // tile rect {x0, y0, x1, y1} (exclusive upper corner); all zero for a culled Gaussian
             const uint2 a = gv.aux[i];
-            const uint32_t x0 = a.y & 1023u, y0 = (a.y >> 10) & 1023u, w = a.y >> 20, h = w ? a.x / w : 0u;
+            // (a masked rect of at most 64 tiles does not store its height: the highest set bit of the mask gives the last row
+            // that matters, and rows above it hold no emitted tile)
+            const uint32_t x0 = a.y & 1023u, y0 = (a.y >> 10) & 1023u, w = (a.y >> 20) & 1023u;
+            uint32_t h = w ? a.x / w : 0u;
+            if (a.y & SGR_RECT_MASKED) h = (63u - (uint32_t)__clzll((long long)gv.tmask[i])) / w + 1u;
             ((uint4*)dst)[i] = a.x ? make_uint4(x0, y0, x0 + w, y0 + h) : make_uint4(0u, 0u, 0u, 0u);
         } break;
+        case 18:  // tile mask (0 = every tile of the rect is emitted)
+            ((uint64_t*)dst)[i] = (gv.aux[i].x && (gv.aux[i].y & SGR_RECT_MASKED)) ? gv.tmask[i] : 0ull;
+            break;
     }
 }
 
@@ -805,7 +813,7 @@ int sgr_export_internal(int which, int P, int R, int width, int height, char* ge
     const int debug = 1;
     const int gx = (width + SGR_BLOCK_X - 1) / SGR_BLOCK_X, gy = (height + SGR_BLOCK_Y - 1) / SGR_BLOCK_Y;
     const size_t N = (size_t)width * height, T = (size_t)gx * gy;
-    if (which <= 7 || which == 14 || which == 16 || which == 17) {
+    if (which <= 7 || which == 14 || which == 16 || which == 17 || which == 18) {
         if (P <= 0) return 0;
         const SgrGeomView gv = sgr_geom_carve(geom_buffer, (size_t)P);
         if (which == 17) { SGR_HIP(hipMemcpyAsync(dst, gv.header + 5, 4, hipMemcpyDeviceToDevice, stream)); return 0; }

@@ -131,7 +131,7 @@ template <int SMAX, bool CULL, bool DPP, bool DET, int BATCH, bool EXACT = false
 __device__ __forceinline__ void
 sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int S,
                      int gx, int gy, const float* __restrict__ bg_color, const float4* __restrict__ rec,
-                     const uint32_t* __restrict__ u0, const float* __restrict__ semantics, const float* __restrict__ alphas,
+                     const uint32_t* __restrict__ u0, const uint64_t* __restrict__ tmask, const float* __restrict__ semantics, const float* __restrict__ alphas,
                      const uint32_t* __restrict__ n_contrib, const uint8_t* __restrict__ hit4,
                      const float* __restrict__ dL_dpixels, const float* __restrict__ dL_dpixel_depths,
                      const float* __restrict__ dL_dalphas, const float* __restrict__ dL_dpixel_semantics,
@@ -273,8 +273,8 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                             : sgr_stage_conic(b);
             sC[tid] = r[2];
             const uint32_t dy_ = __float_as_uint(d4.y);
-            const uint32_t rx0 = dy_ & 1023u, ry0 = (dy_ >> 10) & 1023u, rw = dy_ >> 20;
-            sU[tid] = u0[g] + (ty - ry0) * rw + (tx - rx0);  // first row of the Gaussian (compact array, L2-resident) + tile index in its rect
+            // first row of the Gaussian (compact array, L2-resident) + rank of this tile among the tiles it is emitted for
+            sU[tid] = sgr_row_of(dy_, tx, ty, u0, tmask, g);
             if (SMAX > 0) {
 #pragma unroll
                 for (int ch = 0; ch < SMAX; ch++) sSem[tid * SMAX + ch] = ch < S ? semantics[(size_t)g * S + ch] : 0.0f;
@@ -535,7 +535,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
 
 #define SGR_BWD_ARGS                                                                                                  \
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int S, int gx, int gy,       \
-        const float *__restrict__ bg_color, const float4 *__restrict__ rec, const uint32_t *__restrict__ u0,          \
+        const float *__restrict__ bg_color, const float4 *__restrict__ rec, const uint32_t *__restrict__ u0, const uint64_t *__restrict__ tmask,          \
         const float *__restrict__ semantics,          \
         const float *__restrict__ alphas, const uint32_t *__restrict__ n_contrib, const uint8_t *__restrict__ hit4,        \
         const float *__restrict__ dL_dpixels, const float *__restrict__ dL_dpixel_depths,                                  \
@@ -543,7 +543,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
         const float *__restrict__ dL_dpixel_semantics, float *__restrict__ partials, int row_stride,                      \
         uint8_t *__restrict__ touched
 #define SGR_BWD_PASS                                                                                                  \
-    ranges, point_list, W, H, S, gx, gy, bg_color, rec, u0, semantics, alphas, n_contrib, hit4, dL_dpixels,               \
+    ranges, point_list, W, H, S, gx, gy, bg_color, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpixels,               \
         dL_dpixel_depths, dL_dalphas, dL_dpixel_semantics, partials, row_stride, touched
 template <int SMAX, bool CULL, bool DPP, bool DET>
 __global__ void __launch_bounds__(SGR_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(SGR_BWD_WAVES(SMAX))))
@@ -668,8 +668,8 @@ sgr_blend_bwd_kernel_v2(SGR_BWD_ARGS) {
             sB[tid] = sgr_stage_conic(b);
             sC[tid] = r[2];
             const uint32_t dy_ = __float_as_uint(d4.y);
-            const uint32_t rx0 = dy_ & 1023u, ry0 = (dy_ >> 10) & 1023u, rw = dy_ >> 20;
-            sU[tid] = u0[g] + (ty - ry0) * rw + (tx - rx0);  // first row of the Gaussian (compact array, L2-resident) + tile index in its rect
+            // first row of the Gaussian (compact array, L2-resident) + rank of this tile among the tiles it is emitted for
+            sU[tid] = sgr_row_of(dy_, tx, ty, u0, tmask, g);
             mask4 = CULL ? (hit4 != nullptr ? (uint32_t)hit4[range.x + (uint32_t)pos] : sgr_quadrant_mask(a, b, tx0, ty0))
                          : 0xFu;
         }
@@ -835,21 +835,21 @@ sgr_blend_bwd_kernel_v2(SGR_BWD_ARGS) {
 
 template <int SMAX>
 static void launch_bwd(bool cull, bool dpp, bool det, bool v2, bool exact, unsigned tiles, hipStream_t s, const uint2* ranges, const uint32_t* point_list,
-                       int W, int H, int S, int gx, int gy, const float* bg, const float4* rec, const uint32_t* u0, const float* semantics,
+                       int W, int H, int S, int gx, int gy, const float* bg, const float4* rec, const uint32_t* u0, const uint64_t* tmask, const float* semantics,
                        const float* alphas,
                        const uint32_t* n_contrib, const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth,
                        const float* dL_dalpha, const float* dL_dsem, float* partials, int row_stride, uint8_t* touched) {
     constexpr bool kDet = true;  // every instantiation has the two-row deterministic combine (see SgrBwdBatch)
     if (exact) {
         sgr_blend_bwd_kernel_exact<SMAX><<<tiles, SGR_TILE_THREADS, 0, s>>>(
-            ranges, point_list, W, H, S, gx, gy, bg, rec, u0, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth, dL_dalpha,
+            ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth, dL_dalpha,
             dL_dsem, partials, row_stride, touched);
         return;
     }
     if constexpr (SMAX == 0) {
         if (v2 && dpp) {  // transposed accumulation (S = 0)
 #define SGR_V2(C, D) sgr_blend_bwd_kernel_v2<C, D><<<tiles, SGR_TILE_THREADS, 0, s>>>(                                    \
-            ranges, point_list, W, H, S, gx, gy, bg, rec, u0, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,         \
+            ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,         \
             dL_dalpha, dL_dsem, partials, row_stride, touched)
             if (cull) { if (det) SGR_V2(true, true); else SGR_V2(true, false); }
             else { if (det) SGR_V2(false, true); else SGR_V2(false, false); }
@@ -863,19 +863,19 @@ static void launch_bwd(bool cull, bool dpp, bool det, bool v2, bool exact, unsig
         if constexpr (SMAX == 0) {                                                                                   \
             if (det)                                                                                                 \
                 sgr_blend_bwd_kernel_s0<C, D, true><<<tiles, SGR_TILE_THREADS, 0, s>>>(                               \
-                    ranges, point_list, W, H, S, gx, gy, bg, rec, u0, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,    \
+                    ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,    \
                     dL_dalpha, dL_dsem, partials, row_stride, touched);                                               \
             else                                                                                                     \
                 sgr_blend_bwd_kernel_s0<C, D, false><<<tiles, SGR_TILE_THREADS, 0, s>>>(                              \
-                    ranges, point_list, W, H, S, gx, gy, bg, rec, u0, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,    \
+                    ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,    \
                     dL_dalpha, dL_dsem, partials, row_stride, touched);                                               \
         } else if (kDet && det)                                                                                      \
             sgr_blend_bwd_kernel<SMAX, C, D, kDet><<<tiles, SGR_TILE_THREADS, 0, s>>>(                                \
-                ranges, point_list, W, H, S, gx, gy, bg, rec, u0, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,        \
+                ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,        \
                 dL_dalpha, dL_dsem, partials, row_stride, touched);                                                   \
         else                                                                                                         \
             sgr_blend_bwd_kernel<SMAX, C, D, false><<<tiles, SGR_TILE_THREADS, 0, s>>>(                               \
-                ranges, point_list, W, H, S, gx, gy, bg, rec, u0, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,        \
+                ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,        \
                 dL_dalpha, dL_dsem, partials, row_stride, touched);                                                   \
     } while (0)
     if (cull && dpp) SGR_GO(true, true);
@@ -896,13 +896,13 @@ int sgr_partial_row_stride(int S) {
 }
 
 void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, bool v2, bool exact, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
-                          int H, int S, const float* bg, const float4* rec, const uint32_t* u0, const float* semantics, const float* alphas, const uint32_t* n_contrib,
+                          int H, int S, const float* bg, const float4* rec, const uint32_t* u0, const uint64_t* tmask, const float* semantics, const float* alphas, const uint32_t* n_contrib,
                           const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha,
                           const float* dL_dsem, float* partials, uint8_t* touched, hipStream_t s) {
     if (gx <= 0 || gy <= 0) return;
     const unsigned tiles = sgr_xcd_grid_blocks(gx, gy);  // supertile-ordered grid incl. padding blocks
     const int stride = sgr_partial_row_stride(S);
-#define SGR_BWD(N) launch_bwd<N>(cull, dpp, det, v2, exact, tiles, s, ranges, point_list, W, H, S, gx, gy, bg, rec, u0, semantics, alphas, \
+#define SGR_BWD(N) launch_bwd<N>(cull, dpp, det, v2, exact, tiles, s, ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, \
                                  n_contrib, hit4, dL_dpix, dL_ddepth, dL_dalpha, dL_dsem, partials, stride, touched)
     if (S == 0) SGR_BWD(0);
     else if (S <= 4) SGR_BWD(4);

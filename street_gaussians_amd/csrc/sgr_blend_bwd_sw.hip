@@ -71,7 +71,7 @@ __device__ __forceinline__ void sgr_keep(const sgr_i16& r) { asm volatile("" ::"
 template <bool EXACT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGR_SW_WAVES, SGR_SW_WAVES)))
 sgr_blend_bwd_sw_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int gy,
-                        const float* __restrict__ bg_color, const float4* __restrict__ rec, const uint32_t* __restrict__ u0,
+                        const float* __restrict__ bg_color, const float4* __restrict__ rec, const uint32_t* __restrict__ u0, const uint64_t* __restrict__ tmask,
                         const float* __restrict__ alphas, const uint32_t* __restrict__ n_contrib,
                         const uint8_t* __restrict__ hit4, const float* __restrict__ dL_dpixels,
                         const float* __restrict__ dL_dpixel_depths, const float* __restrict__ dL_dalphas,
@@ -229,8 +229,7 @@ sgr_blend_bwd_sw_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
         if (mine) {
             // u = first row of the Gaussian + index of this tile inside its rect (as in sgr_blend_bwd.hip)
             const uint32_t rc = __float_as_uint(reinterpret_cast<const float*>(rec + 4 * (size_t)g_c + 3)[1]);
-            const uint32_t rx0 = rc & 1023u, ry0 = (rc >> 10) & 1023u, rw = rc >> 20;
-            const uint32_t u = u0[g_c] + (ty - ry0) * rw + (tx - rx0);
+            const uint32_t u = sgr_row_of(rc, tx, ty, u0, tmask, g_c);
             ro_c = ((uint64_t)u * 4u + q) * row_bytes;
             // "row 4 u + q will be written": an order-free OR into the instance's flag byte (no return value)
             __hip_atomic_fetch_or(&touched32[u >> 2], qbit << ((u & 3u) * 8u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -370,17 +369,17 @@ sgr_blend_bwd_sw_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
 // holding the raw moments in natural order [S gx, S gy, S abs, S gxx, S gxy, S gyy, S Gd, r, g, b, depth, -];
 // touched[u] = mask of the quadrant rows that were written (sgr_row_sum_kernel<0, true> consumes both)
 void sgr_launch_blend_bwd_sw(bool exact, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W, int H,
-                             const float* bg, const float4* rec, const uint32_t* u0, const float* alphas,
+                             const float* bg, const float4* rec, const uint32_t* u0, const uint64_t* tmask, const float* alphas,
                              const uint32_t* n_contrib, const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth,
                              const float* dL_dalpha, float* partials, int row_stride, uint8_t* touched, hipStream_t s) {
     if (gx <= 0 || gy <= 0) return;
     const unsigned waves = 4u * sgr_xcd_grid_blocks(gx, gy);
     if (exact)
-        sgr_blend_bwd_sw_kernel<true><<<waves, 64, 0, s>>>(ranges, point_list, W, H, gx, gy, bg, rec, u0, alphas, n_contrib, hit4,
+        sgr_blend_bwd_sw_kernel<true><<<waves, 64, 0, s>>>(ranges, point_list, W, H, gx, gy, bg, rec, u0, tmask, alphas, n_contrib, hit4,
                                                           dL_dpix, dL_ddepth, dL_dalpha, partials, row_stride,
                                                           reinterpret_cast<uint32_t*>(touched));
     else
-        sgr_blend_bwd_sw_kernel<false><<<waves, 64, 0, s>>>(ranges, point_list, W, H, gx, gy, bg, rec, u0, alphas, n_contrib, hit4,
+        sgr_blend_bwd_sw_kernel<false><<<waves, 64, 0, s>>>(ranges, point_list, W, H, gx, gy, bg, rec, u0, tmask, alphas, n_contrib, hit4,
                                                            dL_dpix, dL_ddepth, dL_dalpha, partials, row_stride,
                                                            reinterpret_cast<uint32_t*>(touched));
 }

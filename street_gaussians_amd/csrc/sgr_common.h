@@ -30,6 +30,7 @@
 #define SGR_MAX_GRID_DIM 1023  // tiles per axis representable in the packed rect (10 bits)
 #define SGR_SEM_MAX 32         // semantic channels supported by the blend kernels
 #define SGR_ROW_BASE_N 11      // non-semantic floats of a partial-gradient row (see sgr_blend_bwd.hip)
+#define SGR_RECT_MASKED 0x80000000u  // packed tile rect, bit 31: the Gaussian is emitted for the tiles of SgrGeomView::tmask only
 
 #define SGR_ALPHA_MIN (1.0f / 255.0f)
 #define SGR_DEPTH_KEY_BIAS 0x3E4CCCCDu  // bits of 0.2f: the near-plane test of the preprocess (auxiliary.h:152)
@@ -38,7 +39,10 @@
 
 struct SgrGeomView {
     float4* rec;  // [4P]
-    uint2* aux;               // per Gaussian {tiles_touched, packed tile rect}; {0, 0} when culled
+    uint2* aux;               // per Gaussian {tiles_touched, packed tile rect}; {0, 0} when culled.  Rect word: x0 | y0 << 10 |
+                              // w << 20, bit 31 = "only the tiles set in tmask[g] are emitted" (SGR_RECT_MASKED)
+    uint64_t* tmask;          // per Gaussian with bit 31 of its rect word set: bit j = tile (x0 + j % w, y0 + j / w) of the rect
+                              // is emitted (rects of at most 64 tiles; written for those Gaussians only)
     uint2* aux_sorted;        // the same in (depth, id) order (written by the last pass of the depth sort)
     uint32_t* u0;             // per Gaussian: its first partial-gradient row of the backward = EXCLUSIVE scan of
                               // tiles_touched in INDEX order (the reference's point_offsets minus tiles_touched), made by
@@ -118,6 +122,7 @@ static inline SgrGeomView sgr_geom_carve(char* base, size_t P, char** end = null
     sgr_carve(p, v.rec, Pn * 4);
     sgr_carve(p, v.aux, Pn);
     sgr_carve(p, v.aux_sorted, Pn);
+    sgr_carve(p, v.tmask, Pn);
     sgr_carve(p, v.u0, Pn);
     sgr_carve(p, v.clamped, Pn);
     sgr_carve(p, v.internal_radii, Pn);

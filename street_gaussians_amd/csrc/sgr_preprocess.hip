@@ -240,7 +240,26 @@ sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             x0 = (uint32_t)fx0; x1 = (uint32_t)fx1; y0 = (uint32_t)fy0; y1 = (uint32_t)fy1;
         }
         const uint32_t w = x1 - x0, h = y1 - y0;
-        const uint32_t rect = sgr_pack_rect(x0, y0, w);
+        uint32_t rect = sgr_pack_rect(x0, y0, w);
+        uint32_t nemit = w * h;
+        if (tight > 1 && w >= 2u && h >= 2u && nemit <= 64u) {  // (a single row or column of tiles IS its bounding box)
+            // ... and inside that rect only the tiles the alpha >= 1/255 ellipse reaches (the rect is its bounding box: the
+            // corners go): a 64-bit tile mask for rects of up to 64 tiles (sgr_math.h: sgr_tile_mask), bit 31 of the rect word
+            // says "masked".  duplicate emits the set tiles, the backward numbers a Gaussian's rows by the rank of the tile in
+            // the mask.  0.61 instead of 0.72 of the reference's instances on the benchmark scene.
+            uint64_t tm = sgr_tile_mask(pr.px, pr.py, pr.con_x, pr.con_y, pr.con_z, opacity, x0, y0, x1, y1);
+            if (tm == 0) {  // reaches no tile (opacity below 1/255 ...): the centre's tile, so that the Gaussian owns a row
+                const uint32_t cx = (uint32_t)fminf(fmaxf(floorf(pr.px * (1.0f / SGR_BLOCK_X)), (float)x0), (float)(x1 - 1));
+                const uint32_t cy = (uint32_t)fminf(fmaxf(floorf(pr.py * (1.0f / SGR_BLOCK_Y)), (float)y0), (float)(y1 - 1));
+                tm = 1ull << ((cy - y0) * w + (cx - x0));
+            }
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(tm);
+            if (cnt != nemit) {
+                rect |= SGR_RECT_MASKED;
+                gv.tmask[idx] = tm;
+                nemit = cnt;
+            }
+        }
         nref = rn;
         float4* rec = gv.rec + 4 * (size_t)idx;
         rec[0] = make_float4(pr.px, pr.py, hx, hy);
@@ -251,7 +270,7 @@ sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         const float4 st = sgr_stage_conic(make_float4(pr.con_x, pr.con_y, pr.con_z, opacity));
         rec[3] = make_float4(st.x, __uint_as_float(rect), st.y, st.z);
         gv.clamped[idx] = clamped;
-        gv.aux[idx] = make_uint2(w * h, rect);
+        gv.aux[idx] = make_uint2(nemit, rect);
         // depth-sort key: the bits of the view depth minus the bits of 0.2 (every Gaussian that gets here has depth > 0.2):
         // monotone in the depth, and below 2^27 for depths under 13 107 -- sixteen octaves -- so that the sort takes THREE 9-bit
         // passes instead of four 8-bit ones.  A depth beyond that raises header[2]; the host reads it back together with
@@ -260,7 +279,7 @@ sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         if (dkey >> SGR_DEPTH_KEY_BITS) atomicOr(&gv.header[2], 1u);
         gv.dkeys[0][idx] = dkey;
         radii[idx] = pr.radius;
-        n = w * h;
+        n = nemit;
     }
     // device-scope atomics on one address are resolved beyond the per-XCD L2s (~6 ns each, serialised): one per
     // workgroup, not one per wave (16k of them cost 0.1 ms at P = 1M)
@@ -291,20 +310,26 @@ sgr_duplicate_kernel(int P, SgrGeomView gv, const uint32_t* __restrict__ order, 
     __shared__ uint32_t sOff[SGR_PRE_THREADS / 64][64];
     __shared__ uint32_t sRect[SGR_PRE_THREADS / 64][64];
     __shared__ uint32_t sIdx[SGR_PRE_THREADS / 64][64];
+    __shared__ uint64_t sMask[SGR_PRE_THREADS / 64][64];
     const int i = blockIdx.x * SGR_PRE_THREADS + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t off = 0xffffffffu, incl = 0, idx = 0, rect = 0;
+    uint64_t tmask = 0;
     if (i < P) {
         // everything in depth order and coalesced: the id, the scanned offsets, and the tile rect the depth sort's last
         // pass carried along (aux_sorted) -- no gather of the Gaussian's record
         idx = order[i];
         off = (i == 0) ? 0u : offs_incl[i - 1];
         incl = offs_incl[i];
-        if (incl != off) rect = gv.aux_sorted[i].y;  // tiles_touched > 0
+        if (incl != off) {  // tiles_touched > 0
+            rect = gv.aux_sorted[i].y;
+            if (rect & SGR_RECT_MASKED) tmask = gv.tmask[idx];  // (by id: 8 bytes, masked Gaussians only)
+        }
     }
     sOff[wave][lane] = off;  // lanes past P: 0xffffffff, never <= a slot
     sRect[wave][lane] = rect;
     sIdx[wave][lane] = idx;
+    sMask[wave][lane] = tmask;
     // wave-uniform slot range: exclusive offset of lane 0, inclusive offset of the last lane below P
     const uint32_t start = __builtin_amdgcn_readfirstlane(off);
     const int last = min(63, P - 1 - (blockIdx.x * SGR_PRE_THREADS + wave * 64));
@@ -319,8 +344,9 @@ sgr_duplicate_kernel(int P, SgrGeomView gv, const uint32_t* __restrict__ order, 
         for (int step = 32; step >= 1; step >>= 1)
             if (sOff[wave][o + step] <= s) o += step;
         const uint32_t r = sRect[wave][o];
-        const uint32_t x0 = r & 1023u, y0 = (r >> 10) & 1023u, w = r >> 20;
-        const uint32_t k = s - sOff[wave][o];
+        const uint32_t x0 = r & 1023u, y0 = (r >> 10) & 1023u, w = (r >> 20) & 1023u;
+        uint32_t k = s - sOff[wave][o];
+        if (r & SGR_RECT_MASKED) k = sgr_select_bit(sMask[wave][o], k);  // the k-th tile of the mask, as an index into the rect
         // k / w with one v_rcp_f32 and an exact fix-up (k < 2^20)
         uint32_t q = (uint32_t)((float)k * __builtin_amdgcn_rcpf((float)w));
         int rem = (int)k - (int)(q * w);
@@ -371,13 +397,13 @@ void sgr_launch_mark_visible(int P, const float* means3D, const float* viewmatri
 void sgr_launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, const float* rotations,
                            const float* opacities, const float* shs, const float* cov3D_precomp,
                            const float* colors_precomp, const SgrCam* cam, const SgrGeomView& gv, int* radii,
-                           int prefiltered, bool stage_sh, bool tight, hipStream_t s) {
+                           int prefiltered, bool stage_sh, int tight, hipStream_t s) {
     if (P <= 0) return;
     const bool stage = stage_sh && shs != nullptr && colors_precomp == nullptr && M == 16;
     const size_t lds = stage ? (size_t)(SGR_PRE_THREADS / 64) * 32 * 13 * sizeof(float4) : 0;
     sgr_preprocess_kernel<<<(P + SGR_PRE_THREADS - 1) / SGR_PRE_THREADS, SGR_PRE_THREADS, lds, s>>>(
         P, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, cam, gv, radii, prefiltered,
-        stage ? 1 : 0, tight ? 1 : 0);
+        stage ? 1 : 0, tight);
 }
 
 void sgr_launch_filter(int P, const float* means3D, const float* scales, const float* rotations,

@@ -258,8 +258,9 @@ def restrict_binning(internal, point_list, ranges, W, H, keys=None, n_contrib=No
     """The reference's binning arrays RESTRICTED to the tile rects the HIP path emitted its Gaussians for.
 
     The reference emits a (tile, Gaussian) instance for every tile of the square getRect gives (auxiliary.h:46-57); the HIP
-    path cuts that rect down to the tiles in which the Gaussian can reach alpha >= 1/255 (sgr_preprocess.hip; with
-    sgr_test_switches bit 10 it keeps the reference's rect and this function is the identity).  What it must hold is then:
+    path cuts that rect down to the tiles in which the Gaussian can reach alpha >= 1/255 (sgr_preprocess.hip: the bounding
+    box of those tiles and, for rects of up to 64 tiles, a mask of the tiles themselves; with sgr_test_switches bit 10 it keeps
+    the reference's rect and this function is the identity).  What it must hold is then:
     its sorted list is the reference's sorted list with the instances outside the rects REMOVED and nothing else changed --
     same order, same ranges after the removal, n_contrib counting only the instances that stayed.  (That the removed
     instances change no output is what the image / gradient gates and test_tight_rects_are_invisible check.)
@@ -269,6 +270,7 @@ def restrict_binning(internal, point_list, ranges, W, H, keys=None, n_contrib=No
     from types import SimpleNamespace
     rect = npy(internal("tile_rect")).astype(np.int64)
     P = rect.shape[0]
+    tmask = npy(internal("tile_mask")).view(np.uint64).reshape(-1)  # 0 = every tile of the rect; else bit j = tile j of the rect
     gx, gy = (W + 15) // 16, (H + 15) // 16
     T = gx * gy
     pl = np.asarray(point_list).astype(np.int64).reshape(-1)
@@ -278,10 +280,15 @@ def restrict_binning(internal, point_list, ranges, W, H, keys=None, n_contrib=No
     tx, ty = tile_of % gx, tile_of // gx
     r = rect[pl] if pl.size else np.zeros((0, 4), np.int64)
     keep = (tx >= r[:, 0]) & (tx < r[:, 2]) & (ty >= r[:, 1]) & (ty < r[:, 3])
+    mk = tmask[pl] if pl.size else np.zeros(0, np.uint64)
+    j = np.clip((ty - r[:, 1]) * (r[:, 2] - r[:, 0]) + (tx - r[:, 0]), 0, 63).astype(np.uint64)
+    keep &= (mk == 0) | (((mk >> j) & np.uint64(1)) == 1)
     cum = np.concatenate([[0], np.cumsum(keep)])
     new_rg = np.stack([cum[rg[:, 0]], cum[rg[:, 1]]], axis=1)
     new_rg[new_rg[:, 0] == new_rg[:, 1]] = 0  # a tile nothing was emitted for keeps its memset (rasterizer_impl.cu:313)
     tt = (rect[:, 2] - rect[:, 0]) * (rect[:, 3] - rect[:, 1])
+    pop = np.unpackbits(tmask.view(np.uint8).reshape(-1, 8), axis=1).sum(axis=1).astype(np.int64)
+    tt = np.where(tmask != 0, pop, tt)
     # every rect lies inside the reference's: the reference has an instance for each of its tiles
     assert (np.bincount(pl[keep], minlength=P) == tt).all(), "a HIP tile rect is not inside the reference's"
     out = SimpleNamespace(num_rendered=int(keep.sum()), point_list=pl[keep].astype(np.uint32), ranges=new_rg.astype(np.uint32),

@@ -96,6 +96,24 @@ void hm_quadrant_masks(int n, const float* means2D, const float* conic_opacity, 
     }
 }
 
+// tile masks of n splats over their rects {x0, y0, x1, y1} (tiles), and the two bit utilities the mask needs
+void hm_tile_masks(int n, const float* means2D, const float* conic_opacity, const unsigned* rects, unsigned long long* masks) {
+    for (int i = 0; i < n; i++)
+        masks[i] = sgr_tile_mask(means2D[2 * i], means2D[2 * i + 1], conic_opacity[4 * i], conic_opacity[4 * i + 1],
+                                 conic_opacity[4 * i + 2], conic_opacity[4 * i + 3], rects[4 * i], rects[4 * i + 1], rects[4 * i + 2],
+                                 rects[4 * i + 3]);
+}
+void hm_tile_masks_per_tile(int n, const float* means2D, const float* conic_opacity, const unsigned* rects, unsigned long long* masks) {
+    for (int i = 0; i < n; i++)
+        masks[i] = sgr_tile_mask_per_tile(means2D[2 * i], means2D[2 * i + 1], conic_opacity[4 * i], conic_opacity[4 * i + 1],
+                                          conic_opacity[4 * i + 2], conic_opacity[4 * i + 3], rects[4 * i], rects[4 * i + 1],
+                                          rects[4 * i + 2], rects[4 * i + 3]);
+}
+unsigned hm_select_bit(unsigned long long m, unsigned k) { return sgr_select_bit(m, k); }
+unsigned hm_row_of(unsigned rect, unsigned tx, unsigned ty, const unsigned* u0, const unsigned long long* tmask, unsigned g) {
+    return sgr_row_of(rect, tx, ty, u0, (const uint64_t*)tmask, g);
+}
+
 float hm_power2(float qa, float qb, float qc, float dx, float dy) { return sgr_power2(qa, qb, qc, dx, dy); }
 // parity mode: the staged power expression against the reference's own, and the shared-reciprocal quotient for a given
 // reciprocal seed (the test perturbs the seed by an ulp either way: the device's v_rcp_f32 is only accurate to 1 ulp)

@@ -163,3 +163,66 @@ def test_parity_mode_staged_power_and_quotient_identities(hm):
         q = np.zeros(n, np.float32)
         hm.hm_div_by_seed(n, _p(a), _p(b), _p(np.ascontiguousarray(seed, dtype=np.float32)), _p(q))
         assert (q == want).all(), int((q != want).sum())
+
+
+def test_tile_masks_are_conservative_and_the_bit_utilities_invert_each_other(hm):
+    """sgr_tile_mask (which tiles of its rect a Gaussian is emitted for): a tile that holds a pixel the blend accepts
+    (power <= 0 and alpha >= 1/255, forward.cu:425-430) always has its bit; the mask is worth having (most set bits are
+    needed).  sgr_select_bit / the rank inside sgr_row_of: select enumerates the set bits in order, rank inverts it."""
+    cam = syn.make_camera(400, 256, fx=420.0)
+    sc = syn.make_scene(3000, cam, S=0, seed=9, scale_px=0.012, zmin=1.0, zmax=12.0)
+    sc.scales[::3, 0] *= 6.0  # some needles: their bounding boxes have empty corners
+    fw = oracle.forward(**oracle_kwargs(cam, sc))
+    gx = (cam.image_width + 15) // 16
+    tile = (fw.keys >> np.uint64(32)).astype(np.int64)
+    tx, ty = tile % gx, tile // gx
+    ids, rects = [], []
+    for g in np.unique(fw.point_list):
+        m = fw.point_list == g
+        r = [tx[m].min(), ty[m].min(), tx[m].max() + 1, ty[m].max() + 1]
+        if 2 <= (r[2] - r[0]) * (r[3] - r[1]) <= 64:
+            ids.append(g); rects.append(r)
+    ids = np.array(ids); rects = np.ascontiguousarray(rects, dtype=np.uint32)
+    assert len(ids) > 500
+    m2 = np.ascontiguousarray(fw.means2D[ids]); co = np.ascontiguousarray(fw.conic_opacity[ids])
+    masks = np.zeros(len(ids), np.uint64)
+    hm.hm_tile_masks(len(ids), _p(m2), _p(co), _p(rects), _p(masks))
+    set_bits = needed = total = 0
+    for i in range(len(ids)):
+        x0, y0, x1, y1 = [int(v) for v in rects[i]]
+        w = x1 - x0
+        ys, xs = np.meshgrid(np.arange(y0 * 16, y1 * 16), np.arange(x0 * 16, x1 * 16), indexing="ij")
+        dx = m2[i, 0] - xs.astype(np.float32); dy = m2[i, 1] - ys.astype(np.float32)
+        power = -0.5 * (co[i, 0] * dx * dx + co[i, 2] * dy * dy) - co[i, 1] * dx * dy
+        acc = (power <= 0) & (np.minimum(0.99, co[i, 3] * np.exp(power)) >= 1.0 / 255.0)
+        for j in range(w * (y1 - y0)):
+            jy, jx = divmod(j, w)
+            need = acc[jy * 16:jy * 16 + 16, jx * 16:jx * 16 + 16].any()
+            bit = (int(masks[i]) >> j) & 1
+            assert bit or not need, "the mask dropped a tile with an accepted pixel"
+            set_bits += bit; needed += int(need); total += 1
+    assert needed / set_bits > 0.75 and set_bits / total < 0.95
+    # the row-wise form the preprocess runs against the per-tile definition: the same region up to the margins -- it may
+    # keep a few tiles more (the per-tile test knows both band limits of a tile, the row form one band) or, at a margin, fewer
+    ref_masks = np.zeros(len(ids), np.uint64)
+    hm.hm_tile_masks_per_tile(len(ids), _p(m2), _p(co), _p(rects), _p(ref_masks))
+    pop = lambda a: int(np.unpackbits(a.view(np.uint8)).sum())
+    assert abs(pop(masks) - pop(ref_masks)) <= 0.02 * pop(ref_masks), (pop(masks), pop(ref_masks))
+    hm.hm_select_bit.restype = C.c_uint32
+    hm.hm_select_bit.argtypes = [C.c_uint64, C.c_uint32]
+    hm.hm_row_of.restype = C.c_uint32
+    hm.hm_row_of.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
+    rng = np.random.default_rng(3)
+    u0 = np.array([1000], np.uint32)
+    for _ in range(300):
+        m = int(rng.integers(1, 2 ** 63, dtype=np.uint64)) & int(rng.integers(1, 2 ** 63, dtype=np.uint64)) | (1 << int(rng.integers(0, 64)))
+        bits = [b for b in range(64) if (m >> b) & 1]
+        tm = np.array([m], np.uint64)
+        for k, b in enumerate(bits):
+            assert hm.hm_select_bit(m, k) == b
+            # a masked rect of width 8 at (3, 5): tile index b -> row u0 + rank
+            rect = 3 | (5 << 10) | (8 << 20) | 0x80000000
+            assert hm.hm_row_of(rect, 3 + b % 8, 5 + b // 8, _p(u0), _p(tm), 0) == 1000 + k
+    rect = 3 | (5 << 10) | (8 << 20)  # without a mask: the index inside the rect
+    assert hm.hm_row_of(rect, 3 + 5, 5 + 2, _p(u0), None, 0) == 1000 + 2 * 8 + 5
+    fw.free()

@@ -191,8 +191,9 @@ def test_restrict_binning_restates_the_reference_lists_on_smaller_rects():
         rect[g] = [tx[m].min(), ty[m].min(), tx[m].max() + 1, ty[m].max() + 1]
     assert ((rect[:, 2] - rect[:, 0]) * (rect[:, 3] - rect[:, 1]) == fw.tiles_touched).all()
 
-    def internal_for(r):
-        return lambda name: _t.from_numpy(r.astype(np.int32)) if name == "tile_rect" else None
+    def internal_for(r, masks=None):
+        mk = np.zeros(P, np.int64) if masks is None else masks.astype(np.uint64).view(np.int64)
+        return lambda name: _t.from_numpy(r.astype(np.int32)) if name == "tile_rect" else (_t.from_numpy(mk) if name == "tile_mask" else None)
 
     same = restrict_binning(internal_for(rect), fw.point_list, fw.ranges, W, H, keys=fw.keys, n_contrib=fw.n_contrib)
     assert same.num_rendered == fw.num_rendered and same.removed == 0
@@ -223,6 +224,16 @@ def test_restrict_binning_restates_the_reference_lists_on_smaller_rects():
     t = (y // 16) * gx + x // 16
     a = fw.ranges[t][0]
     assert sub.n_contrib[y, x] == keep[a:a + fw.n_contrib[y, x]].sum()
+    # tile masks: drop the last tile of every rect of 2..64 tiles through its mask instead of through the rect
+    area = (rect[:, 2] - rect[:, 0]) * (rect[:, 3] - rect[:, 1])
+    masks = np.zeros(P, np.uint64)
+    sel = (area >= 2) & (area <= 64)
+    masks[sel] = (np.uint64(1) << (area[sel] - 1).astype(np.uint64)) - np.uint64(1)
+    msk = restrict_binning(internal_for(rect, masks), fw.point_list, fw.ranges, W, H, keys=fw.keys, n_contrib=fw.n_contrib)
+    last = np.array([sel[g] and (y - rect[g, 1]) * (rect[g, 2] - rect[g, 0]) + (x - rect[g, 0]) == area[g] - 1
+                     for g, x, y in zip(fw.point_list, tx, ty)])
+    assert msk.removed == last.sum() == sel[np.unique(fw.point_list)].sum()
+    assert (msk.point_list == fw.point_list[~last]).all() and (msk.tiles_touched[sel] == area[sel] - 1).all()
     with pytest.raises(AssertionError, match="not inside"):  # a rect that sticks out of the reference's is refused
         bad = rect.copy()
         g0 = int(fw.point_list[0])
