@@ -839,7 +839,7 @@ def main():
                        "instances_emitted": wl.R_emitted,
                        "instances_note": "num_rendered_R = the reference's num_rendered (3-sigma squares, auxiliary.h getRect), the "
                                          "unit of SURVEY 8d's byte formulas; instances_emitted = what this library duplicates, sorts "
-                                         "and blends (rects cut down to the tiles where the Gaussian can reach alpha >= 1/255; "
+                                         "and blends (rects cut down to the tiles where the Gaussian can reach alpha >= 1/255, with a tile mask inside them; "
                                          "bit-identical images, SGR_REF_RECT=1 restores the reference's rects)",
                        "parallelism": f"view-dp{world}" + ((" + RCCL all-reduce of Gaussian grads" + (
                            " (dense 44 B/Gaussian; SH gradient rebuilt from an all-gather of per-view dRGB, 12 B/Gaussian/view)"
