@@ -83,3 +83,45 @@ void replay(int W, int H, const uint32_t* ranges, const uint32_t* plist, const f
   }
   for (int i = 0; i < 16; ++i) out[i] = acc[i];
 }
+
+// Histogram of the number of hitting lanes per (quadrant, instance) visit: hist[k] = visits with exactly k of the 64 pixels
+// of the quadrant passing the alpha test while still unfinished (k = 1..64).  Same replay as above.
+void replay_lane_hist(int W, int H, const uint32_t* ranges, const uint32_t* plist, const float* m2d, const float* co,
+                      const uint32_t* ncontrib, double* hist) {
+  int gx = (W + 15) / 16, gy = (H + 15) / 16;
+  double acc[65] = {0};
+#pragma omp parallel
+  {
+    double a[65] = {0};
+#pragma omp for schedule(dynamic, 8)
+    for (int t = 0; t < gx * gy; ++t) {
+      uint32_t r0 = ranges[2 * t], r1 = ranges[2 * t + 1];
+      if (r1 <= r0) continue;
+      int tx = t % gx, ty = t / gx;
+      uint32_t nc[256]; uint32_t maxc = 0;
+      for (int p = 0; p < 256; ++p) {
+        int px = tx * 16 + (p & 15), py = ty * 16 + (p >> 4);
+        nc[p] = (px < W && py < H) ? ncontrib[py * W + px] : 0;
+        if (nc[p] > maxc) maxc = nc[p];
+      }
+      for (uint32_t pos = 0; pos < maxc; ++pos) {
+        uint32_t g = plist[r0 + pos];
+        float X = m2d[2 * g], Y = m2d[2 * g + 1], A = co[4 * g], B = co[4 * g + 1], Cc = co[4 * g + 2], O = co[4 * g + 3];
+        int lanes[4] = {0, 0, 0, 0};
+        for (int p = 0; p < 256; ++p) {
+          if (pos >= nc[p]) continue;
+          int lx = p & 15, ly = p >> 4;
+          float dx = X - (float)(tx * 16 + lx), dy = Y - (float)(ty * 16 + ly);
+          float pw = -0.5f * (A * dx * dx + Cc * dy * dy) - B * dx * dy;
+          if (pw > 0.f) continue;
+          if (fminf(0.99f, O * expf(pw)) < 1.f / 255.f) continue;
+          lanes[(ly >> 3) * 2 + (lx >> 3)]++;
+        }
+        for (int q = 0; q < 4; ++q) if (lanes[q]) a[lanes[q]] += 1;
+      }
+    }
+#pragma omp critical
+    for (int i = 0; i < 65; ++i) acc[i] += a[i];
+  }
+  for (int i = 0; i < 65; ++i) hist[i] = acc[i];
+}
