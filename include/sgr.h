@@ -41,7 +41,10 @@ int sgr_version(void);
  * P Gaussians, D = active SH degree, M = SH coefficients per Gaussian (row stride of shs), S = semantic
  * channels (<= 32).  Outputs: out_color[3,H,W], out_depth[1,H,W], out_alpha[1,H,W] (= sum alpha_i*T_i),
  * out_semantic[S,H,W], radii[P] (may be NULL).  Every output element is written (P == 0: zeros, as the
- * reference's torch::full(0) would leave them).  Returns num_rendered (R). */
+ * reference's torch::full(0) would leave them).  Returns num_rendered (R) = the number of (tile, Gaussian) instances this
+ * call emitted; it sizes the binning buffer and is what sgr_backward must be given.  By default a Gaussian is emitted
+ * only for the tiles in which it can reach alpha >= 1/255 (a subset of the reference's getRect square: same images, see
+ * sgr_test_switches bits 10 / 11), so R is smaller than the reference's count for the same frame. */
 int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn binning_buffer, void* binning_user,
                 sgr_alloc_fn image_buffer, void* image_user, int P, int D, int M, int S, const float* background,
                 int width, int height, const float* means3D, const float* shs, const float* colors_precomp,
