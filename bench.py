@@ -155,6 +155,43 @@ def cpu_baseline(args, cam, sc):
             "seconds": round(t_small, 3), "one_thread": one}
 
 
+def cpu_smoke_recipe():
+    """BASELINE.json configs[0] on the host's cores: the reference's own smoke test, script/test_gaussian_rasterization.py:44-91
+    -- 10 k torch.rand Gaussians (SH degree 0 with M = 4, un-normalised quaternions), its pinhole camera, 256x256, "Test 1" a
+    forward without semantics and "Test 2" one with 15 semantic channels -- through the C oracle (the reference has no CPU
+    path of its own; tests/test_gpu_parity.py: test_smoke_recipe_config0 is the same recipe through the GPU path)."""
+    import math
+    from oracle import oracle
+    c = syn.smoke_test_camera()
+    g = torch.Generator().manual_seed(0)
+    n, H, W = 10000, 256, 256
+    means3D, _m2d = torch.rand(n, 3, generator=g), torch.rand(n, 3, generator=g)
+    shs, opacity = torch.rand(n, 4, 3, generator=g), torch.rand(n, 1, generator=g)
+    scales, rotations = torch.rand(n, 3, generator=g), torch.rand(n, 4, generator=g)
+    rotations[:, 0] = 1
+    semantics = torch.rand(n, 15, generator=g)
+    out, R = {}, 0
+    for name, sem in (("test1_no_semantics", None), ("test2_15_semantic_channels", semantics)):
+        best = None
+        for _ in range(3):
+            t0 = time.time()
+            fw = oracle.forward(means3D=means3D, opacities=opacity, viewmatrix=c["world_view_transform"],
+                                projmatrix=c["full_proj_transform"], campos=c["camera_center"], bg=torch.zeros(3),
+                                tanfovx=math.tan(c["FoVx"] * 0.5), tanfovy=math.tan(c["FoVy"] * 0.5), image_height=H,
+                                image_width=W, sh_degree=0, shs=shs, scales=scales, rotations=rotations, semantics=sem,
+                                internals=False)
+            d = time.time() - t0
+            R = fw.num_rendered
+            fw.free()
+            best = d if best is None else min(best, d)
+        out[name + "_ms"] = round(1e3 * best, 2)
+    out.update({"gaussians": n, "image": f"{W}x{H}", "sh_degree": 0, "num_rendered_R": int(R),
+                "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)),
+                "what": "configs[0]: the forward calls of script/test_gaussian_rasterization.py:44-91 through the C oracle "
+                        "(OpenMP), best of 3 each"})
+    return out
+
+
 def reference_kernels_on_gpu(args, cam, sc):
     """Times the reference's OWN kernels (untouched CUDA sources compiled for gfx950, oracle/_ref) on this GPU at
     the same workload: the most meaningful speed-up denominator.  Test infrastructure used as a
@@ -720,36 +757,39 @@ def main():
         if kernel_samples < 16 and s_timed.get("blend_bwd"):
             timed = dict(timed, blend_bwd=s_timed["blend_bwd"])
             kernel_samples, kernel_region = (n + 7) // 8, f"the sustained region of {n} steps"
-    # parity mode of the blend kernels (the reference's power expression, accurate expf, true
-    # division -- bit-identical alpha / depth / semantic images and rel-1e-4 end-to-end gradients against the reference's
-    # kernels): an extra, untimed-for-the-headline region on the same workload, so that its cost is in the line
-    parity_mode = None
+    # The CONFORMING configurations (north_star: "tile/bin indices bit-exact ... within 1e-4 rel"), measured on the same
+    # workload in regions of their own so that their cost is in the line next to `value`:
+    #   exact  = sgr_test_switches bit 7 (SGR_EXACT=1): the reference's power expression, the device library's expf, the IEEE
+    #            quotient T / (1 - alpha), unfused; K12/K13 without FP contraction -- alpha / depth / semantic images
+    #            bit-identical to the reference's strict build, every gradient within rel 1e-4 END TO END;
+    #   strict = bits 7 + 10 (SGR_EXACT=1 SGR_REF_RECT=1): additionally the reference's own tile rects, so that
+    #            num_rendered / point_list / keys / ranges / n_contrib are the reference's ENTRY FOR ENTRY
+    #            (tests/test_gpu_fullsize.py: test_threeway_against_reference_kernels_at_baseline_size).
+    # `value` itself is the default arithmetic on the cut-down tile lists (same images bit for bit, same sums regrouped).
+    modes = {}
     if world == 1 and dist is None:
         from street_gaussians_amd import _C as native_c
         prev = native_c.test_switches(-1)
-        native_c.test_switches(prev | native_c.EXACT)
-        try:
-            for _ in range(5):
-                wl.step()
-            n_p = max(args.steps, int(0.6 / max(dt / args.steps, 1e-5)) + 1)  # the same kind of region as `sustained`
-            pdt, _ = profiled_steps(L, wl, fence, n_p, 0)
-            _, p_stage = profiled_steps(L, wl, fence, 16, (1 << 5) | (1 << 7) | (1 << 8))
-            parity_mode = {"steps": n_p, "ms_per_step": round(1e3 * pdt / n_p, 4), "iters_per_s": round(n_p / pdt, 3),
-                           "blend_fwd_ms": round(p_stage["blend_fwd"], 4) if p_stage.get("blend_fwd") else None,
-                           "blend_bwd_ms": round(p_stage["blend_bwd"], 4) if p_stage.get("blend_bwd") else None,
-                           "gauss_bwd_ms": round(p_stage["gauss_bwd"], 4) if p_stage.get("gauss_bwd") else None,
-                           "what": "same workload with sgr_test_switches bit 7 (SGR_EXACT=1): the mode that meets north_star's "
-                                   "1e-4 gate END TO END against the reference's kernels (alpha / depth / semantic images "
-                                   "bit-identical; tests/test_gpu_fullsize.py, tests/test_gpu_parity.py) -- the reference's power "
-                                   "expression, the device library's expf and the IEEE quotient T / (1 - alpha), unfused, "
-                                   "per-Gaussian backward without FP contraction; the default mode (`value`) uses v_exp_f32 "
-                                   "on a pre-scaled conic, a Newton-refined reciprocal and contraction: same algorithm, "
-                                   "different last bits (DESIGN.md section 4)"}
-        finally:
-            native_c.test_switches(prev)
+        for label, mask in (("exact", native_c.EXACT), ("strict", native_c.EXACT | native_c.REF_RECT)):
+            native_c.test_switches(prev | mask)
+            try:
+                for _ in range(5):
+                    wl.step()
+                n_p = max(args.steps, int(0.6 / max(dt / args.steps, 1e-5)) + 1)  # the same kind of region as `sustained`
+                pdt, _ = profiled_steps(L, wl, fence, n_p, 0)
+                _, p_stage = profiled_steps(L, wl, fence, 16, 0x1FF)
+                m_R, m_V, _ = wl.counts()  # under the switch: what this mode emits
+                modes[label] = {"steps": n_p, "ms_per_step": round(1e3 * pdt / n_p, 4), "iters_per_s": round(n_p / pdt, 3),
+                                "instances_emitted": wl.R_emitted, "stages_ms": {k: (round(v, 4) if v is not None else None)
+                                                                                 for k, v in p_stage.items()},
+                                "switches": int(mask)}
+            finally:
+                native_c.test_switches(prev)
         for _ in range(3):
             wl.step()
+    parity_mode = modes.get("exact")
     R, V, pairs_blended = wl.counts()
+    wl_R_emitted = wl.R_emitted  # default mode (the mode regions above ran wl.counts() under their own switches)
     N = args.width * args.height
     # N > 1 (or a forced one-rank group) with --densify-loop: configs[4] as BASELINE.json words it, every rank taking part
     densify_multi = None
@@ -768,6 +808,7 @@ def main():
         algo_bytes, fwd_bytes = blend_bytes(S, R, N, V)
         T_tiles = ((args.width + 15) // 16) * ((args.height + 15) // 16)
         sb = stage_bytes(args.gaussians, wl.V_in, V, R, N, T_tiles, S)
+        sb_emitted = stage_bytes(args.gaussians, wl.V_in, V, wl_R_emitted, N, T_tiles, S)
         achieved = algo_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms else None
         fwd_ms = stage_ms["blend_fwd"]
         traffic, valu, traffic_note, pmc_derived = None, None, None, None
@@ -797,41 +838,48 @@ def main():
                                 "source": "profiles/pmc_blend_bwd.json (SQ_INSTS_VALU) / live kernel_ms"}
             except Exception as ex:
                 traffic, traffic_note = None, f"profiles/pmc_blend_bwd.json unreadable: {ex}"
-        # `value`: whole-job throughput.  When the K timed steps lasted less than a second (N = 1) it is the figure of the
-        # >= 1 s sustained region (the K-step region itself stays in the line as `timed_region`)
+        # `value`: whole-job throughput of the timed region -- EXACTLY --steps steps between two fences, as the command line
+        # says.  (Round 4 printed the >= 1 s sustained region as `value` next to `steps: K`; the two agree to < 0.1 % once
+        # the device is at its clocks, and a line whose `steps` and `ms_per_step` describe different regions reads wrong.)
         value = round(world * args.steps / dt, 3)
         ms_per_step = round(1e3 * dt / args.steps, 4)
-        timed_region = {"steps": args.steps, "ms_per_step": ms_per_step, "value": value,
-                        "what": "exactly --steps steps between two fences (barrier + synchronize)"}
-        if sustained is not None:
-            value, ms_per_step = sustained["iters_per_s"], sustained["ms_per_step"]
         # the bound the dominant kernel actually runs against: VALU issue.  Per-visit pipe cycles from the static model of the
-        # kernel's ISA priced with MEASURED instruction costs (tools/valu_model.py, tools/ubench/valu_rates.hip), times the
-        # visits of this frame, over the 1024 SIMDs
+        # kernel's ISA priced with instruction costs MEASURED IN CYCLES (tools/valu_model.py over tools/ubench/valu_rates2.hip:
+        # s_memtime in the kernel, clock reported), times the visits of this frame, over the 1024 SIMDs at the ubench's clock
         valu_issue = None
         try:
-            vm = json.load(open(os.path.join(ROOT, "profiles", "r4", "valu_model.json")))
+            vm = json.load(open(os.path.join(ROOT, "profiles", "r5", "valu_model.json")))
             if S == 0 and bwd_ms and vm["default"].get("source_sha16") == sgr_build.source_sha16():
                 visits = count_visits(wl, R)
-                cyc = vm["default"]["valu_pipe_cycles_per_visit"]
-                bound_ms = visits * cyc / (1024 * 2.4e9) * 1e3
-                valu_issue = {"bound": "valu_issue", "visits": visits, "valu_pipe_cycles_per_visit": cyc,
+                cyc, ghz = vm["default"]["valu_pipe_cycles_per_visit"], vm["default"]["clock_ghz"]
+                bound_ms = visits * cyc / (1024 * ghz * 1e9) * 1e3
+                valu_issue = {"bound": "valu_issue", "visits": visits, "valu_pipe_cycles_per_visit": cyc, "clock_ghz": ghz,
                               "bound_ms": round(bound_ms, 4), "kernel_ms": round(bwd_ms, 4), "frac": round(bound_ms / bwd_ms, 3),
-                              "source": "profiles/r4/valu_model.json (static ISA model x measured instruction costs, "
-                                        "profiles/r4/valu_rates.jsonl); time bound = visits * cycles / (1024 SIMDs * ubench clock)"}
+                              "source": "profiles/r5/valu_model.json (static ISA model x instruction costs in cycles, "
+                                        "profiles/r5/valu_rates2.jsonl); time bound = visits * cycles / (1024 SIMDs * measured clock)"}
             elif S == 0:
-                valu_issue = {"note": "profiles/r4/valu_model.json was made for other kernel sources: re-run tools/valu_model.py"}
+                valu_issue = {"note": "profiles/r5/valu_model.json was made for other kernel sources: re-run tools/valu_model.py"}
         except Exception as ex:
             valu_issue = {"note": f"unavailable: {ex}"[:160]}
+
+        def kernel_roofline(kms, instances):
+            """HBM fraction of the blend backward for a launch of `kms` ms: SURVEY 8d's formula on the instances the launch
+            actually processed (the basis of `frac`), and on the reference's R (the work the reference's kernel does)."""
+            if not kms:
+                return None
+            be, br = blend_bytes(S, instances, N, V)[0], algo_bytes
+            return {"kernel_ms": round(kms, 4), "instances": instances, "algorithmic_bytes_per_launch": be,
+                    "achieved": round(be / (kms * 1e-3) / 1e9, 2), "frac": round(be / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "frac_on_reference_R": round(br / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+
+        rl_default = kernel_roofline(bwd_ms, wl_R_emitted)
+        rl_modes = {k: kernel_roofline(m["stages_ms"].get("blend_bwd"), m["instances_emitted"]) for k, m in modes.items()}
+        g = lambda d, k: (d or {}).get(k)
         line = {
             "metric": "train iters/s (fwd+bwd) @1M Gaussians 1920x1280 SH3",
             "value": value,
-            "value_source": ("sustained region (>= 1 s of back-to-back steps after the timed region; the timed region is "
-                             "`timed_region`)" if sustained is not None else "the timed region of --steps steps"),
-            "value_exact": parity_mode["iters_per_s"] if parity_mode is not None else None,
-            "ms_per_step_exact": parity_mode["ms_per_step"] if parity_mode is not None else None,
-            "modes": "value = default arithmetic of the blend kernels; value_exact = parity mode (SGR_EXACT=1), the mode that "
-                     "meets the 1e-4 gate end to end against the reference's kernels: see `parity_mode`",
+            "value_exact": g(modes.get("exact"), "iters_per_s"),
+            "value_strict": g(modes.get("strict"), "iters_per_s"),
             "unit": "iters/s",
             "n_gpus": world,
             "rccl_ranks": (dist.get_world_size() if dist is not None else 0),
@@ -839,7 +887,8 @@ def main():
             "warmup": args.warmup,
             "device_warmup_s": args.device_warmup,
             "ms_per_step": ms_per_step,
-            "timed_region": timed_region,
+            "ms_per_step_exact": g(modes.get("exact"), "ms_per_step"),
+            "ms_per_step_strict": g(modes.get("strict"), "ms_per_step"),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -852,11 +901,11 @@ def main():
                        "gaussians": args.gaussians, "width": args.width, "height": args.height, "sh_degree": 3,
                        "semantic_channels": S, "loss": args.loss, "views_per_step": world, "num_rendered_R": R, "visible_V": V,
                        "R_over_P": round(R / args.gaussians, 3), "V_over_P": round(V / args.gaussians, 3),
-                       "instances_emitted": wl.R_emitted,
+                       "instances_emitted": wl_R_emitted,
                        "instances_note": "num_rendered_R = the reference's num_rendered (3-sigma squares, auxiliary.h getRect), the "
-                                         "unit of SURVEY 8d's byte formulas; instances_emitted = what this library duplicates, sorts "
+                                         "unit of SURVEY 8d's byte formulas; instances_emitted = what the default mode duplicates, sorts "
                                          "and blends (rects cut down to the tiles where the Gaussian can reach alpha >= 1/255, with a tile mask inside them; "
-                                         "bit-identical images, SGR_REF_RECT=1 restores the reference's rects)",
+                                         "bit-identical images); value_strict runs on the reference's rects (SGR_REF_RECT=1)",
                        "parallelism": f"view-dp{world}" + ((" + RCCL all-reduce of Gaussian grads" + (
                            " (dense 44 B/Gaussian; SH gradient rebuilt from an all-gather of per-view dRGB, 12 B/Gaussian/view)"
                            if args.reduce == "factored" else " (one 236 B/Gaussian bucket)")) if world > 1 else ""),
@@ -865,32 +914,35 @@ def main():
                            "side stream, overlapped with the next step's forward (one-step-delayed gradients in training)"
                            if args.exchange == "overlap" else "blocking, inside the step")),
                        "kernel_sources_sha16": sgr_build.source_sha16()},
+            # scalars first (the driver's record keeps the scalar fields of this object): `frac` is on the instances the
+            # launch processes; the three modes side by side
             "roofline": {"bound": "hbm", "kernel": kernel_name,
-                         "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": traffic,
+                         "achieved": g(rl_default, "achieved"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": g(rl_default, "frac"), "frac_on_reference_R": g(rl_default, "frac_on_reference_R"),
+                         "traffic": traffic,
+                         "kernel_ms": g(rl_default, "kernel_ms"),
+                         "kernel_ms_exact": g(rl_modes.get("exact"), "kernel_ms"), "frac_exact": g(rl_modes.get("exact"), "frac"),
+                         "kernel_ms_strict": g(rl_modes.get("strict"), "kernel_ms"), "frac_strict": g(rl_modes.get("strict"), "frac"),
+                         "valu_issue_frac": g(valu_issue, "frac"),
+                         "algorithmic_bytes_per_launch": g(rl_default, "algorithmic_bytes_per_launch"),
+                         "algorithmic_bytes_note": "SURVEY 8d: (44+4S) R + (28+4S) N + (48+4S) V with R = the instances the launch "
+                                                   "processes (config.instances_emitted); frac_on_reference_R: the same with the "
+                                                   "reference's num_rendered",
                          "traffic_note": traffic_note, "valu": valu, "valu_issue": valu_issue, "pmc": pmc_derived,
-                         "algorithmic_bytes_per_launch": algo_bytes,
-                         "algorithmic_bytes_note": "SURVEY 8d: (44+4S) R + (28+4S) N + (48+4S) V with R = the REFERENCE's num_rendered "
-                                                   "(config.num_rendered_R) -- the work the reference's kernel does for this frame",
-                         # the same formula on the instances this library actually emits (tile rects cut down)
-                         "on_emitted_instances": (lambda be: {"instances": wl.R_emitted, "algorithmic_bytes_per_launch": be,
-                                                              "achieved": round(be / (bwd_ms * 1e-3) / 1e9, 2) if bwd_ms else None,
-                                                              "frac": round(be / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if bwd_ms else None})(
-                             blend_bytes(S, wl.R_emitted, N, V)[0]),
-                         "kernel_ms": round(bwd_ms, 4) if bwd_ms else None,
+                         "modes": {"default": rl_default, **rl_modes},
                          "kernel_ms_source": f"HIP events around the kernel on its launch stream, mean over "
                                              f"{kernel_samples} launches of {kernel_region} "
                                              f"(every 8th step at most carries the event pair)",
                          "blend_fwd": {"kernel_ms": round(fwd_ms, 4) if fwd_ms else None,
-                                       "achieved": round(fwd_bytes / (fwd_ms * 1e-3) / 1e9, 2) if fwd_ms else None,
-                                       "algorithmic_bytes_per_launch": fwd_bytes},
+                                       "achieved": round(blend_bytes(S, wl_R_emitted, N, V)[1] / (fwd_ms * 1e-3) / 1e9, 2) if fwd_ms else None,
+                                       "algorithmic_bytes_per_launch": blend_bytes(S, wl_R_emitted, N, V)[1]},
                          "stages_ms": {k: (round(v, 4) if v is not None else None) for k, v in stage_ms.items()},
                          "stages_ms_source": "extra pass after the timed region, every stage bracketed by HIP events",
-                         "stages_bytes": sb, "stages_hbm_frac": stage_hbm_frac(stage_ms, sb),
-                         "stages_hbm_frac_on_emitted_instances": stage_hbm_frac(
-                             stage_ms, stage_bytes(args.gaussians, wl.V_in, V, wl.R_emitted, N, T_tiles, S)),
+                         "stages_bytes": sb_emitted, "stages_hbm_frac": stage_hbm_frac(stage_ms, sb_emitted),
+                         "stages_hbm_frac_on_reference_R": stage_hbm_frac(stage_ms, sb),
                          "stages_bytes_source": "SURVEY 8d algorithmic bytes (B_pre, B_scan, B_dup, B_sort = 24 R, B_rng, "
-                                                "B_blend_f, B_blend_b, B_pre_b); frac = bytes / stage time / 8 TB/s",
+                                                "B_blend_f, B_blend_b, B_pre_b) with R = the emitted instances; frac = bytes / "
+                                                "stage time / 8 TB/s",
                          "sum_n_contrib_pairs": pairs_blended,
                          "note": "the blend kernels are VALU-issue bound (SURVEY 8d; `valu_issue`: the backward runs at that "
                                  "fraction of its pipes' capacity at measured instruction costs); the HBM fraction is reported "
@@ -898,8 +950,12 @@ def main():
         }
         if sustained is not None:
             line["sustained"] = sustained
-        if parity_mode is not None:
-            line["parity_mode"] = parity_mode
+        if modes:
+            line["modes"] = dict(modes, what="exact = sgr_test_switches bit 7 (SGR_EXACT=1): meets north_star's 1e-4 gate END TO END "
+                                 "against the reference's kernels (alpha / depth / semantic images bit-identical); strict = bits 7 + 10 "
+                                 "(+ SGR_REF_RECT=1): additionally the reference's tile rects, binning arrays entry for entry; "
+                                 "`value` = default arithmetic (v_exp_f32 on a pre-scaled conic, Newton-refined reciprocal, "
+                                 "contraction) on the cut-down tile lists: same algorithm, different last bits (DESIGN.md section 4)")
         if exchange_overlap is not None:
             line["exchange_overlap"] = exchange_overlap
         if world == 1 and dist is None and not args.no_other_configs and not args.scene:
@@ -919,6 +975,25 @@ def main():
             except Exception as ex:  # the baseline is a reported extra; never lose the GPU number over it
                 line["cpu_baseline"] = {"value": None, "unit": "iters/s", "cores": os.cpu_count(), "kind": "port",
                                         "sample": f"failed: {ex}"}
+            try:
+                line["cpu_baseline"]["configs0_smoke_recipe"] = cpu_smoke_recipe()
+            except Exception as ex:
+                line["cpu_baseline"]["configs0_smoke_recipe"] = {"error": str(ex)[:160]}
+        # LAST key: the figures a reader of the tail of this line needs, in one short object
+        line["summary"] = {
+            "value": value, "ms_per_step": ms_per_step, "steps": args.steps,
+            "value_exact": line["value_exact"], "ms_per_step_exact": line["ms_per_step_exact"],
+            "value_strict": line["value_strict"], "ms_per_step_strict": line["ms_per_step_strict"],
+            "sustained_ms_per_step": g(sustained, "ms_per_step"),
+            "blend_bwd_ms": {"default": g(rl_default, "kernel_ms"), "exact": g(rl_modes.get("exact"), "kernel_ms"),
+                             "strict": g(rl_modes.get("strict"), "kernel_ms")},
+            "blend_bwd_hbm_frac_on_processed_instances": {"default": g(rl_default, "frac"), "exact": g(rl_modes.get("exact"), "frac"),
+                                                          "strict": g(rl_modes.get("strict"), "frac")},
+            "blend_bwd_hbm_frac_on_reference_R": g(rl_default, "frac_on_reference_R"),
+            "valu_issue_frac": g(valu_issue, "frac"),
+            "instances": {"reference_R": R, "emitted_default": wl_R_emitted},
+            "cpu_baseline_iters_per_s": g(line.get("cpu_baseline"), "value"),
+            "reference_kernels_on_this_gpu_iters_per_s": g(line.get("reference_kernels_mi355x"), "iters_per_s")}
         try:  # RCCL prints a version banner through C stdio; flush it so the JSON line stays the last line
             C.CDLL(None).fflush(None)
         except Exception:
@@ -954,12 +1029,17 @@ def other_configs(args, L, dev, fence):
             R, V, _ = wl.counts()
             bb, fb = blend_bytes(S, R, args.width * args.height, V)
             sb = stage_bytes(P, wl.V_in, V, R, args.width * args.height, ((args.width + 15) // 16) * ((args.height + 15) // 16), S)
+            Npx, Tt = args.width * args.height, ((args.width + 15) // 16) * ((args.height + 15) // 16)
+            sbe = stage_bytes(P, wl.V_in, V, wl.R_emitted, Npx, Tt, S)  # on the instances the kernels process
+            bbe = blend_bytes(S, wl.R_emitted, Npx, V)[0]
             out.append({"config": name, "gaussians": P, "semantic_channels": S, "steps": steps,
                         "ms_per_step": round(1e3 * dt / steps, 4), "iters_per_s": round(steps / dt, 3),
-                        "num_rendered_R": R, "instances_emitted": wl.R_emitted, "visible_V": V, "stages_hbm_frac": stage_hbm_frac(st, sb),
+                        "num_rendered_R": R, "instances_emitted": wl.R_emitted, "visible_V": V,
+                        "stages_hbm_frac": stage_hbm_frac(st, sbe), "stages_hbm_frac_on_reference_R": stage_hbm_frac(st, sb),
                         "blend_bwd_ms": round(st["blend_bwd"], 4) if st["blend_bwd"] else None,
                         "blend_fwd_ms": round(st["blend_fwd"], 4) if st["blend_fwd"] else None,
-                        "blend_bwd_hbm_frac": round(bb / (st["blend_bwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if st["blend_bwd"] else None,
+                        "blend_bwd_hbm_frac": round(bbe / (st["blend_bwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if st["blend_bwd"] else None,
+                        "blend_bwd_hbm_frac_on_reference_R": round(bb / (st["blend_bwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if st["blend_bwd"] else None,
                         "stages_ms": {k: (round(v, 4) if v is not None else None) for k, v in st.items()}})
             del wl
         except Exception as ex:  # an extra: never lose the headline over it

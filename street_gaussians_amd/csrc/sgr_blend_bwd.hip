@@ -56,6 +56,39 @@ struct SgrBwdBatch { static constexpr int value = SMAX <= 8 ? SGR_BWD_BATCH : SG
 #ifndef SGR_FOLD
 #define SGR_FOLD 1
 #endif
+// VISIT ROWS (round 5).  Until round 4 the (up to four) wave partials of an instance met in LDS with ds_add_f32 on two
+// zero-initialised rows per slot.  The LDS adds floats ONE LANE AT A TIME -- tools/ubench/valu_rates2.hip: a ds_add_f32 costs
+// the CU's LDS 3 cycles per active lane, 36 for the twelve lanes of a row, against 4 for a ds_write_b32 -- and the counters
+// had the LDS array 60 % busy in this kernel (profiles/pmc_blend_bwd.json: SQ_LDS_IDX_ACTIVE), most of it these adds.  Now
+// every VISIT gets a row of its own in LDS: wave q's visits of a round take consecutive rows in the order it walks them
+// (row = the rows of the quadrants before it + a running count: scalar bookkeeping), the sums are written with PLAIN
+// stores -- one writer per row, no atomics, no zero fill -- and the flush adds the rows of an instance's visits in quadrant
+// order (the rank of a slot among the set bits of a quadrant's survivor mask = its row: one v_mbcnt pair).  The row array
+// keeps its size (2 rows per slot = 256 at 128-entry rounds); a round whose survivor masks hold more visits than that
+// (big splats seen by three or four quadrants each) walks fewer slots -- a multiple of 32, at least a quarter of the round --
+// and the next round re-stages the rest.  Deterministic as before (fixed order everywhere).  SGR_VROWS=0: the two-row
+// ds_add_f32 combine (A/B: tools/build_variant.py); the !DET / !DPP test instantiations always use it.
+#ifndef SGR_VROWS
+#define SGR_VROWS 1
+#endif
+// SPARSE visits (round 5).  The reduce-scatter costs the same 9 permlane swaps + 7 DPP adds however few of the wave's 64
+// pixels hit, and on the benchmark frame 27 % of the visits have at most 8 hitting lanes (tools/lane_hist.py).  A visit with
+// at most SGR_SPARSE_K hitting lanes skips the cross-lane reduction: the hit lanes file their 12 values in a per-wave LDS
+// stage (entry = rank of the lane among the hit lanes: three ds_write_b128 under the hit lanes' EXEC), the twelve lanes
+// that own the row positions read the entries back and add them in rank order (one ds_read_b32 per entry, k - 1 plain
+// adds), then add the sum to the slot's row exactly like the dense path does -- still ONE contribution per wave and
+// instance, so the two-row combine stays bit-reproducible.  LDS operations of one wave execute in order: no wait between
+// the writes and the reads.  0 disables the path (A/B: tools/build_variant.py).  S = 0 instantiations only.
+#ifndef SGR_SPARSE_K
+#define SGR_SPARSE_K 8
+#endif
+// SGR_SPARSE_MODE 2: the hit lanes ADD their values into ONE per-wave entry instead (eleven ds_add_f32 under the hit lanes'
+// EXEC, all lanes of an instruction on the same address: the LDS serialises them in lane order, and nobody else touches the
+// entry), a row owner reads the sum, clears the word and adds it to the row: no rank, no adds on the VALU, one LDS round
+// trip, 192 bytes of LDS whatever the threshold.
+#ifndef SGR_SPARSE_MODE
+#define SGR_SPARSE_MODE 1
+#endif
 
 // self-test of the DPP reduction (sgr_selftest in sgr_api.hip)
 __global__ void sgr_wave_sum_test_kernel(const float* in, float* out_dpp, float* out_shfl) {
@@ -127,6 +160,17 @@ __device__ __forceinline__ void sgr_lds_barrier() {
     __syncthreads();
 }
 
+// byte address inside the workgroup's LDS allocation of a pointer into a __shared__ array (for ds_* written as asm)
+__device__ __forceinline__ uint32_t sgr_lds_addr(const float* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)p;
+}
+// population count of a wave-uniform lane mask, on the scalar unit (hipcc compares the i64 ctpop with a VALU v_cmp_gt_u64)
+__device__ __forceinline__ int sgr_popc64(uint64_t m) {
+    int r;
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(r) : "s"(m) : "scc");
+    return r;
+}
+
 template <int SMAX, bool CULL, bool DPP, bool DET, int BATCH, bool EXACT = false>
 __device__ __forceinline__ void
 sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int S,
@@ -146,10 +190,9 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
     // rows (flush, zero fill) spread over all 64 banks -- at 16 / 24 / 32 floats per row (4, 12, 20 channels) they fell
     // on 4-8 banks (SQ_LDS_BANK_CONFLICT: 102 M cycles per launch at 20 channels, none at S = 0)
     constexpr int ACCW = NVAL + (((NVAL / 4) & 1) ? 0 : 4);
-    __shared__ float4 sA[BATCH];  // {x, y, -, -}
+    __shared__ float4 sA[BATCH];  // {x, y, bits of the instance's partial-row index u, -}
     __shared__ float4 sB[BATCH];  // {qa, qb, qc, opacity}
     __shared__ float4 sC[BATCH];  // {r, g, b, depth}
-    __shared__ uint32_t sU[BATCH];
     __shared__ uint64_t sBits[4][4];
     __shared__ int sMax[4];
     // The (up to four) wave partials of an instance meet in LDS with ds_add_f32.  DET: two zero-initialised
@@ -159,7 +202,15 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
     // !DET: a single row shared by all four waves (arrival order can change the last bit, like the reference's
     // atomicAdd).
     constexpr int NROW = DET ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) float sAcc[NROW * BATCH * ACCW];
+    constexpr bool VROWS = SGR_VROWS && DET && DPP && SGR_FOLD;  // one LDS row per visit, plain stores (see SGR_VROWS)
+    constexpr int CAP = NROW * BATCH;                             // rows in LDS
+    constexpr int NCH = BATCH / 64;                               // 64-slot chunks of a round
+    // sparse-visit stage (see SGR_SPARSE_K): SPK entries of 12 floats per wave, behind the rows in the same array so that
+    // the row owners reach it from their row address with one wave-uniform offset
+    constexpr int SPK = (SMAX == 0 && DPP && SGR_FOLD) ? SGR_SPARSE_K : 0;
+    constexpr int SPE = SGR_SPARSE_MODE == 2 ? (SPK > 0 ? 1 : 0) : SPK;  // stage entries per wave
+    constexpr int STAGE0 = NROW * BATCH * ACCW;
+    __shared__ __attribute__((aligned(16))) float sAcc[STAGE0 + 4 * SPE * 12];
     __shared__ __attribute__((aligned(16))) float sSem[SMAX > 0 ? BATCH * SMAX : 4];  // zero-padded to SMAX
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -225,6 +276,9 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
     if (lane == 0) sMax[wave] = mx;
+    if (SGR_SPARSE_MODE == 2) {
+        if (SPK > 0 && tid < 4 * 12) sAcc[STAGE0 + tid] = 0.0f;  // the per-wave accumulation entries start (and are left) at zero
+    } else if (SPK > 0 && tid < 4 * SPK) sAcc[STAGE0 + tid * 12 + 11] = 0.0f;  // padding word of the stage entries: never written again
     sgr_lds_barrier();
     const int maxc = max(max(sMax[0], sMax[1]), max(sMax[2], sMax[3]));
     const float tx0 = (float)(tx * SGR_BLOCK_X), ty0 = (float)(ty * SGR_BLOCK_Y);
@@ -234,7 +288,12 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
     // float4 number 4i + fold_t0 of the slot's row; its first lane adds it at component lane >> 4
     const int fold_t0 = (0x3120 >> (((lane >> 2) & 3) * 4)) & 3;  // {0, 2, 1, 3}[bank]
     const bool fold_leader = (lane & 3) == 0;
-    const int acc_fold_off = (DET ? (wave >> 1) : 0) * BATCH * ACCW + 4 * fold_t0 + (lane >> 4);
+    const int acc_fold_off = (VROWS ? 0 : (DET ? (wave >> 1) : 0) * BATCH * ACCW) + 4 * fold_t0 + (lane >> 4);
+    // sparse-visit stage of this wave, as floats from sAcc (wave-uniform: scalar registers), and the same relative to the
+    // row set this wave adds into -- a row owner's stage address is its row address + one scalar
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int stage_off = STAGE0 + wave_s * (SPE * 12);
+    const int stage_rel = stage_off - (VROWS ? 0 : (DET ? (wave_s >> 1) : 0) * BATCH * ACCW);
 
     // The staging of a round is a dependent pair of gathers (list entry -> record).  The first half is taken out of the
     // round: the entry (and its hit byte) of round n + 1 is loaded while round n walks -- 2 VGPRs held across the walk --
@@ -250,17 +309,19 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
             if (CULL && hit4 != nullptr) h_pre = hit4[range.x + (uint32_t)pos0];
         }
     }
-    for (int hi = maxc - 1; hi >= 0; hi -= BATCH) {
+    for (int hi = maxc - 1; hi >= 0;) {
         // slot t of this batch holds list position hi - t (descending: back to front)
         sgr_lds_barrier();  // previous batch fully consumed (rows written) before LDS is overwritten
         const bool stager = tid < BATCH;  // whole waves: the batch is a multiple of 64
         const int pos = stager ? hi - tid : -1;
         uint32_t mask4 = 0;
+        if (!VROWS) {
 #pragma unroll
-        for (int row = tid; row < NROW * BATCH; row += SGR_TILE_THREADS) {
-            float4* z = reinterpret_cast<float4*>(&sAcc[row * ACCW]);
+            for (int row = tid; row < NROW * BATCH; row += SGR_TILE_THREADS) {
+                float4* z = reinterpret_cast<float4*>(&sAcc[row * ACCW]);
 #pragma unroll
-            for (int k4 = 0; k4 < ACCW / 4; k4++) z[k4] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int k4 = 0; k4 < ACCW / 4; k4++) z[k4] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
         if (pos >= 0) {
             const uint32_t g = SGR_BWD_PREFETCH ? g_pre : point_list[range.x + (uint32_t)pos];
@@ -268,13 +329,13 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
             const float4 a = r[0];
             const float4 b = r[1];
             const float4 d4 = r[3];
-            sA[tid] = a;
             sB[tid] = EXACT ? make_float4(-0.5f * b.x, -b.y, -0.5f * b.z, b.w)
                             : sgr_stage_conic(b);
             sC[tid] = r[2];
             const uint32_t dy_ = __float_as_uint(d4.y);
-            // first row of the Gaussian (compact array, L2-resident) + rank of this tile among the tiles it is emitted for
-            sU[tid] = sgr_row_of(dy_, tx, ty, u0, tmask, g);
+            // first row of the Gaussian (compact array, L2-resident) + rank of this tile among the tiles it is emitted for:
+            // rides in the spare word of the slot's position record (written and read back by this thread only)
+            sA[tid] = make_float4(a.x, a.y, __uint_as_float(sgr_row_of(dy_, tx, ty, u0, tmask, g)), 0.0f);
             if (SMAX > 0) {
 #pragma unroll
                 for (int ch = 0; ch < SMAX; ch++) sSem[tid * SMAX + ch] = ch < S ? semantics[(size_t)g * S + ch] : 0.0f;
@@ -301,8 +362,52 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
         }
         sgr_lds_barrier();
 
+        // VROWS: the survivor masks of all four quadrants (wave-uniform: scalar registers), how many slots of this round are
+        // walked (`lim`: all of them unless the masks hold more visits than there are rows) and the first row of every quadrant
+        int lim = BATCH;
+        uint64_t vm[4][NCH];
+        int vfirst[4] = {0, 0, 0, 0};
+        if constexpr (VROWS) {
+            auto below = [](const uint64_t m, const int nb) { return nb >= 64 ? m : (nb <= 0 ? 0ull : (m & ((1ull << nb) - 1ull))); };
+            uint64_t raw[4][NCH];
+            int total = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int c = 0; c < NCH; c++) {
+                    raw[q][c] = sgr_uniform_u64(sBits[q][c]);
+                    total += sgr_popc64(raw[q][c]);
+                }
+            if (total > CAP) {  // rare: shrink the round to the largest multiple of 32 slots whose visits fit the rows
+                for (lim = BATCH - 32; lim > 32; lim -= 32) {
+                    int t = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+#pragma unroll
+                        for (int c = 0; c < NCH; c++) t += sgr_popc64(below(raw[q][c], lim - 64 * c));
+                    if (t <= CAP) break;
+                }
+            }
+            int first = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                vfirst[q] = first;
+#pragma unroll
+                for (int c = 0; c < NCH; c++) {
+                    vm[q][c] = below(raw[q][c], lim - 64 * c);
+                    first += sgr_popc64(vm[q][c]);
+                }
+            }
+        }
+        int rown = 0;  // VROWS: the row of this wave's next visit
+        if constexpr (VROWS) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) rown = (wave_s == q) ? vfirst[q] : rown;
+        }
+
+        // `rowi`: the visit's LDS row (VROWS; wave-uniform), else unused
         auto process = [&](const int j, const float4 q, const float dx, const float dy, const float power2, const float G,
-                           const float alpha, const bool valid) __attribute__((always_inline)) {
+                           const float alpha, const int rowi) __attribute__((always_inline)) {
                 const int posj = hi - j;  // 0-based list position == `contributor` after its decrement
                 // backward.cu:527-545
                 // (pixels outside the image have lastc = 0).  The wave-wide "any hit" is taken from the three compare
@@ -310,7 +415,19 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                 const bool k0 = posj < lastc, k1 = !(power2 > 0.0f), k2 = !(alpha < SGR_ALPHA_MIN);
                 const uint64_t hm = __builtin_amdgcn_ballot_w64(k0) & __builtin_amdgcn_ballot_w64(k1) &
                                     __builtin_amdgcn_ballot_w64(k2);
-                if (!valid || hm == 0) return;
+                if (hm == 0) {
+                    // no pixel takes part (every passing pixel of the forward finished on this instance): the visit's row is
+                    // read by the flush all the same -- zeros
+                    if constexpr (VROWS) {
+                        if (fold_leader) {
+                            float* dst = sAcc + (acc_fold_off + rowi * ACCW);
+#pragma unroll
+                            for (int c0 = 0; c0 < NVAL; c0 += 16)
+                                if (fold_t0 < (NVAL - c0 < 16 ? NVAL - c0 : 16) / 4) dst[c0] = 0.0f;
+                        }
+                    }
+                    return;
+                }
                 const bool hit = k0 && k1 && k2;
 
                 const float4 c = sC[j];
@@ -419,11 +536,78 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                 // LDS row layout: float4 t = values (4t, 4t+2, 4t+1, 4t+3) -- the order the reduce-scatter leaves
                 // them in rows 0..3 of register t; the flush below swaps the middle pair back.
                 float r[NVAL / 4];
+                if constexpr (SPK > 0) {
+                    const int kc = sgr_popc64(hm);
+                    if (SGR_SPARSE_MODE == 2 && kc <= SPK) {
+                        if (hit) {  // every hit lane adds into the wave's entry (laid out like a row: float4 t = values 4t, 4t+2, 4t+1, 4t+3)
+                            const uint32_t ea = sgr_lds_addr(sAcc + stage_off);
+#define SGR_STAGE_ADD(OFF, VAL) asm volatile("ds_add_f32 %0, %1 offset:" #OFF : : "v"(ea), "v"(VAL) : "memory")
+                            SGR_STAGE_ADD(0, v[0]); SGR_STAGE_ADD(4, v[2]); SGR_STAGE_ADD(8, v[1]); SGR_STAGE_ADD(12, v[3]);
+                            SGR_STAGE_ADD(16, v[4]); SGR_STAGE_ADD(20, v[6]); SGR_STAGE_ADD(24, v[5]); SGR_STAGE_ADD(28, v[7]);
+                            SGR_STAGE_ADD(32, v[8]); SGR_STAGE_ADD(36, v[10]); SGR_STAGE_ADD(40, v[9]);
+#undef SGR_STAGE_ADD
+                        }
+                        __builtin_amdgcn_wave_barrier();  // same wave, program order: the LDS serves the read below after the adds above
+                        if (fold_leader && fold_t0 < NVAL / 4) {
+                            float* src = sAcc + (acc_fold_off + stage_rel);
+                            const float t = *src;
+                            *src = 0.0f;  // behind the read in the LDS queue
+                            if constexpr (VROWS) sAcc[acc_fold_off + rowi * ACCW] = t;
+                            else atomicAdd(sAcc + (acc_fold_off + j * ACCW), t);
+                            asm volatile("; sparse visit done" ::: "memory");
+                        }
+                        return;
+                    }
+                    if (SGR_SPARSE_MODE != 2 && kc <= SPK) {
+                        if (hit) {  // entry = rank among the hit lanes; an entry is laid out like a row (float4 t = values 4t, 4t+2, 4t+1, 4t+3)
+                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+                            // 32-bit stores written as ds_write_b32 (the optimiser merges plain stores into ds_write_b128, which
+                            // wants its four values in consecutive registers: the copies that takes landed in the dense path too)
+                            const uint32_t ea = sgr_lds_addr(sAcc + stage_off) + rank * 48u;
+#define SGR_STAGE_ST(OFF, VAL) asm volatile("ds_write_b32 %0, %1 offset:" #OFF : : "v"(ea), "v"(VAL) : "memory")
+                            SGR_STAGE_ST(0, v[0]); SGR_STAGE_ST(4, v[2]); SGR_STAGE_ST(8, v[1]); SGR_STAGE_ST(12, v[3]);
+                            SGR_STAGE_ST(16, v[4]); SGR_STAGE_ST(20, v[6]); SGR_STAGE_ST(24, v[5]); SGR_STAGE_ST(28, v[7]);
+                            SGR_STAGE_ST(32, v[8]); SGR_STAGE_ST(36, v[10]); SGR_STAGE_ST(40, v[9]);  // word 11: zero since the prologue
+#undef SGR_STAGE_ST
+                        }
+                        __builtin_amdgcn_wave_barrier();  // same wave, program order: the LDS serves the reads below after the writes above
+                        if (fold_leader && fold_t0 < NVAL / 4) {
+                            const float* src = sAcc + (acc_fold_off + stage_rel);
+                            // kc is wave-uniform: one case, all its loads in flight at once, adds in rank order
+                            auto sum_first = [&](auto KC) __attribute__((always_inline)) {
+                                constexpr int kk = decltype(KC)::value;
+                                float a[kk];
+#pragma unroll
+                                for (int e = 0; e < kk; e++) a[e] = src[e * 12];
+                                float t = a[0];
+#pragma unroll
+                                for (int e = 1; e < kk; e++) t += a[e];
+                                return t;
+                            };
+                            float t = 0.0f;
+                            switch (kc) {
+#define SGR_SPARSE_CASE(N) case N: if constexpr (N <= SPK) t = sum_first(std::integral_constant<int, (N <= SPK ? N : 1)>{}); break
+                                SGR_SPARSE_CASE(1); SGR_SPARSE_CASE(2); SGR_SPARSE_CASE(3); SGR_SPARSE_CASE(4);
+                                SGR_SPARSE_CASE(5); SGR_SPARSE_CASE(6); SGR_SPARSE_CASE(7); SGR_SPARSE_CASE(8);
+                                SGR_SPARSE_CASE(9); SGR_SPARSE_CASE(10); SGR_SPARSE_CASE(11); SGR_SPARSE_CASE(12);
+#undef SGR_SPARSE_CASE
+                                default: break;
+                            }
+                            static_assert(SGR_SPARSE_MODE == 2 || SPK <= 12, "add sparse cases");
+                            if constexpr (VROWS) sAcc[acc_fold_off + rowi * ACCW] = t;
+                            else atomicAdd(sAcc + (acc_fold_off + j * ACCW), t);
+                            // keeps the optimiser from merging this ds_add_f32 with the dense path's: the merged tail made the
+                            // twelve values live across this block (and the loads above serialise for want of registers)
+                            asm volatile("; sparse visit done" ::: "memory");
+                        }
+                        return;
+                    }
+                }
                 if (DPP && SGR_FOLD) {
                     // 16 values at a time (one result register, one ds_add_f32 each): the same instructions as one
                     // pass over all NVAL values, but the channel products w * dL/dsemantic are formed chunk by chunk,
                     // so a wide instantiation keeps 16 + 8 instead of NVAL + NVAL/2 reduction registers live
-                    float* dst = sAcc + (acc_fold_off + j * ACCW);  // j is wave-uniform: scalar multiply
+                    float* dst = sAcc + (acc_fold_off + (VROWS ? rowi : j) * ACCW);  // wave-uniform: scalar multiply
                     auto fold_chunk = [&](auto C0, auto CN) __attribute__((always_inline)) {
                         constexpr int c0 = decltype(C0)::value, cn = decltype(CN)::value;
                         float vv[cn], g[1];
@@ -434,7 +618,10 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                                                        : (idx - SGR_ROW_BASE < SMAX ? wm * dLdS[(idx - SGR_ROW_BASE) % NS] : 0.0f);
                         }
                         sgr_wave_reduce_fold<cn>(vv, g);
-                        if (fold_leader && fold_t0 < cn / 4) atomicAdd(&dst[c0], g[0]);
+                        if (fold_leader && fold_t0 < cn / 4) {
+                            if constexpr (VROWS) dst[c0] = g[0];  // the visit's own row: one writer
+                            else atomicAdd(&dst[c0], g[0]);
+                        }
                     };
                     fold_chunk(std::integral_constant<int, 0>{}, std::integral_constant<int, (NVAL < 16 ? NVAL : 16)>{});
                     if constexpr (NVAL > 16)
@@ -463,8 +650,15 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                 }
         };
         for (int chunk = 0; chunk < BATCH / 64; chunk++) {
-            uint64_t m = sBits[wave][chunk];
-            m = sgr_uniform_u64(m);
+            uint64_t m;
+            if constexpr (VROWS) {  // this wave's (limited) survivor mask of the chunk, picked with scalar selects
+                m = vm[0][chunk];
+#pragma unroll
+                for (int q = 1; q < 4; q++) m = (wave_s == q) ? vm[q][chunk] : m;
+            } else {
+                m = sBits[wave][chunk];
+                m = sgr_uniform_u64(m);
+            }
             // scalar bookkeeping kept short (SALU issues once per four cycles per SIMD): s_ff1 + s_bitset0 per survivor, and
             // the odd survivor is taken first so that the loop is pairs only
             if (__builtin_popcountll(m) & 1) {
@@ -473,7 +667,8 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                 const float dx0 = a0.x - pxf, dy0 = a0.y - pyf;
                 const float pw0 = EXACT ? sgr_power_ref_staged(q0.x, q0.y, q0.z, dx0, dy0) : sgr_power2(q0.x, q0.y, q0.z, dx0, dy0);
                 const float G0 = EXACT ? (SGR_EXACT_TRIM ? sgr_expf_ref(pw0) : expf(pw0)) : __builtin_amdgcn_exp2f(pw0);
-                process(j0, q0, dx0, dy0, pw0, G0, fminf(0.99f, q0.w * G0), true);
+                process(j0, q0, dx0, dy0, pw0, G0, fminf(0.99f, q0.w * G0), rown);
+                rown++;
             }
             while (m) {
                 // two survivors per trip: LDS reads and exp() of both are independent of each other; only the
@@ -487,8 +682,9 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                 const float pw1 = EXACT ? sgr_power_ref_staged(q1.x, q1.y, q1.z, dx1, dy1) : sgr_power2(q1.x, q1.y, q1.z, dx1, dy1);
                 const float G0 = EXACT ? (SGR_EXACT_TRIM ? sgr_expf_ref(pw0) : expf(pw0)) : __builtin_amdgcn_exp2f(pw0), G1 = EXACT ? (SGR_EXACT_TRIM ? sgr_expf_ref(pw1) : expf(pw1)) : __builtin_amdgcn_exp2f(pw1);
                 const float al0 = fminf(0.99f, q0.w * G0), al1 = fminf(0.99f, q1.w * G1);
-                process(j0, q0, dx0, dy0, pw0, G0, al0, true);
-                process(j1, q1, dx1, dy1, pw1, G1, al1, true);
+                process(j0, q0, dx0, dy0, pw0, G0, al0, rown);
+                process(j1, q1, dx1, dy1, pw1, G1, al1, rown + 1);
+                rown += 2;
             }
         }
         sgr_lds_barrier();
@@ -496,14 +692,35 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
         // forward's hit record that is the set of instances that blended into the tile (plus the rare one whose every
         // passing pixel finished on it: a row of zeros); flagging rows per visit instead cost an LDS store + exec
         // juggling in the walk.
-        if (mask4 != 0) {
-            const uint32_t u = sU[tid];
+        if (mask4 != 0 && tid < lim) {
+            const uint32_t u = __float_as_uint(sA[tid].z);
             touched[u] = 1;  // the per-Gaussian reduction only reads rows that were written (no 64 B/instance memset)
             float4* row = reinterpret_cast<float4*>(partials + (size_t)u * row_stride);
             float4 r[NVAL / 4];
 #pragma unroll
             for (int k4 = 0; k4 < NVAL / 4; k4++) r[k4] = make_float4(0.f, 0.f, 0.f, 0.f);
-            {
+            if constexpr (VROWS) {
+                // the rows of this slot's visits, in quadrant order: row of quadrant q = the quadrant's first row + the rank of
+                // the slot among the set bits of its survivor masks (whole chunks before this wave's: scalar; inside: v_mbcnt)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    int before = vfirst[q];
+#pragma unroll
+                    for (int c = 0; c + 1 < NCH; c++) before += (c < wave_s) ? sgr_popc64(vm[q][c]) : 0;
+                    uint64_t mine = vm[q][0];
+#pragma unroll
+                    for (int c = 1; c < NCH; c++) mine = (wave_s == c) ? vm[q][c] : mine;
+                    if ((mask4 >> q) & 1u) {
+                        const int rq = before + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+                        const float4* src = reinterpret_cast<const float4*>(&sAcc[rq * ACCW]);
+#pragma unroll
+                        for (int k4 = 0; k4 < NVAL / 4; k4++) {
+                            const float4 t = src[k4];
+                            r[k4].x += t.x; r[k4].y += t.y; r[k4].z += t.z; r[k4].w += t.w;
+                        }
+                    }
+                }
+            } else {
                 const float4* src = reinterpret_cast<const float4*>(&sAcc[tid * ACCW]);
 #pragma unroll
                 for (int k4 = 0; k4 < NVAL / 4; k4++) r[k4] = src[k4];
@@ -529,6 +746,15 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
             }
 #pragma unroll
             for (int k4 = 0; k4 < NVAL / 4; k4++) row[k4] = make_float4(r[k4].x, r[k4].z, r[k4].y, r[k4].w);
+        }
+        // next round: the slots this one did not walk (VROWS with more visits than rows) are staged again
+        hi -= lim;
+        if (SGR_BWD_PREFETCH && lim != BATCH) {  // rare: the entries fetched ahead were those of hi - BATCH
+            const int posn = stager ? hi - tid : -1;
+            if (posn >= 0) {
+                g_pre = point_list[range.x + (uint32_t)posn];
+                if (CULL && hit4 != nullptr) h_pre = hit4[range.x + (uint32_t)posn];
+            }
         }
     }
 }

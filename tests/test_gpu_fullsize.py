@@ -212,7 +212,8 @@ def test_threeway_against_reference_kernels_at_baseline_size(name, P, S):
     del gref_b
     ref_img = {k: npy(getattr(rf, k)) for k in ["color", "depth", "alpha", "semantic"]}
     ref_int = dict(R=rf.num_rendered, radii=npy(rf.radii), point_list=npy(rf.internal("point_list")).view(np.uint32),
-                   keys=npy(rf.internal("keys")).view(np.uint64), ranges=npy(rf.internal("ranges")).view(np.uint32))
+                   keys=npy(rf.internal("keys")).view(np.uint64), ranges=npy(rf.internal("ranges")).view(np.uint32),
+                   n_contrib=npy(rf.internal("n_contrib")).view(np.uint32).reshape(-1))
     gref = {k: npy(v) for k, v in gref.items()}
     rf.free()
     torch.cuda.empty_cache()
@@ -234,12 +235,12 @@ def test_threeway_against_reference_kernels_at_baseline_size(name, P, S):
             ref.use("strict")
         torch.cuda.empty_cache()
 
+    from gpu_utils import switches
+    from street_gaussians_amd import _C
     fw = oracle.forward(**kw)
     gor = oracle.backward(fw, wts["color"], wts["depth"], wts["alpha"], gsem, parallel="exact")
     # the HIP path in its parity mode (sgr_math.h sgr_power_ref: the reference's power expression, accurate expf, true
     # division): the forward must then reproduce the strict build's alpha image bit for bit
-    from gpu_utils import switches
-    from street_gaussians_amd import _C
     with switches(_C.EXACT):
         res_x, _ = raw_forward(kw)
         g_x = raw_backward(kw, res_x, wts)
@@ -247,6 +248,31 @@ def test_threeway_against_reference_kernels_at_baseline_size(name, P, S):
         img_x = {k: npy(res_x[k]) for k in ["color", "depth", "alpha", "semantic"]}
         g_x = {k: npy(v) for k, v in g_x.items()}
         del res_x
+    # The STRICTLY conforming configuration (parity arithmetic + the reference's tile rects, sgr_test_switches bits 7 + 10):
+    # every binning array is the reference kernels' ENTRY FOR ENTRY at this BASELINE size -- no restriction to the emitted
+    # tiles (rasterizer_impl.cu:70-138, auxiliary.h:46-57) -- and n_contrib / alpha / depth are bit-identical.  The default
+    # arithmetic with the reference's rects (bit 10 alone) must produce the same lists as well (n_contrib may differ by the
+    # alpha-threshold flips of v_exp_f32, counted below).
+    strict = {}
+    for label, mask in (("strict", _C.EXACT | _C.REF_RECT), ("ref_rect", _C.REF_RECT)):
+        with switches(mask):
+            res_s, int_s = raw_forward(kw)
+            torch.cuda.synchronize()
+            assert res_s["R"] == ref_int["R"] == int(int_s("num_rendered_reference")[0]), (label, res_s["R"], ref_int["R"])
+            assert np.array_equal(npy(res_s["radii"]), ref_int["radii"]), label
+            assert np.array_equal(npy(int_s("point_list")).view(np.uint32).reshape(-1), ref_int["point_list"].reshape(-1)), label
+            assert np.array_equal(npy(int_s("keys")).view(np.uint64).reshape(-1), ref_int["keys"].reshape(-1)), label
+            assert np.array_equal(npy(int_s("ranges")).view(np.uint32).reshape(-1), ref_int["ranges"].reshape(-1)), label
+            nc_s = npy(int_s("n_contrib")).view(np.uint32).reshape(-1)
+            strict[label] = {"R": int(res_s["R"]), "n_contrib_differs": int((nc_s != ref_int["n_contrib"]).sum())}
+            if label == "strict":
+                assert strict[label]["n_contrib_differs"] == 0, strict
+                for k in ["alpha", "depth"] + (["semantic"] if S else []):
+                    assert np.array_equal(npy(res_s[k]).reshape(-1), ref_img[k].reshape(-1)), (label, k)
+            else:
+                assert strict[label]["n_contrib_differs"] <= 1e-4 * nc_s.size, strict
+            del res_s, int_s, nc_s
+        torch.cuda.empty_cache()
     res, internal = raw_forward(kw)
     g = raw_backward(kw, res, wts)
     torch.cuda.synchronize()
@@ -262,7 +288,7 @@ def test_threeway_against_reference_kernels_at_baseline_size(name, P, S):
     assert (ref_int["ranges"].reshape(-1) == fw.ranges.reshape(-1)).all()
     assert (npy(internal("ranges")).view(np.uint32).reshape(-1) == b.ranges.reshape(-1)).all()
 
-    rec = dict(P=P, S=S, R=int(fw.num_rendered), R_emitted=b.num_rendered, images={}, grads={})
+    rec = dict(P=P, S=S, R=int(fw.num_rendered), R_emitted=b.num_rendered, images={}, grads={}, entry_for_entry=strict)
     del b
     if gfmad is not None:
         rec["fmad_build_integers"] = fmad_int
@@ -327,3 +353,58 @@ def test_threeway_against_reference_kernels_at_baseline_size(name, P, S):
         assert st["hip_vs_ref"]["outside"] <= allow, (k, st)
         worst = max(st["oracle_vs_ref"]["worst_abs_over_scale"], st.get("fmad_vs_ref", {"worst_abs_over_scale": 0})["worst_abs_over_scale"])
         assert st["hip_vs_ref"]["worst_abs_over_scale"] <= max(GRAD_CAP, 1.5 * worst), (k, st)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The cut itself, checked INDEPENDENTLY of the HIP path's own export (tests/gpu_utils.restrict_binning takes the rects and
+# masks the library reports): from the C oracle's conic_opacity / means2D and ITS (tile, Gaussian) list -- the reference's
+# instances, auxiliary.h:46-57 -- recompute with plain torch tensor ops, pixel by pixel, which instances have ANY pixel of
+# their tile with power <= 0 and alpha = min(0.99, opacity * exp(power)) >= 1/255 (forward.cu:420-430: the only instances
+# that can change an output), and require every one of them to be in the list the library emits by default.  The converse
+# (how many emitted instances can never blend) is reported: the tightness of the cut.
+@pytest.mark.parametrize("name,P,S", [("headline_1M", 1_000_000, 0)])
+def test_every_instance_that_can_blend_is_emitted(name, P, S):
+    cam = syn.make_camera(1920, 1280, fx=2050.0)
+    sc = syn.make_scene(P, cam, S=S, seed=0)
+    kw = oracle_kwargs(cam, sc, bg=torch.tensor([0.1, 0.2, 0.3]))
+    H, W = cam.image_height, cam.image_width
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    fw = oracle.forward(**kw)
+    dev = torch.device("cuda")
+    pl = torch.from_numpy(fw.point_list.astype(np.int64)).to(dev)
+    rg = torch.from_numpy(fw.ranges.astype(np.int64).reshape(-1, 2)).to(dev)
+    tile = torch.repeat_interleave(torch.arange(gx * gy, device=dev), rg[:, 1] - rg[:, 0])
+    assert tile.numel() == pl.numel() == fw.num_rendered
+    con = torch.from_numpy(np.ascontiguousarray(fw.conic_opacity, np.float32)).to(dev)
+    m2d = torch.from_numpy(np.ascontiguousarray(fw.means2D, np.float32)).to(dev)
+    oy, ox = torch.meshgrid(torch.arange(16, device=dev), torch.arange(16, device=dev), indexing="ij")
+    ox, oy = ox.reshape(1, -1).float(), oy.reshape(1, -1).float()
+    can = torch.zeros(pl.numel(), dtype=torch.bool, device=dev)
+    CH = 400_000
+    for a in range(0, pl.numel(), CH):
+        g_, t_ = pl[a:a + CH], tile[a:a + CH]
+        px = ((t_ % gx) * 16).float().unsqueeze(1) + ox
+        py = ((t_ // gx) * 16).float().unsqueeze(1) + oy
+        inside = (px < W) & (py < H)
+        c = con[g_]
+        dx = m2d[g_, 0:1] - px
+        dy = m2d[g_, 1:2] - py
+        power = -0.5 * (c[:, 0:1] * dx * dx + c[:, 2:3] * dy * dy) - c[:, 1:2] * dx * dy  # forward.cu:420
+        alpha = torch.clamp(c[:, 3:4] * torch.exp(power), max=0.99)
+        can[a:a + CH] = (inside & (power <= 0) & (alpha >= 1.0 / 255.0)).any(dim=1)
+    need = (tile * P + pl)[can]
+    res, internal = raw_forward(kw)  # default mode: the cut-down rects with their tile masks
+    e_pl = internal("point_list").view(torch.int32).to(torch.int64).reshape(-1)
+    e_rg = internal("ranges").view(torch.int32).to(torch.int64).reshape(-1, 2)
+    e_tile = torch.repeat_interleave(torch.arange(gx * gy, device=dev), e_rg[:, 1] - e_rg[:, 0])
+    assert e_tile.numel() == e_pl.numel() == res["R"]
+    emitted = torch.sort(e_tile * P + e_pl).values
+    pos = torch.searchsorted(emitted, need).clamp(max=emitted.numel() - 1)
+    missing = int((emitted[pos] != need).sum())
+    rec = dict(reference_instances=int(pl.numel()), can_blend=int(can.sum()), emitted=int(emitted.numel()), missing=missing,
+               emitted_that_cannot_blend=int(emitted.numel() - can.sum()) + missing)
+    _save("cut_" + name, rec)
+    print(json.dumps({"cut_" + name: rec}))
+    assert missing == 0, rec
+    assert emitted.numel() <= pl.numel()
+    fw.free()

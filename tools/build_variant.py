@@ -3,6 +3,9 @@
 street_gaussians_amd/variants/libsgr_hip_<name>.so; select it with SGR_LIB=<path> SGR_BINDING=ctypes.
 
     python tools/build_variant.py <name> <flags...>        e.g.  python tools/build_variant.py nopf -DSGR_BWD_PREFETCH=0
+    python tools/build_variant.py <name> --only=sgr_blend_bwd.hip[,more.hip] <flags...>
+        recompiles only the named sources with the flags and links them with the SHIPPED build's other objects
+        (a switch that lives in one file: seconds instead of minutes; run street_gaussians_amd.build first)
 """
 import os
 import subprocess
@@ -14,6 +17,11 @@ sys.path.insert(0, ROOT)
 from street_gaussians_amd import build as b  # noqa: E402
 
 name, flags = sys.argv[1], sys.argv[2:]
+only = None
+for f in list(flags):
+    if f.startswith("--only="):
+        only = f.split("=", 1)[1].split(",")
+        flags.remove(f)
 out_dir = os.path.join(b.HERE, "variants")
 obj_dir = os.path.join(b.OBJ, "variant_" + name)
 os.makedirs(out_dir, exist_ok=True)
@@ -21,6 +29,10 @@ os.makedirs(obj_dir, exist_ok=True)
 
 
 def one(src):
+    if only is not None and src not in only:
+        o = os.path.join(b.OBJ, src.replace(".hip", ".o"))  # the shipped build's object
+        assert os.path.exists(o), f"{o}: build the shipped library first"
+        return o
     o = os.path.join(obj_dir, src.replace(".hip", ".o"))
     subprocess.check_call(["/opt/rocm/bin/hipcc"] + b.flags_for(src) + flags + ["-c", os.path.join(b.CSRC, src), "-o", o])
     return o

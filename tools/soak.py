@@ -18,9 +18,12 @@ from helpers import oracle_kwargs  # noqa: E402
 from street_gaussians_amd import synthetic as syn  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+only = [int(x) for x in os.environ["SOAK_CONFIGS"].split(",")] if os.environ.get("SOAK_CONFIGS") else None  # indices into the list below
 cam = syn.make_camera(1920, 1280, fx=2050.0)
 bad = 0
-for P, S in [(1_000_000, 0), (400_000, 19), (300_000, 3), (300_000, 8), (300_000, 12), (300_000, 16), (200_000, 24), (200_000, 32)]:
+for ci, (P, S) in enumerate([(1_000_000, 0), (400_000, 19), (300_000, 3), (300_000, 8), (300_000, 12), (300_000, 16), (200_000, 24), (200_000, 32)]):
+    if only is not None and ci not in only:
+        continue
     sc = syn.make_scene(P, cam, S=S, seed=3)
     kw = oracle_kwargs(cam, sc)
     wts = syn.loss_weights(cam, S=S)
