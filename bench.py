@@ -553,13 +553,21 @@ def profiled_steps(L, wl, fence, steps, stage_mask, every=1):
     L.sgr_profile_select(stage_mask)
     L.sgr_profile_sample(every)
     L.sgr_profile_enable(1)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if os.environ.get("SGR_BENCH_REGION_TRACE") else None
     fence()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for i in range(steps):
+        if marks:
+            marks[i].record()
         wl.step()
     wl.drain()  # the last step's exchange belongs to the timed region
+    if marks:
+        marks[steps].record()
     fence()
     dt = time.perf_counter() - t0
+    if marks:  # debug: where a short region loses time (GPU time between the starts of consecutive steps)
+        print("[region-trace]", steps, round(1e3 * dt, 3), [round(marks[i].elapsed_time(marks[i + 1]), 3) for i in range(steps)][:40],
+              file=sys.stderr)
     sums = (C.c_double * 9)()
     counts = (C.c_int * 9)()
     L.sgr_profile_read(sums, counts)

@@ -110,7 +110,8 @@ typedef struct sgr_backward_extras {
     int rows; /* length of the three persistent arrays (rows); with segments every [dst_offset, dst_offset + count) must lie
                * inside [0, rows) and the destination ranges must be pairwise disjoint (two segments on the same rows would be
                * a racy read-modify-write) -- checked on the host, SGR_E_INVALID otherwise.  0 = unknown: not checked. */
-} sgr_backward_extras;
+} sgr_backward_extras; /* layout of sgr_version() >= 101 (100 ended at n_segments: a caller built against that header must
+                        * not be run against this library -- check sgr_version() before passing the struct) */
 int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, int width, int height,
                     const float* means3D, const float* shs, const float* colors_precomp, const float* semantics,
                     const float* alphas, const float* scales, float scale_modifier, const float* rotations,

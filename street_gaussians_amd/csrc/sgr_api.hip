@@ -24,7 +24,7 @@ void sgr_launch_preprocess(int P, int D, int M, const float* means3D, const floa
 void sgr_launch_filter(int P, const float* means3D, const float* scales, const float* rotations,
                        const float* cov3D_precomp, const SgrCamArgs& ca, const SgrGeomView& gv, int* radii,
                        float* means2D, int prefiltered, hipStream_t s);
-void sgr_launch_duplicate(int P, const SgrGeomView& gv, const uint32_t* order, const uint32_t* offs_incl, uint32_t* keys,
+void sgr_launch_duplicate(int P, const SgrGeomView& gv, const uint32_t* order, const uint32_t* bsum, const uint32_t* sub, uint32_t* keys,
                           uint32_t* vals, int gx, hipStream_t s);
 void sgr_launch_tile_ranges(int L, const uint32_t* keys, uint2* ranges, uint8_t* touched, hipStream_t s);
 void sgr_launch_compose_keys(int L, const uint32_t* tile_keys, const uint32_t* point_list, const float4* rec, uint64_t* out,
@@ -38,7 +38,7 @@ void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, bool v2, bool exact, in
                           int H, int S, const float* bg, const float4* rec, const uint32_t* u0, const uint64_t* tmask, const float* semantics, const float* alphas,
                           const uint32_t* n_contrib, const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth,
                           const float* dL_dalpha, const float* dL_dsem, float* partials, uint8_t* touched, hipStream_t s);
-void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const int* radii, const float* shs,
+int sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const int* radii, const float* shs,
                           const float* scales, const float* rotations, const float* cov3D_precomp, const SgrCam* cam,
                           const SgrGeomView& gv, const float* partials, int row_stride, const uint8_t* touched,
                           float4* cd, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
@@ -50,7 +50,7 @@ void sgr_launch_blend_bwd_sw(bool exact, int gx, int gy, const uint2* ranges, co
                              const uint32_t* n_contrib, const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth,
                              const float* dL_dalpha, float* partials, int row_stride, uint8_t* touched, hipStream_t s);
 // the same compiled with FP contraction off (sgr_gauss_bwd_strict.hip): parity mode
-void sgr_launch_gauss_bwd_strict(int P, int D, int M, int S, const float* means3D, const int* radii, const float* shs,
+int sgr_launch_gauss_bwd_strict(int P, int D, int M, int S, const float* means3D, const int* radii, const float* shs,
                                  const float* scales, const float* rotations, const float* cov3D_precomp, const SgrCam* cam,
                                  const SgrGeomView& gv, const float* partials, int row_stride, const uint8_t* touched,
                                  float4* cd, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
@@ -280,7 +280,7 @@ SgrFlagBlock sgr_acquire_flag_block() {
 extern "C" {
 
 const char* sgr_last_error(void) { return g_err.c_str(); }
-int sgr_version(void) { return 100; }
+int sgr_version(void) { return 101; }  // 101: sgr_backward_extras gained color_ready_event + rows, sgr_test_sort32 max_bits
 
 size_t sgr_geometry_bytes(int P) {
     return sgr_required([&](char* b, char** e) { sgr_geom_carve(b, (size_t)P, e); });
@@ -399,8 +399,10 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
         order = gv.dvals[dcur];
         // (second sequence of the same launches: the exclusive scan in index order = every Gaussian's first partial-gradient
         // row of the backward, SgrGeomView::u0)
-        sgr_launch_scan(reinterpret_cast<const uint32_t*>(gv.aux_sorted), gv.tt_sorted, (size_t)P, gv.scan_tmp, true, stream,
-                        nullptr, nullptr, 2, reinterpret_cast<const uint32_t*>(gv.aux), gv.u0);
+        // (the scan's last step -- offsets of the individual Gaussians -- is done by the duplicate kernel, which needs them:
+        // round 4 ran a third launch that wrote them to an array)
+        sgr_launch_scan_head(reinterpret_cast<const uint32_t*>(gv.aux_sorted), reinterpret_cast<const uint32_t*>(gv.aux), (size_t)P,
+                             2, gv.scan_tmp, gv.sub_sums, stream);
         SGR_STAGE("depth_sort+scan");
         prof_end(stream);
         // The window between "R is known" and "the GPU runs out of queued work" is only the ~0.12 ms of sort + scan
@@ -434,7 +436,9 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     }
     if (host_vals[0] & 1u)
         return fail(SGR_E_PREFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
-    if (host_vals[4] > 0x7fffffffu || host_vals[5] > 0x7fffffffu) return fail(SGR_E_INVALID, "more than 2^31 tile instances");
+    // (host_vals[5], what num_rendered would be with the reference's rects, is reporting only -- export 17, best effort: it
+    // shares a 64-bit atomic with the emitted count and is not a reason to refuse a frame whose emitted list fits)
+    if (host_vals[4] > 0x7fffffffu) return fail(SGR_E_INVALID, "more than 2^31 tile instances");
     const int R = (int)host_vals[4];
 
     if (!bbase || sgr_binning_bytes(R) > have_bytes) {
@@ -446,11 +450,12 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     const SgrBinView bv = sgr_bin_carve(bbase, (size_t)R);
 
     int cur = 0;
+    // (also with R == 0: the kernel finishes the index-order scan, SgrGeomView::u0, which the exports read)
+    prof_begin(2, stream);
+    sgr_launch_duplicate(P, gv, order, gv.scan_tmp, gv.sub_sums, bv.keys[0], bv.vals[0], gx, stream);
+    SGR_STAGE("duplicate");
+    prof_end(stream);
     if (R > 0) {
-        prof_begin(2, stream);
-        sgr_launch_duplicate(P, gv, order, gv.tt_sorted, bv.keys[0], bv.vals[0], gx, stream);
-        SGR_STAGE("duplicate");
-        prof_end(stream);
         prof_begin(3, stream);
         const int bit = (int)getHigherMsb((uint32_t)T);  // rasterizer_impl.cu:303
         cur = sgr_launch_sort_pairs32(bv.keys, bv.vals, (uint32_t)R, bit, bv.hist, bv.scan_tmp, stream);
@@ -607,12 +612,13 @@ int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, 
         prof_end(stream);
     }
     prof_begin(8, stream);
-    ((switches() & 128) ? sgr_launch_gauss_bwd_strict : sgr_launch_gauss_bwd)(
+    const int ev_failed = ((switches() & 128) ? sgr_launch_gauss_bwd_strict : sgr_launch_gauss_bwd)(
         P, D, M, S, means3D, radii_ptr, shs, scales, rotations, cov3D_precomp, cam_slot(gv), gv, partials, stride, touched, cd,
         dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, dL_dsemantic, sink, quad ? 1 : 0,
         (switches() & 128) ? 1 : 0, W, H, extras ? (hipEvent_t)extras->color_ready_event : nullptr, (switches() & 512) ? 1 : 0, stream);
     SGR_STAGE("gauss_bwd");
     prof_end(stream);
+    if (ev_failed) return fail(SGR_E_HIP, "hipEventRecord(color_ready_event) failed: is it a valid event of this device?");
     if (touched && ((switches() & (1 | 8)) != 0 || quad)) SGR_HIP(hipMemsetAsync(touched, 0, (size_t)R, stream));
     return 0;
 }

@@ -72,22 +72,22 @@ struct SgrBwdBatch { static constexpr int value = SMAX <= 8 ? SGR_BWD_BATCH : SG
 #define SGR_VROWS 1
 #endif
 // SPARSE visits (round 5).  The reduce-scatter costs the same 9 permlane swaps + 7 DPP adds however few of the wave's 64
-// pixels hit, and on the benchmark frame 27 % of the visits have at most 8 hitting lanes (tools/lane_hist.py).  A visit with
-// at most SGR_SPARSE_K hitting lanes skips the cross-lane reduction: the hit lanes file their 12 values in a per-wave LDS
-// stage (entry = rank of the lane among the hit lanes: three ds_write_b128 under the hit lanes' EXEC), the twelve lanes
-// that own the row positions read the entries back and add them in rank order (one ds_read_b32 per entry, k - 1 plain
-// adds), then add the sum to the slot's row exactly like the dense path does -- still ONE contribution per wave and
-// instance, so the two-row combine stays bit-reproducible.  LDS operations of one wave execute in order: no wait between
-// the writes and the reads.  0 disables the path (A/B: tools/build_variant.py).  S = 0 instantiations only.
+// pixels hit, and on the benchmark frame 27 % of the visits have at most 8 hitting lanes, 41 % at most 16
+// (tools/lane_hist.py).  A visit with few hitting lanes skips the cross-lane reduction: the hit lanes file their 12 values
+// in an LDS stage (entry = rank of the lane among the hit lanes: twelve ds_write_b32 under the hit lanes' EXEC), the twelve
+// lanes that own the row positions read the entries back and add them in rank order (k - 1 plain adds), then store the sum
+// into the visit's row exactly like the dense path does.  LDS operations of one wave execute in order: no wait between the
+// writes and the reads.  The stage is SGR_SPARSE_K rows per wave behind the visit rows (9: what the LDS has left at eight
+// workgroups per CU).  Which path a visit takes depends on its hit lanes alone -- not on what else is in the round -- so the
+// gradients stay bit-identical with the cull / hit record on or off (tests).  Measured on the benchmark frame
+// (profiles/r5/ab_sparse.txt): thresholds 8, 9, 12 within 0.5 % of each other, 16 (stage in the round's unused rows) 1 %
+// behind -- the sum over many entries costs what the reduce-scatter does.  0 disables the path (A/B: tools/build_variant.py).
+// S = 0 instantiations with visit rows only.
+// (Tried first and dropped: the hit lanes ADDING into one per-wave entry with ds_add_f32 -- no VALU work at all, but the
+// LDS serialises float adds at 3-4 cycles per lane-operation, tools/ubench/valu_rates2.hip: 0.97 ms instead of 0.72 at a
+// threshold of 8, profiles/r5/ab_sparse.txt.)
 #ifndef SGR_SPARSE_K
-#define SGR_SPARSE_K 8
-#endif
-// SGR_SPARSE_MODE 2: the hit lanes ADD their values into ONE per-wave entry instead (eleven ds_add_f32 under the hit lanes'
-// EXEC, all lanes of an instruction on the same address: the LDS serialises them in lane order, and nobody else touches the
-// entry), a row owner reads the sum, clears the word and adds it to the row: no rank, no adds on the VALU, one LDS round
-// trip, 192 bytes of LDS whatever the threshold.
-#ifndef SGR_SPARSE_MODE
-#define SGR_SPARSE_MODE 1
+#define SGR_SPARSE_K 9
 #endif
 
 // self-test of the DPP reduction (sgr_selftest in sgr_api.hip)
@@ -194,6 +194,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
     __shared__ float4 sB[BATCH];  // {qa, qb, qc, opacity}
     __shared__ float4 sC[BATCH];  // {r, g, b, depth}
     __shared__ uint64_t sBits[4][4];
+    __shared__ uint64_t sVis[4][4];  // VROWS: [quadrant][chunk] the slots whose visit had a hitting pixel (= owns a row)
     __shared__ int sMax[4];
     // The (up to four) wave partials of an instance meet in LDS with ds_add_f32.  DET: two zero-initialised
     // rows per slot, waves {0,1} add into row 0 and waves {2,3} into row 1, the flush adds row 0 + row 1.  Every
@@ -202,15 +203,18 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
     // !DET: a single row shared by all four waves (arrival order can change the last bit, like the reference's
     // atomicAdd).
     constexpr int NROW = DET ? 2 : 1;
-    constexpr bool VROWS = SGR_VROWS && DET && DPP && SGR_FOLD;  // one LDS row per visit, plain stores (see SGR_VROWS)
+    // one LDS row per visit, plain stores (see SGR_VROWS).  S = 0 only: the channel-carrying instantiations stage 64 entries per
+    // round, the row bookkeeping is paid twice as often per visit and measured 5 % slower at 2 M + 19 channels
+    constexpr bool VROWS = SGR_VROWS && DET && DPP && SGR_FOLD && SMAX == 0;
     constexpr int CAP = NROW * BATCH;                             // rows in LDS
     constexpr int NCH = BATCH / 64;                               // 64-slot chunks of a round
-    // sparse-visit stage (see SGR_SPARSE_K): SPK entries of 12 floats per wave, behind the rows in the same array so that
-    // the row owners reach it from their row address with one wave-uniform offset
-    constexpr int SPK = (SMAX == 0 && DPP && SGR_FOLD) ? SGR_SPARSE_K : 0;
-    constexpr int SPE = SGR_SPARSE_MODE == 2 ? (SPK > 0 ? 1 : 0) : SPK;  // stage entries per wave
-    constexpr int STAGE0 = NROW * BATCH * ACCW;
-    __shared__ __attribute__((aligned(16))) float sAcc[STAGE0 + 4 * SPE * 12];
+    // sparse visits (see SGR_SPARSE_K): the largest hit-lane count that may take the stage path, and the rows the array has
+    // beyond the CAP a round's visits may fill
+    constexpr int SPK = (VROWS && SMAX == 0) ? SGR_SPARSE_K : 0;
+    constexpr int XROWS = 4 * SPK;  // the stage: SPK entries (rows) per wave behind the visit rows
+    static_assert(SPK == 0 || ACCW == 12, "a stage entry is a row of 12 floats");
+    static_assert(SPK <= 16, "add sparse cases");
+    __shared__ __attribute__((aligned(16))) float sAcc[(CAP + XROWS) * ACCW];
     __shared__ __attribute__((aligned(16))) float sSem[SMAX > 0 ? BATCH * SMAX : 4];  // zero-padded to SMAX
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -276,9 +280,6 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
     if (lane == 0) sMax[wave] = mx;
-    if (SGR_SPARSE_MODE == 2) {
-        if (SPK > 0 && tid < 4 * 12) sAcc[STAGE0 + tid] = 0.0f;  // the per-wave accumulation entries start (and are left) at zero
-    } else if (SPK > 0 && tid < 4 * SPK) sAcc[STAGE0 + tid * 12 + 11] = 0.0f;  // padding word of the stage entries: never written again
     sgr_lds_barrier();
     const int maxc = max(max(sMax[0], sMax[1]), max(sMax[2], sMax[3]));
     const float tx0 = (float)(tx * SGR_BLOCK_X), ty0 = (float)(ty * SGR_BLOCK_Y);
@@ -289,11 +290,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
     const int fold_t0 = (0x3120 >> (((lane >> 2) & 3) * 4)) & 3;  // {0, 2, 1, 3}[bank]
     const bool fold_leader = (lane & 3) == 0;
     const int acc_fold_off = (VROWS ? 0 : (DET ? (wave >> 1) : 0) * BATCH * ACCW) + 4 * fold_t0 + (lane >> 4);
-    // sparse-visit stage of this wave, as floats from sAcc (wave-uniform: scalar registers), and the same relative to the
-    // row set this wave adds into -- a row owner's stage address is its row address + one scalar
-    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-    const int stage_off = STAGE0 + wave_s * (SPE * 12);
-    const int stage_rel = stage_off - (VROWS ? 0 : (DET ? (wave_s >> 1) : 0) * BATCH * ACCW);
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);  // wave-uniform copy: scalar registers
 
     // The staging of a round is a dependent pair of gathers (list entry -> record).  The first half is taken out of the
     // round: the entry (and its hit byte) of round n + 1 is loaded while round n walks -- 2 VGPRs held across the walk --
@@ -400,14 +397,18 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
             }
         }
         int rown = 0;  // VROWS: the row of this wave's next visit
+        constexpr int kq = SPK;                              // sparse visits: the threshold ...
+        const int stage_off = (CAP + wave_s * SPK) * ACCW;   // ... and this wave's stage (floats from sAcc; wave-uniform)
         if constexpr (VROWS) {
 #pragma unroll
             for (int q = 0; q < 4; q++) rown = (wave_s == q) ? vfirst[q] : rown;
         }
+        (void)kq; (void)stage_off;
 
-        // `rowi`: the visit's LDS row (VROWS; wave-uniform), else unused
+        uint64_t vis = 0;  // VROWS: the slots of the current chunk this wave gave a row (scalar)
+        // VROWS: a visit with at least one hitting pixel takes the wave's next row (`rown`, wave-uniform) and sets its bit in `vis`
         auto process = [&](const int j, const float4 q, const float dx, const float dy, const float power2, const float G,
-                           const float alpha, const int rowi) __attribute__((always_inline)) {
+                           const float alpha) __attribute__((always_inline)) {
                 const int posj = hi - j;  // 0-based list position == `contributor` after its decrement
                 // backward.cu:527-545
                 // (pixels outside the image have lastc = 0).  The wave-wide "any hit" is taken from the three compare
@@ -415,18 +416,12 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                 const bool k0 = posj < lastc, k1 = !(power2 > 0.0f), k2 = !(alpha < SGR_ALPHA_MIN);
                 const uint64_t hm = __builtin_amdgcn_ballot_w64(k0) & __builtin_amdgcn_ballot_w64(k1) &
                                     __builtin_amdgcn_ballot_w64(k2);
-                if (hm == 0) {
-                    // no pixel takes part (every passing pixel of the forward finished on this instance): the visit's row is
-                    // read by the flush all the same -- zeros
-                    if constexpr (VROWS) {
-                        if (fold_leader) {
-                            float* dst = sAcc + (acc_fold_off + rowi * ACCW);
-#pragma unroll
-                            for (int c0 = 0; c0 < NVAL; c0 += 16)
-                                if (fold_t0 < (NVAL - c0 < 16 ? NVAL - c0 : 16) / 4) dst[c0] = 0.0f;
-                        }
-                    }
-                    return;
+                // no pixel takes part (every passing pixel of the forward finished on this instance): no row, nothing to add
+                if (hm == 0) return;
+                const int rowi = rown;
+                if constexpr (VROWS) {
+                    rown++;
+                    vis = sgr_bitset1(vis, j & 63);
                 }
                 const bool hit = k0 && k1 && k2;
 
@@ -538,27 +533,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                 float r[NVAL / 4];
                 if constexpr (SPK > 0) {
                     const int kc = sgr_popc64(hm);
-                    if (SGR_SPARSE_MODE == 2 && kc <= SPK) {
-                        if (hit) {  // every hit lane adds into the wave's entry (laid out like a row: float4 t = values 4t, 4t+2, 4t+1, 4t+3)
-                            const uint32_t ea = sgr_lds_addr(sAcc + stage_off);
-#define SGR_STAGE_ADD(OFF, VAL) asm volatile("ds_add_f32 %0, %1 offset:" #OFF : : "v"(ea), "v"(VAL) : "memory")
-                            SGR_STAGE_ADD(0, v[0]); SGR_STAGE_ADD(4, v[2]); SGR_STAGE_ADD(8, v[1]); SGR_STAGE_ADD(12, v[3]);
-                            SGR_STAGE_ADD(16, v[4]); SGR_STAGE_ADD(20, v[6]); SGR_STAGE_ADD(24, v[5]); SGR_STAGE_ADD(28, v[7]);
-                            SGR_STAGE_ADD(32, v[8]); SGR_STAGE_ADD(36, v[10]); SGR_STAGE_ADD(40, v[9]);
-#undef SGR_STAGE_ADD
-                        }
-                        __builtin_amdgcn_wave_barrier();  // same wave, program order: the LDS serves the read below after the adds above
-                        if (fold_leader && fold_t0 < NVAL / 4) {
-                            float* src = sAcc + (acc_fold_off + stage_rel);
-                            const float t = *src;
-                            *src = 0.0f;  // behind the read in the LDS queue
-                            if constexpr (VROWS) sAcc[acc_fold_off + rowi * ACCW] = t;
-                            else atomicAdd(sAcc + (acc_fold_off + j * ACCW), t);
-                            asm volatile("; sparse visit done" ::: "memory");
-                        }
-                        return;
-                    }
-                    if (SGR_SPARSE_MODE != 2 && kc <= SPK) {
+                    if (kc <= kq) {
                         if (hit) {  // entry = rank among the hit lanes; an entry is laid out like a row (float4 t = values 4t, 4t+2, 4t+1, 4t+3)
                             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
                             // 32-bit stores written as ds_write_b32 (the optimiser merges plain stores into ds_write_b128, which
@@ -567,21 +542,28 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
 #define SGR_STAGE_ST(OFF, VAL) asm volatile("ds_write_b32 %0, %1 offset:" #OFF : : "v"(ea), "v"(VAL) : "memory")
                             SGR_STAGE_ST(0, v[0]); SGR_STAGE_ST(4, v[2]); SGR_STAGE_ST(8, v[1]); SGR_STAGE_ST(12, v[3]);
                             SGR_STAGE_ST(16, v[4]); SGR_STAGE_ST(20, v[6]); SGR_STAGE_ST(24, v[5]); SGR_STAGE_ST(28, v[7]);
-                            SGR_STAGE_ST(32, v[8]); SGR_STAGE_ST(36, v[10]); SGR_STAGE_ST(40, v[9]);  // word 11: zero since the prologue
+                            SGR_STAGE_ST(32, v[8]); SGR_STAGE_ST(36, v[10]); SGR_STAGE_ST(40, v[9]); SGR_STAGE_ST(44, v[11]);
 #undef SGR_STAGE_ST
                         }
                         __builtin_amdgcn_wave_barrier();  // same wave, program order: the LDS serves the reads below after the writes above
                         if (fold_leader && fold_t0 < NVAL / 4) {
-                            const float* src = sAcc + (acc_fold_off + stage_rel);
+                            const float* src = sAcc + (acc_fold_off + stage_off);
                             // kc is wave-uniform: one case, all its loads in flight at once, adds in rank order
                             auto sum_first = [&](auto KC) __attribute__((always_inline)) {
-                                constexpr int kk = decltype(KC)::value;
-                                float a[kk];
+                                constexpr int kk = decltype(KC)::value, k0 = kk < 8 ? kk : 8;
+                                float a[k0];  // (at most eight loads in flight: the kernel lives on 64 registers)
 #pragma unroll
-                                for (int e = 0; e < kk; e++) a[e] = src[e * 12];
+                                for (int e = 0; e < k0; e++) a[e] = src[e * 12];
                                 float t = a[0];
 #pragma unroll
-                                for (int e = 1; e < kk; e++) t += a[e];
+                                for (int e = 1; e < k0; e++) t += a[e];
+                                if constexpr (kk > 8) {
+                                    float b[kk - 8];
+#pragma unroll
+                                    for (int e = 8; e < kk; e++) b[e - 8] = src[e * 12];
+#pragma unroll
+                                    for (int e = 8; e < kk; e++) t += b[e - 8];
+                                }
                                 return t;
                             };
                             float t = 0.0f;
@@ -590,13 +572,12 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                                 SGR_SPARSE_CASE(1); SGR_SPARSE_CASE(2); SGR_SPARSE_CASE(3); SGR_SPARSE_CASE(4);
                                 SGR_SPARSE_CASE(5); SGR_SPARSE_CASE(6); SGR_SPARSE_CASE(7); SGR_SPARSE_CASE(8);
                                 SGR_SPARSE_CASE(9); SGR_SPARSE_CASE(10); SGR_SPARSE_CASE(11); SGR_SPARSE_CASE(12);
+                                SGR_SPARSE_CASE(13); SGR_SPARSE_CASE(14); SGR_SPARSE_CASE(15); SGR_SPARSE_CASE(16);
 #undef SGR_SPARSE_CASE
                                 default: break;
                             }
-                            static_assert(SGR_SPARSE_MODE == 2 || SPK <= 12, "add sparse cases");
-                            if constexpr (VROWS) sAcc[acc_fold_off + rowi * ACCW] = t;
-                            else atomicAdd(sAcc + (acc_fold_off + j * ACCW), t);
-                            // keeps the optimiser from merging this ds_add_f32 with the dense path's: the merged tail made the
+                            sAcc[acc_fold_off + rowi * ACCW] = t;  // the visit's own row: one writer
+                            // keeps the optimiser from merging this store with the dense path's: the merged tail made the
                             // twelve values live across this block (and the loads above serialise for want of registers)
                             asm volatile("; sparse visit done" ::: "memory");
                         }
@@ -651,13 +632,11 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
         };
         for (int chunk = 0; chunk < BATCH / 64; chunk++) {
             uint64_t m;
-            if constexpr (VROWS) {  // this wave's (limited) survivor mask of the chunk, picked with scalar selects
-                m = vm[0][chunk];
-#pragma unroll
-                for (int q = 1; q < 4; q++) m = (wave_s == q) ? vm[q][chunk] : m;
-            } else {
-                m = sBits[wave][chunk];
-                m = sgr_uniform_u64(m);
+            m = sBits[wave][chunk];
+            m = sgr_uniform_u64(m);
+            if constexpr (VROWS) {  // only the slots this round walks (`chunk` may be a run-time index: no register array here)
+                const int nb = lim - 64 * chunk;
+                m = nb >= 64 ? m : (nb <= 0 ? 0ull : (m & ((1ull << nb) - 1ull)));
             }
             // scalar bookkeeping kept short (SALU issues once per four cycles per SIMD): s_ff1 + s_bitset0 per survivor, and
             // the odd survivor is taken first so that the loop is pairs only
@@ -667,8 +646,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                 const float dx0 = a0.x - pxf, dy0 = a0.y - pyf;
                 const float pw0 = EXACT ? sgr_power_ref_staged(q0.x, q0.y, q0.z, dx0, dy0) : sgr_power2(q0.x, q0.y, q0.z, dx0, dy0);
                 const float G0 = EXACT ? (SGR_EXACT_TRIM ? sgr_expf_ref(pw0) : expf(pw0)) : __builtin_amdgcn_exp2f(pw0);
-                process(j0, q0, dx0, dy0, pw0, G0, fminf(0.99f, q0.w * G0), rown);
-                rown++;
+                process(j0, q0, dx0, dy0, pw0, G0, fminf(0.99f, q0.w * G0));
             }
             while (m) {
                 // two survivors per trip: LDS reads and exp() of both are independent of each other; only the
@@ -682,9 +660,12 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                 const float pw1 = EXACT ? sgr_power_ref_staged(q1.x, q1.y, q1.z, dx1, dy1) : sgr_power2(q1.x, q1.y, q1.z, dx1, dy1);
                 const float G0 = EXACT ? (SGR_EXACT_TRIM ? sgr_expf_ref(pw0) : expf(pw0)) : __builtin_amdgcn_exp2f(pw0), G1 = EXACT ? (SGR_EXACT_TRIM ? sgr_expf_ref(pw1) : expf(pw1)) : __builtin_amdgcn_exp2f(pw1);
                 const float al0 = fminf(0.99f, q0.w * G0), al1 = fminf(0.99f, q1.w * G1);
-                process(j0, q0, dx0, dy0, pw0, G0, al0, rown);
-                process(j1, q1, dx1, dy1, pw1, G1, al1, rown + 1);
-                rown += 2;
+                process(j0, q0, dx0, dy0, pw0, G0, al0);
+                process(j1, q1, dx1, dy1, pw1, G1, al1);
+            }
+            if constexpr (VROWS) {
+                if (lane == 0) sVis[wave][chunk] = vis;
+                vis = 0;
             }
         }
         sgr_lds_barrier();
@@ -692,6 +673,13 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
         // forward's hit record that is the set of instances that blended into the tile (plus the rare one whose every
         // passing pixel finished on it: a row of zeros); flagging rows per visit instead cost an LDS store + exec
         // juggling in the walk.
+        uint64_t vq[4][NCH];  // VROWS: the slots every quadrant's wave gave a row (wave-uniform)
+        if constexpr (VROWS) {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int c = 0; c < NCH; c++) vq[q][c] = sgr_uniform_u64(sVis[q][c]);
+        }
         if (mask4 != 0 && tid < lim) {
             const uint32_t u = __float_as_uint(sA[tid].z);
             touched[u] = 1;  // the per-Gaussian reduction only reads rows that were written (no 64 B/instance memset)
@@ -701,16 +689,16 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
             for (int k4 = 0; k4 < NVAL / 4; k4++) r[k4] = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (VROWS) {
                 // the rows of this slot's visits, in quadrant order: row of quadrant q = the quadrant's first row + the rank of
-                // the slot among the set bits of its survivor masks (whole chunks before this wave's: scalar; inside: v_mbcnt)
+                // the slot among the slots the quadrant's wave gave a row (whole chunks before this wave's: scalar; inside: v_mbcnt)
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     int before = vfirst[q];
 #pragma unroll
-                    for (int c = 0; c + 1 < NCH; c++) before += (c < wave_s) ? sgr_popc64(vm[q][c]) : 0;
-                    uint64_t mine = vm[q][0];
+                    for (int c = 0; c + 1 < NCH; c++) before += (c < wave_s) ? sgr_popc64(vq[q][c]) : 0;
+                    uint64_t mine = vq[q][0];
 #pragma unroll
-                    for (int c = 1; c < NCH; c++) mine = (wave_s == c) ? vm[q][c] : mine;
-                    if ((mask4 >> q) & 1u) {
+                    for (int c = 1; c < NCH; c++) mine = (wave_s == c) ? vq[q][c] : mine;
+                    if ((mine >> lane) & 1ull) {
                         const int rq = before + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
                         const float4* src = reinterpret_cast<const float4*>(&sAcc[rq * ACCW]);
 #pragma unroll

@@ -51,7 +51,8 @@ struct SgrGeomView {
     uint32_t* dkeys[2];       // depth bits per Gaussian (0xffffffff = culled), ping-pong for the depth sort
     uint32_t* dvals[2];       // Gaussian ids; after the sort dvals[cur] = ids in (depth, id) order (dvals[0] is never
                               // written by the preprocess: the first pass takes the element index as the value)
-    uint32_t* tt_sorted;      // inclusive scan of tiles_touched in depth order
+    uint32_t* sub_sums;       // the scan's 256-element sub-block offsets (both sequences): [2][ceil(P / 2048) * 8] -- where a
+                              // 256-thread workgroup of sgr_duplicate_kernel starts inside its 2048-element scan block
     uint32_t* dhist;          // digit histogram of the depth sort
     uint32_t* clamped;  // 3-bit mask per Gaussian, one u32 each (keeps stores simple and aligned)
     int* internal_radii;
@@ -130,7 +131,7 @@ static inline SgrGeomView sgr_geom_carve(char* base, size_t P, char** end = null
     sgr_carve(p, v.dkeys[1], Pn);
     sgr_carve(p, v.dvals[0], Pn);
     sgr_carve(p, v.dvals[1], Pn);
-    sgr_carve(p, v.tt_sorted, Pn);
+    sgr_carve(p, v.sub_sums, 2 * 8 * ((Pn + SGR_SCAN_ITEMS - 1) / SGR_SCAN_ITEMS));
     {
         const size_t nh = sgr_sort_hist_words(Pn);
         sgr_carve(p, v.dhist, nh);
@@ -197,6 +198,13 @@ SgrFlagBlock sgr_acquire_flag_block();
 void sgr_launch_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, bool inclusive, hipStream_t s,
                      uint32_t* total_out = nullptr, const uint32_t* gather = nullptr, int in_stride = 1,
                      const uint32_t* in2 = nullptr, uint32_t* out2 = nullptr);
+// The first two of the scan's three launches for TWO sequences of n elements (in[i * in_stride], in2[i * in_stride]): block
+// sums reduced and scanned (tmp[b] = exclusive prefix of 2048-element block b, tmp[nb] = total; second sequence behind it at
+// tmp + nb + 1), and sub[seq * 8 nb + 8 b + j] = the offset of 256-element sub-block j inside block b.  The consumer does
+// the last step itself: element i = tmp[i / 2048] + sub[i / 256] + its exclusive prefix inside its 256-element sub-block
+// (the forward's duplicate kernel: no third launch, no scanned array written and read back).
+void sgr_launch_scan_head(const uint32_t* in, const uint32_t* in2, size_t n, int in_stride, uint32_t* tmp, uint32_t* sub,
+                          hipStream_t s);
 // stable LSD radix sorts on key bits [0, end_bit); return the index (0/1) of the buffer pair holding the result
 int sgr_sort_get_one_sweep();
 void sgr_sort_set_one_sweep(int on);  // A/B: 1 = the one-sweep form instead of histogram + row scan + scatter per pass
@@ -208,6 +216,29 @@ int sgr_launch_sort_pairs32(uint32_t* const keys[2], uint32_t* const vals[2], ui
                             uint32_t* scan_tmp, hipStream_t s, bool iota = false, const uint2* aux_in = nullptr,
                             uint2* aux_out = nullptr, int max_bits = 8);  // max_bits: digit width cap, 8 or 9
 int sgr_sort_pass_count(int end_bit);  // passes (= buffer flips) of a sort on key bits [0, end_bit)
+
+// ---- wave / block scan primitives (sgr_scan_sort.hip, sgr_preprocess.hip) ----
+__device__ __forceinline__ uint32_t sgr_wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread over a 256-thread block; returns block total in `total`
+__device__ __forceinline__ uint32_t sgr_block_excl_scan256(uint32_t v, uint32_t* lds4, uint32_t& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t inc = sgr_wave_incl_scan(v, lane);
+    if (lane == 63) lds4[wave] = inc;
+    __syncthreads();
+    const uint32_t w0 = lds4[0], w1 = lds4[1], w2 = lds4[2], w3 = lds4[3];
+    __syncthreads();
+    const uint32_t base = (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);
+    total = w0 + w1 + w2 + w3;
+    return base + inc - v;
+}
 
 // XCD-aware workgroup -> tile map.  The dispatcher places workgroup b on XCD b % 8 (observed, used for speed only),
 // and each XCD has a private 4 MiB L2.  A splat's instances live in neighbouring tiles, so neighbouring tiles

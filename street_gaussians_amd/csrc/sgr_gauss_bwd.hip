@@ -503,14 +503,15 @@ sgr_gauss_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, con
     *reinterpret_cast<float4*>(dL_drot + 4 * (size_t)idx) = make_float4(drot[0], drot[1], drot[2], drot[3]);
 }
 
-void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const int* radii, const float* shs,
+// returns non-zero when `after_rows` could not be recorded (everything is launched regardless)
+int sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const int* radii, const float* shs,
                           const float* scales, const float* rotations, const float* cov3D_precomp, const SgrCam* cam,
                           const SgrGeomView& gv, const float* partials, int row_stride, const uint8_t* touched,
                           float4* cd, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dsemantic,
                           const SgrStatSink& sink, int quad, int exact, int W, int H, hipEvent_t after_rows, int rs_wave,
                           hipStream_t s) {
-    if (P <= 0) return;
+    if (P <= 0) return 0;
     const float lsc = exact ? 1.0f : SGR_LOG2E;
     const float kx = (0.5f * (float)W) / lsc, ky = (0.5f * (float)H) / lsc;
     const unsigned nb = (P + SGR_GB_THREADS - 1) / SGR_GB_THREADS;
@@ -548,8 +549,12 @@ void sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, cons
     else SGR_RS(32);
 #undef SGR_RS
 #undef SGR_RSW
-    if (after_rows) (void)hipEventRecord(after_rows, s);  // dL/dmean2D, dL/dopacity, dL/dcolour are final from here on
+    // dL/dmean2D, dL/dopacity, dL/dcolour are final from here on.  A failed record must not pass silently: the reducer's side
+    // stream would wait on a stale record and read the colour gradient unsynchronised -- the error is picked up by the
+    // failure is returned to sgr_backward_ex, which reports SGR_E_HIP
+    const bool ev_failed = after_rows && hipEventRecord(after_rows, s) != hipSuccess;
     sgr_gauss_bwd_kernel<<<nb, SGR_GB_THREADS, 0, s>>>(P, D, M, means3D, radii, shs, scales, rotations, cov3D_precomp, cam,
                                                        gv, cd, dL_dmean2D, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
                                                        dL_dscale, dL_drot);
+    return ev_failed ? 1 : 0;
 }

@@ -314,8 +314,11 @@ SGR_HD uint64_t sgr_tile_mask(float px, float py, float A, float B, float C, flo
     if (!(det > 0.0f && A > 0.0f && C > 0.0f)) return full;
     const float ymax = sqrtf(A * t2 / det);
     const float s = sqrtf(t2 / (det * C));
+    // (an overflowing s or ymax -- det cancelled away for a needle clipped by the screen -- would put NaN into the row extents
+    // below, where fmin / fmax silently pick the other operand: keep every tile instead)
+    if (!(s <= 3.0e38f && ymax <= 3.0e38f)) return full;
     const float inva = 1.0f / A;
-    const float dyf = -B * s, dyg = B * s;  // where f peaks / g bottoms out
+    const float dyf = (B == 0.0f) ? 0.0f : -B * s, dyg = (B == 0.0f) ? 0.0f : B * s;  // where f peaks / g bottoms out
     uint64_t tm = 0;
     for (uint32_t rr = 0; rr < h; rr++) {
         const float dy0 = (float)((y0 + rr) * 16u) - 0.25f - py, dy1 = dy0 + 15.5f;

@@ -304,25 +304,40 @@ sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, co
 // writes slots start + 64*it + l (fully coalesced 256-byte stores; a lane-per-Gaussian loop writes 64 scattered
 // 4-byte runs per instruction and was store-issue bound: 0.08 ms for 62 MB) and finds the slot's owner with a binary
 // search over the wave's 64 exclusive offsets in LDS, then its tile from the owner's packed rect.
+// Round 5: the kernel also does the LAST step of the forward's two scans itself (sgr_launch_scan_head left the block
+// prefixes and the sub-block offsets): the slot range of every Gaussian in depth order = prefix of its 2048-block + offset of
+// its 256-element sub-block + an exclusive scan over the workgroup's 256 counts -- and, in the same way over the counts in
+// INDEX order, every Gaussian's first partial-gradient row u0 (SgrGeomView::u0).  One launch and one scanned array
+// (4 bytes / Gaussian written and read back, 8 more read) less per forward: scan + duplicate 0.045 -> 0.036 ms at 1 M
+// Gaussians, 0.16 -> 0.12 ms at 5 M.
+static_assert(SGR_PRE_THREADS == 256 && SGR_SCAN_ITEMS == 8 * SGR_PRE_THREADS, "one workgroup = one sub-block of the scan");
 __global__ void __launch_bounds__(SGR_PRE_THREADS)
-sgr_duplicate_kernel(int P, SgrGeomView gv, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offs_incl,
-                     uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int gx) {
+sgr_duplicate_kernel(int P, SgrGeomView gv, const uint32_t* __restrict__ order, const uint32_t* __restrict__ bsum,
+                     const uint32_t* __restrict__ sub, uint32_t nb, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                     int gx) {
     __shared__ uint32_t sOff[SGR_PRE_THREADS / 64][64];
     __shared__ uint32_t sRect[SGR_PRE_THREADS / 64][64];
     __shared__ uint32_t sIdx[SGR_PRE_THREADS / 64][64];
     __shared__ uint64_t sMask[SGR_PRE_THREADS / 64][64];
+    __shared__ uint32_t lds4[4];
     const int i = blockIdx.x * SGR_PRE_THREADS + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t off = 0xffffffffu, incl = 0, idx = 0, rect = 0;
     uint64_t tmask = 0;
+    // everything in depth order and coalesced: the id, and {tiles_touched, tile rect} the depth sort's last pass carried
+    // along (aux_sorted) -- no gather of the Gaussian's record
+    const uint2 as = (i < P) ? gv.aux_sorted[i] : make_uint2(0u, 0u);
+    const uint32_t t2 = (i < P) ? gv.aux[i].x : 0u;  // the same count in index order
+    uint32_t total;
+    const uint32_t ex1 = sgr_block_excl_scan256(as.x, lds4, total) + bsum[blockIdx.x >> 3] + sub[blockIdx.x];
+    const uint32_t ex2 = sgr_block_excl_scan256(t2, lds4, total) + bsum[nb + 1 + (blockIdx.x >> 3)] + sub[8 * nb + blockIdx.x];
     if (i < P) {
-        // everything in depth order and coalesced: the id, the scanned offsets, and the tile rect the depth sort's last
-        // pass carried along (aux_sorted) -- no gather of the Gaussian's record
+        gv.u0[i] = ex2;
         idx = order[i];
-        off = (i == 0) ? 0u : offs_incl[i - 1];
-        incl = offs_incl[i];
+        off = ex1;
+        incl = ex1 + as.x;
         if (incl != off) {  // tiles_touched > 0
-            rect = gv.aux_sorted[i].y;
+            rect = as.y;
             if (rect & SGR_RECT_MASKED) tmask = gv.tmask[idx];  // (by id: 8 bytes, masked Gaussians only)
         }
     }
@@ -414,10 +429,12 @@ void sgr_launch_filter(int P, const float* means3D, const float* scales, const f
         P, means3D, scales, rotations, cov3D_precomp, gv.header, radii, means2D, prefiltered, ca);
 }
 
-void sgr_launch_duplicate(int P, const SgrGeomView& gv, const uint32_t* order, const uint32_t* offs_incl, uint32_t* keys,
-                          uint32_t* vals, int gx, hipStream_t s) {
+// bsum / sub: what sgr_launch_scan_head left for the two count sequences (aux_sorted in depth order, aux in index order)
+void sgr_launch_duplicate(int P, const SgrGeomView& gv, const uint32_t* order, const uint32_t* bsum, const uint32_t* sub,
+                          uint32_t* keys, uint32_t* vals, int gx, hipStream_t s) {
     if (P <= 0) return;
-    sgr_duplicate_kernel<<<(P + SGR_PRE_THREADS - 1) / SGR_PRE_THREADS, SGR_PRE_THREADS, 0, s>>>(P, gv, order, offs_incl, keys,
+    const uint32_t nb = (uint32_t)(((size_t)P + SGR_SCAN_ITEMS - 1) / SGR_SCAN_ITEMS);
+    sgr_duplicate_kernel<<<(P + SGR_PRE_THREADS - 1) / SGR_PRE_THREADS, SGR_PRE_THREADS, 0, s>>>(P, gv, order, bsum, sub, nb, keys,
                                                                                              vals, gx);
 }
 

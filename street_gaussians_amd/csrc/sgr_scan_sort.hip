@@ -25,30 +25,6 @@
 
 
 // ------------------------------------------------------------------------------------------------
-// wave / block primitives
-__device__ __forceinline__ uint32_t sgr_wave_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
-    return v;
-}
-
-// exclusive scan of one value per thread over a 256-thread block; returns block total in `total`
-__device__ __forceinline__ uint32_t sgr_block_excl_scan256(uint32_t v, uint32_t* lds4, uint32_t& total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t inc = sgr_wave_incl_scan(v, lane);
-    if (lane == 63) lds4[wave] = inc;
-    __syncthreads();
-    const uint32_t w0 = lds4[0], w1 = lds4[1], w2 = lds4[2], w3 = lds4[3];
-    __syncthreads();
-    const uint32_t base = (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);
-    total = w0 + w1 + w2 + w3;
-    return base + inc - v;
-}
-
-// ------------------------------------------------------------------------------------------------
 // scan kernels: ITEMS = 2048 per block = 256 threads x 8 consecutive elements
 // gather != nullptr: element i of the scanned sequence is in[gather[i]] (the forward scans tiles_touched in depth
 // order without materialising the permuted array)
@@ -59,18 +35,21 @@ __device__ __forceinline__ uint32_t sgr_block_excl_scan256(uint32_t v, uint32_t*
 __global__ void __launch_bounds__(256) sgr_scan_reduce_kernel(const uint32_t* __restrict__ in, size_t n,
                                                               uint32_t* __restrict__ block_sums,
                                                               const uint32_t* __restrict__ gather, int stride,
-                                                              const uint32_t* __restrict__ in2, unsigned nb) {
+                                                              const uint32_t* __restrict__ in2, unsigned nb,
+                                                              uint32_t* __restrict__ sub) {
     __shared__ uint32_t lds4[4];
     unsigned b = blockIdx.x;
-    if (b >= nb) { b -= nb; in = in2; gather = nullptr; block_sums += nb + 1; }
+    if (b >= nb) { b -= nb; in = in2; gather = nullptr; block_sums += nb + 1; if (sub) sub += 8 * nb; }
     const size_t base = (size_t)b * SGR_SCAN_ITEMS + (size_t)threadIdx.x * 8;
     uint32_t s = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++)
         if (base + i < n) s += gather ? in[(size_t)gather[base + i] * stride] : in[(base + i) * stride];
     uint32_t total;
-    sgr_block_excl_scan256(s, lds4, total);
+    const uint32_t ex = sgr_block_excl_scan256(s, lds4, total);
     if (threadIdx.x == 0) block_sums[b] = total;
+    // (sgr_launch_scan_head) where each 256-element sub-block -- 32 threads' elements -- starts inside this block
+    if (sub != nullptr && (threadIdx.x & 31) == 0) sub[8 * b + (threadIdx.x >> 5)] = ex;
 }
 
 // one block per sequence: exclusive scan of block_sums[0..nb) in place; block_sums[nb] = grand total
@@ -128,10 +107,18 @@ void sgr_launch_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp,
     const size_t nb = (n + SGR_SCAN_ITEMS - 1) / SGR_SCAN_ITEMS;
     const unsigned seqs = in2 ? 2u : 1u;
 
-    sgr_scan_reduce_kernel<<<(unsigned)nb * seqs, 256, 0, s>>>(in, n, tmp, gather, in_stride, in2, (unsigned)nb);
+    sgr_scan_reduce_kernel<<<(unsigned)nb * seqs, 256, 0, s>>>(in, n, tmp, gather, in_stride, in2, (unsigned)nb, nullptr);
     sgr_scan_spine_kernel<<<seqs, 256, 0, s>>>(tmp, nb, total_out);
     sgr_scan_final_kernel<<<(unsigned)nb * seqs, 256, 0, s>>>(in, out, n, tmp, gather, in_stride, inclusive, in2, out2,
                                                              (unsigned)nb);
+}
+
+void sgr_launch_scan_head(const uint32_t* in, const uint32_t* in2, size_t n, int in_stride, uint32_t* tmp, uint32_t* sub,
+                          hipStream_t s) {
+    if (n == 0) return;
+    const size_t nb = (n + SGR_SCAN_ITEMS - 1) / SGR_SCAN_ITEMS;
+    sgr_scan_reduce_kernel<<<(unsigned)nb * 2u, 256, 0, s>>>(in, n, tmp, nullptr, in_stride, in2, (unsigned)nb, sub);
+    sgr_scan_spine_kernel<<<2, 256, 0, s>>>(tmp, nb, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------

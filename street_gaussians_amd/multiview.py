@@ -463,6 +463,8 @@ class FactoredGradReducer:
             else:
                 self._gather_works = [dist.all_gather_into_tensor(self._all, mine, group=self.group, async_op=True)]
         else:
+            if early:  # the payload was packed on the side stream: the compute stream's copy must come after it
+                torch.cuda.current_stream(mine.device).wait_stream(side)
             self._all.copy_(mine)
         if early:
             # the all-gather is already queued behind the packed payload; the dense bucket follows it on the side stream

@@ -226,3 +226,51 @@ def test_tile_masks_are_conservative_and_the_bit_utilities_invert_each_other(hm)
     rect = 3 | (5 << 10) | (8 << 20)  # without a mask: the index inside the rect
     assert hm.hm_row_of(rect, 3 + 5, 5 + 2, _p(u0), None, 0) == 1000 + 2 * 8 + 5
     fw.free()
+
+
+def test_tile_mask_row_form_never_drops_a_needed_tile_for_extreme_splats(hm):
+    """Randomised sweep of sgr_tile_mask (the O(rows) form the preprocess runs) over the cases the advisor flagged: extreme
+    anisotropy (needles whose conic determinant nearly cancels), axis-aligned conics (B == 0 exactly), centres far off the
+    screen, opacities at both ends.  Ground truth = the blend's own per-pixel test (power <= 0 and alpha >= 1/255,
+    forward.cu:425-430) evaluated on every pixel of every tile of the rect: a tile with an accepted pixel must have its bit.
+    (A lost tile is the one way the tile masks could change an image.)"""
+    rng = np.random.default_rng(11)
+    n = 4000
+    # covariance from eigenvalues spanning 1e-1 .. 1e5 px^2 and a random angle; a third axis-aligned (B == 0 exactly)
+    l1 = 10.0 ** rng.uniform(-1, 5, n)
+    l2 = 10.0 ** rng.uniform(-1, 1.5, n)
+    th = rng.uniform(0, np.pi, n)
+    th[::3] = rng.integers(0, 2, len(th[::3])) * (np.pi / 2)
+    c, s = np.cos(th), np.sin(th)
+    a = l1 * c * c + l2 * s * s + 0.3
+    b = (l1 - l2) * c * s
+    b[::3] = 0.0
+    cc = l1 * s * s + l2 * c * c + 0.3
+    det = a * cc - b * b
+    conic = np.stack([cc / det, -b / det, a / det], 1)
+    opac = np.where(rng.random(n) < 0.3, rng.uniform(0.004, 0.02, n), rng.uniform(0.02, 1.0, n))
+    # rects of 2..64 tiles somewhere on a 64 x 64 tile screen, the centre inside, at the border of, or far outside the rect
+    w = rng.integers(1, 9, n); h = rng.integers(1, 9, n)
+    w = np.where(w * h < 2, 2, w)
+    x0 = rng.integers(0, 56, n); y0 = rng.integers(0, 56, n)
+    cx = (x0 + w * rng.uniform(-1.5, 2.5, n)) * 16.0
+    cy = (y0 + h * rng.uniform(-1.5, 2.5, n)) * 16.0
+    m2 = np.ascontiguousarray(np.stack([cx, cy], 1), dtype=np.float32)
+    co = np.ascontiguousarray(np.concatenate([conic, opac[:, None]], 1), dtype=np.float32)
+    rects = np.ascontiguousarray(np.stack([x0, y0, x0 + w, y0 + h], 1), dtype=np.uint32)
+    masks = np.zeros(n, np.uint64)
+    hm.hm_tile_masks(n, _p(m2), _p(co), _p(rects), _p(masks))
+    needed_total = 0
+    for i in range(n):
+        X0, Y0, X1, Y1 = [int(v) for v in rects[i]]
+        ww = X1 - X0
+        ys, xs = np.meshgrid(np.arange(Y0 * 16, Y1 * 16), np.arange(X0 * 16, X1 * 16), indexing="ij")
+        dx = m2[i, 0] - xs.astype(np.float32); dy = m2[i, 1] - ys.astype(np.float32)
+        with np.errstate(over="ignore", invalid="ignore"):
+            power = np.float32(-0.5) * (co[i, 0] * dx * dx + co[i, 2] * dy * dy) - co[i, 1] * dx * dy
+            acc = (power <= 0) & (np.minimum(np.float32(0.99), co[i, 3] * np.exp(power)) >= np.float32(1.0 / 255.0))
+        need = acc.reshape(Y1 - Y0, 16, ww, 16).any(axis=(1, 3)).reshape(-1)
+        bits = np.array([(int(masks[i]) >> j) & 1 for j in range(need.size)], bool)
+        assert not (need & ~bits).any(), (i, m2[i], co[i], rects[i], hex(int(masks[i])))
+        needed_total += int(need.sum())
+    assert needed_total > n // 4  # the sweep does exercise tiles that are needed

@@ -24,3 +24,8 @@ tot=h.sum(); print("visits",tot)
 cum=np.cumsum(h)/tot
 for k in (1,2,3,4,6,8,12,16,24,32,48,64): print(k, round(cum[k],4))
 print("mean lanes", (h*np.arange(65)).sum()/tot)
+if len(sys.argv) > 2:  # full histogram for tools/valu_model.py
+    import json
+    json.dump({"gaussians": int(sys.argv[1]), "visits": float(tot), "hist_hit_lanes": [float(x) for x in h],
+               "note": "visits by number of hitting lanes (0..64), CPU replay of the benchmark frame (tools/replay_visits.c)"},
+              open(sys.argv[2], "w"))

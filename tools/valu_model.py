@@ -1,13 +1,20 @@
 #!/usr/bin/env python
-"""VALU issue model of the blend backward (no GPU): compiles the kernel to ISA, takes the pair loop of the walk (the last
-innermost loop of the kernel: two visits per trip), classifies its instructions and prices them with the issue costs
-MEASURED on MI355X by tools/ubench/valu_rates.hip (profiles/r4/valu_rates.jsonl: SIMD cycles per wave instruction at eight
-waves per SIMD -- plain f32 VALU 2.5-2.7, v_add_f32_dpp 4.4, v_permlane32/16_swap and the transcendentals 8.6, SALU 4.2).
-The result -- VALU-pipe cycles per (quadrant, instance) visit -- times the visits of a frame, over the 1024 SIMDs of the chip
-at the clock the counters show, is the time the kernel needs if its VALU pipes never idle: the bound bench.py reports as
-`roofline.valu_issue`.
+"""VALU issue model of the blend backward (no GPU), round 5.
 
-    python tools/valu_model.py [kernel name substring]   ->  profiles/r4/valu_model.json
+The kernel's time when its VALU pipes never idle = sum over the frame's visits of the pipe cycles their instruction path
+costs, over the 1024 SIMDs of the chip at the measured clock.  Two paths since round 5 (csrc/sgr_blend_bwd.hip):
+
+  dense   per-pixel terms + the 64-lane reduce-scatter (9 permlane swaps, 9 adds, 7 DPP adds) + one store;
+  sparse  (k hitting lanes, k <= SGR_SPARSE_K) per-pixel terms + 2 v_mbcnt + address + k - 1 plain adds.
+
+Instruction counts come from the ISA hipcc emits: the pair loop (two visits per trip) of a dense-only build
+(-DSGR_SPARSE_K=0) gives the dense path and, split at the first permlane swap of each visit, the part both paths share;
+the sparse path's own instructions are read off the shipped build (from the v_mbcnt pair to the `sparse visit done` marker of
+the k = 1 case, + k - 1 adds).  Costs are MEASURED IN CYCLES by tools/ubench/valu_rates2.hip (profiles/r5/valu_rates2.jsonl:
+launch time x the clock the waves read from s_memtime / wall_clock64, 8 waves per SIMD, >= 20 ms per launch).  The mix of
+the paths is the replay's histogram of hitting lanes per visit (tools/lane_hist.py -> profiles/r5/lane_hist_1M.json).
+
+    python tools/valu_model.py   ->  profiles/r5/valu_model.json   (what bench.py reports as roofline.valu_issue)
 """
 import collections
 import json
@@ -20,19 +27,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from street_gaussians_amd import build as b  # noqa: E402
 
-RATES = os.path.join(ROOT, "profiles", "r4", "valu_rates.jsonl")
-OUT = os.path.join(ROOT, "profiles", "r4", "valu_model.json")
+RATES = os.path.join(ROOT, "profiles", "r5", "valu_rates2.jsonl")
+HIST = os.path.join(ROOT, "profiles", "r5", "lane_hist_1M.json")
+OUT = os.path.join(ROOT, "profiles", "r5", "valu_model.json")
+SPARSE_K = 9  # SGR_SPARSE_K of the shipped build
 
 
 def measured_costs():
-    c = {}
+    c, clk = {}, []
     for ln in open(RATES):
         r = json.loads(ln)
-        if r["waves_per_simd"] == 8:
-            c[r["inst"]] = r["simd_cycles_per_wave_inst_at_2.4GHz"]
-    return {"valu": 0.5 * (c["v_fma_f32"] + c["v_mul_f32"]), "dpp": c["v_add_f32_dpp row_ror"], "swap": c["v_permlane32_swap"],
-            "trans": 0.5 * (c["v_exp_f32"] + c["v_rcp_f32"]), "cmp": 0.5 * (c["v_fma_f32"] + c["v_mul_f32"]),
-            "salu": c["s_add_u32"], "snop": c["s_nop 0"]}
+        if "inst" in r and r["waves_per_simd"] == 8 and r["lanes"] == 64:
+            key = [k for k in r if k.endswith("_from_wall_time")]
+            c[r["inst"]] = r[key[0]] if key else None
+            clk.append(r["clock_ghz"])
+    plain = (c["v_fma_f32"] + c["v_mul_f32"] + c["v_add_f32"]) / 3.0
+    clk.sort()
+    return {"valu": plain, "dpp": c["v_add_f32_dpp row_ror"], "swap": c["v_permlane32_swap"],
+            "trans": 0.5 * (c["v_exp_f32"] + c["v_rcp_f32"]), "cmp": c["v_cmp_lt_f32"], "mbcnt": c["v_mbcnt_lo_u32_b32"],
+            "pk": c["v_pk_mul_f32"], "salu": c["s_add_u32"], "snop": c["s_nop 0"]}, clk[len(clk) // 2]
 
 
 def classify(line):
@@ -44,7 +57,11 @@ def classify(line):
     if op.startswith("v_") and "dpp" in line:
         return "dpp"
     if op.startswith("v_cmp"):
-        return "cmp"  # (the ubench's 4.4 is a chain on VCC; the kernel's compares write different SGPR pairs)
+        return "cmp"
+    if op.startswith("v_mbcnt"):
+        return "mbcnt"
+    if op.startswith("v_pk_"):
+        return "pk"
     if op.startswith("v_"):
         return "valu"
     if op.startswith("s_nop"):
@@ -62,9 +79,9 @@ def classify(line):
     return "other"
 
 
-def model(src, kernel_substr, visits_per_trip=2):
-    asm = os.path.join("/tmp", "valu_model_" + src.replace(".hip", ".s"))
-    subprocess.run(["/opt/rocm/bin/hipcc"] + b.flags_for(src) + ["--offload-device-only", "-S", os.path.join(b.CSRC, src), "-o", asm],
+def isa(src, kernel_substr, extra):
+    asm = os.path.join("/tmp", "valu_model_" + src.replace(".hip", "") + ("_x" if extra else "") + ".s")
+    subprocess.run(["/opt/rocm/bin/hipcc"] + b.flags_for(src) + extra + ["--offload-device-only", "-S", os.path.join(b.CSRC, src), "-o", asm],
                    capture_output=True, text=True, check=True)
     text = open(asm).read()
     names = re.findall(r"^(_Z\S+):", text, re.M)
@@ -72,32 +89,97 @@ def model(src, kernel_substr, visits_per_trip=2):
     pick = [n for n, d in zip(names, dem) if kernel_substr in d]
     assert pick, f"no kernel matching {kernel_substr!r}"
     body = text[text.index(pick[0] + ":"):]
-    body = body[:body.index("s_endpgm")]
-    lines = body.split("\n")
-    heads = [i for i, ln in enumerate(lines) if "Inner Loop Header" in ln]
-    loop = lines[heads[-1]:]
-    counts = collections.Counter()
-    for ln in loop:
+    return body[:body.index("s_endpgm")].split("\n"), dem[names.index(pick[0])][:90]
+
+
+def insts(lines):
+    out = []
+    for ln in lines:
         ln = ln.strip()
         if not ln or ln.startswith((";", ".")) or ln.endswith(":"):
             continue
-        counts[classify(ln)] += 1
-    cost = measured_costs()
-    valu_cycles = sum(cost[k] * counts[k] for k in ("valu", "dpp", "swap", "trans", "cmp"))
-    scalar_cycles = sum(cost["salu"] * counts[k] for k in ("salu", "smem")) + cost["snop"] * counts["snop"]
-    return {"kernel": dem[names.index(pick[0])][:90], "source": src, "source_sha16": b.source_sha16(),
-            "instructions_per_trip": dict(counts), "visits_per_trip": visits_per_trip,
-            "measured_cost_cycles_at_2.4GHz": {k: round(v, 2) for k, v in cost.items()},
-            "valu_pipe_cycles_per_visit": round(valu_cycles / visits_per_trip, 1),
-            "scalar_pipe_cycles_per_visit": round(scalar_cycles / visits_per_trip, 1),
-            "note": "cycles as counted by the microbenchmark at its nominal 2.4 GHz; time bound = visits * cycles / (1024 SIMDs * 2.4e9)"}
+        out.append(ln)
+    return out
+
+
+def price(counts, cost):
+    return sum(cost[k] * n for k, n in counts.items() if k in ("valu", "dpp", "swap", "trans", "cmp", "mbcnt", "pk"))
+
+
+def model(kernel_substr):
+    cost, clock = measured_costs()
+    # dense-only build: the pair loop = the last innermost loop of the kernel
+    lines, name = isa("sgr_blend_bwd.hip", kernel_substr, ["-DSGR_SPARSE_K=0"])
+    # basic blocks carry "in Loop: Header=BBx_y" in their label comments (hipcc places a loop's blocks anywhere in the
+    # function): the pair loop = the innermost loop whose blocks hold the twelve permlane32 swaps of two visits
+    blocks, cur = {}, None
+    for ln in lines:
+        m = re.match(r"^(\.LBB\d+_\d+:|; %bb\.\d+:)(.*)$", ln)
+        if m:
+            hdr = re.search(r"Header=BB(\d+_\d+) Depth=(\d+)", m.group(2))
+            own = re.match(r"^\.LBB(\d+_\d+):", ln)
+            cur = (hdr.group(1), int(hdr.group(2))) if hdr else ((own.group(1), 0) if own else None)
+            continue
+        if "Loop Header: Depth=" in ln and cur is not None:  # the header block belongs to the loop it heads
+            d = int(re.search(r"Depth=(\d+)", ln).group(1))
+            cur = (cur[0], d)
+            continue
+        if cur is not None:
+            blocks.setdefault(cur, []).append(ln)
+    loop = []
+    for key, body in blocks.items():
+        cand = insts(body)
+        if sum(x.startswith("v_permlane32_swap") for x in cand) == 12 and (not loop or len(cand) < len(loop)):
+            loop = cand
+    assert loop, "pair loop (two visits of six permlane32 swaps) not found"
+    dense_trip = collections.Counter(classify(ln) for ln in loop)
+    # the reduce-scatter of one visit: from its first permlane swap up to and including its last DPP add
+    first = next(i for i, ln in enumerate(loop) if ln.startswith("v_permlane32_swap"))
+    last = first
+    for i in range(first, len(loop)):
+        if classify(loop[i]) in ("swap", "dpp"):
+            last = i
+        if loop[i].startswith("ds_write_b32") and i > first + 10:
+            break
+    reduce = collections.Counter(classify(ln) for ln in loop[first:last + 1])
+    # sparse path's own instructions, shipped build: v_mbcnt_lo ... marker of the k = 1 case
+    slines, _ = isa("sgr_blend_bwd.hip", kernel_substr, [])
+    sl = insts(slines)
+    z = max(i for i, ln in enumerate(sl) if ln.startswith("ds_write_b32") and "offset:44" in ln)  # last store of a stage entry
+    a = max(i for i, ln in enumerate(sl[:z]) if ln.startswith("v_mbcnt_lo"))
+    assert z - a < 24, "stage stores not found next to their v_mbcnt pair"
+    stage = collections.Counter(classify(ln) for ln in sl[a:z])
+    stage["valu"] += 2  # the row owners' address add + the zero of the padding word
+    dense = price(dense_trip, cost) / 2.0
+    red = price(reduce, cost)
+    hist = json.load(open(HIST))
+    h = hist["hist_hit_lanes"]
+    tot = sum(h[1:])
+    cyc = 0.0
+    sparse_share = 0.0
+    for k in range(1, 65):
+        if k <= SPARSE_K:
+            c = dense - red + price(stage, cost) + (k - 1) * cost["valu"]
+            sparse_share += h[k] / tot
+        else:
+            c = dense
+        cyc += h[k] / tot * c
+    return {"kernel": name, "source": "sgr_blend_bwd.hip", "source_sha16": b.source_sha16(),
+            "instructions_per_trip_dense": dict(dense_trip), "visits_per_trip": 2,
+            "reduce_scatter_instructions_per_visit": dict(reduce), "sparse_stage_instructions_per_visit": dict(stage),
+            "cost_cycles_per_wave_instruction": {k: round(v, 2) for k, v in cost.items()}, "clock_ghz": round(clock, 3),
+            "dense_pipe_cycles_per_visit": round(dense, 1), "reduce_scatter_cycles_per_visit": round(red, 1),
+            "sparse_pipe_cycles_per_visit_at_k": {str(k): round(dense - red + price(stage, cost) + (k - 1) * cost["valu"], 1) for k in (1, 4, 9)},
+            "sparse_visit_share": round(sparse_share, 4), "valu_pipe_cycles_per_visit": round(cyc, 1),
+            "note": "cycles from tools/ubench/valu_rates2.hip (launch time x measured clock / wave-instructions, 8 waves per SIMD); "
+                    "mix of the two paths from the replay's hit-lane histogram with the threshold at SGR_SPARSE_K; time bound = visits x cycles / (1024 SIMDs x clock)"}
 
 
 if __name__ == "__main__":
-    what = sys.argv[1] if len(sys.argv) > 1 else "sgr_blend_bwd_kernel_s0<true, true, true>"
-    res = {"default": model("sgr_blend_bwd.hip", what), "parity_mode": model("sgr_blend_bwd.hip", "sgr_blend_bwd_kernel_exact<0>"),
-           "scalar_walk": model("sgr_blend_bwd_sw.hip", "sgr_blend_bwd_sw_kernel<false>")}
+    res = {"default": model("sgr_blend_bwd_kernel_s0<true, true, true>"), "parity_mode": model("sgr_blend_bwd_kernel_exact<0>")}
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     json.dump(res, open(OUT, "w"), indent=1)
     for k, v in res.items():
-        print(k, v["instructions_per_trip"], "VALU-pipe", v["valu_pipe_cycles_per_visit"], "scalar", v["scalar_pipe_cycles_per_visit"])
+        print(k, "dense", v["dense_pipe_cycles_per_visit"], "reduce", v["reduce_scatter_cycles_per_visit"], "sparse@k",
+              v["sparse_pipe_cycles_per_visit_at_k"], "share", v["sparse_visit_share"], "=> per visit", v["valu_pipe_cycles_per_visit"],
+              "clock", v["clock_ghz"])
