@@ -330,6 +330,59 @@ class Workload:
         return R, V, int(n_contrib.to(torch.int64).sum().item())
 
 
+class GpuLoopBackend:
+    """What DensifyLoop runs on: the product path (HIP rasterizer, fused densify kernels, CUDA events).  A test can hand the
+    loop another backend with the same members -- tests/test_multiview_gloo.py runs the unchanged control flow (steps,
+    statistics reduce, replicated densify, reducer rebuild, thresholds) on CPU tensors across two gloo ranks."""
+    reducer_kw = {}  # extra keyword arguments of multiview.FactoredGradReducer (a CPU backend supplies mask_fn / rebuild_fn)
+
+    def __init__(self, dev):
+        self.device = dev
+
+    def rasterizer(self, settings):
+        from diff_gaussian_rasterization import GaussianRasterizer
+        return GaussianRasterizer(settings)
+
+    def settings(self, **kw):
+        from diff_gaussian_rasterization import GaussianRasterizationSettings
+        return GaussianRasterizationSettings(**kw)
+
+    def densify_and_prune(self, *a, **kw):
+        from street_gaussians_amd import densify
+        return densify.densify_and_prune(*a, **kw)
+
+    def last_num_rendered(self):
+        from street_gaussians_amd import rasterizer
+        return rasterizer.last_num_rendered()
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def mark(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def elapsed_ms(self, a, b):
+        return a.elapsed_time(b)
+
+    def reserve(self, n_points):
+        from street_gaussians_amd import densify
+        self.pool = densify.Pool(self.device, factor=1.5, instances_per_point=8.0)
+        nbytes = self.pool.reserve(n_points)
+        torch.cuda.reset_peak_memory_stats(self.device)
+        return nbytes
+
+    def allocator(self):
+        st = torch.cuda.memory_stats(self.device)
+        return {k: int(st.get(k, 0)) for k in ("num_device_alloc", "num_alloc_retries", "num_ooms", "num_device_free",
+                                               "reserved_bytes.all.peak", "allocated_bytes.all.peak")}
+
+    def host_wait_us(self, reset):
+        from street_gaussians_amd import _native
+        return _native.lib().sgr_profile_host_wait_us(reset)
+
+
 class DensifyLoop:
     """BASELINE.json configs[4] as written: 5 M Gaussians, 1920x1280, SH degree 3, with the densify / prune step ACTIVE
     between iterations, so that P, R and the three scratch buffers change under load ("one synthetic densify
@@ -346,14 +399,14 @@ class DensifyLoop:
     and ~5 % pruned per step.  reset_opacity (train.py:207-208) is exercised by tests/test_gpu_densify_loop.py, not here:
     it makes every splat transparent, i.e. it would replace the stress workload by a trivial one."""
 
-    def __init__(self, args, P, dev, densify_every, dist=None, rank=0, force_dist=False):
+    def __init__(self, args, P, dev, densify_every, dist=None, rank=0, force_dist=False, backend=None):
         """dist != None (N > 1, or a forced one-rank group): the configuration as BASELINE.json words it -- Gaussians
         replicated, one camera view per rank, gradients exchanged every step, and the densify step REPLICATED: per-view
         statistics combined across ranks, the same densify_and_prune with the same normals on every rank
         (multiview.densify_replicated), reducers rebuilt for the new P."""
-        from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
         self.args, self.dev, self.every = args, dev, max(1, densify_every)
         self.dist, self.rank, self.force_dist = dist, rank, force_dist
+        self.be = be = backend if backend is not None else GpuLoopBackend(dev)
         self.reducer = self.normals = None
         W, H = args.width, args.height
         cam0 = syn.make_camera(W, H, fx=2050.0 * W / 1920.0)
@@ -366,11 +419,11 @@ class DensifyLoop:
                        "opacity": d(torch.log(op / (1 - op))), "scaling": d(torch.log(sc.scales)), "rotation": d(sc.rotations)}
         self.states = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in self.params.items()}
         self.w = {k: v.to(dev) for k, v in syn.loss_weights(cam, S=0, seed=1 + rank).items()}
-        self.st = GaussianRasterizationSettings(
+        self.st = be.settings(
             image_height=H, image_width=W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=torch.zeros(3, device=dev),
             scale_modifier=1.0, viewmatrix=cam.viewmatrix.to(dev), projmatrix=cam.projmatrix.to(dev), sh_degree=3,
             campos=cam.campos.to(dev), prefiltered=False, debug=False)
-        self.rast = GaussianRasterizer(self.st)
+        self.rast = be.rasterizer(self.st)
         self.kw = None
         self.log = []
         self.max_R = 0
@@ -379,7 +432,7 @@ class DensifyLoop:
             from street_gaussians_amd import multiview
             i = self.inputs
             self.reducer = multiview.FactoredGradReducer([i[k] for k in ("means3D", "scales", "rotations", "opacities")],
-                                                         i["shs"], i["means3D"], force=force_dist)
+                                                         i["shs"], i["means3D"], force=force_dist, **be.reducer_kw)
             self.reducer.warm_up()
             self.normals = multiview.ReplicatedNormals(seed=17)
 
@@ -397,7 +450,6 @@ class DensifyLoop:
         self.rast.stats_sink = self.stats.sink()
 
     def step(self):
-        from street_gaussians_amd import rasterizer
         i, w = self.inputs, self.w
         for t in list(i.values()) + [self.means2D]:
             t.grad = None
@@ -406,7 +458,7 @@ class DensifyLoop:
         torch.autograd.backward([color, depth, alpha], [w["color"], w["depth"], w["alpha"]])
         if self.reducer is not None:
             self.reducer.all_reduce()  # blocking exchange: the step's summed gradients
-        self.max_R = max(self.max_R, rasterizer.last_num_rendered())
+        self.max_R = max(self.max_R, self.be.last_num_rendered())
 
     def calibrate(self):
         """Thresholds from the statistics accumulated so far (untimed): ~10 % of the points over max_grad, half of those
@@ -422,29 +474,29 @@ class DensifyLoop:
                        percent_dense=thr, percent_big_ws=1e9, prune_big=False)
 
     def densify(self):
-        from street_gaussians_amd import densify
-        torch.cuda.synchronize()
+        sync = self.be.sync
+        sync()
         t_r = time.perf_counter()
         if self.dist is not None:
             # replicated densify, step 1: the per-view statistics of all ranks become one (sums / max) -- part of the path
             from street_gaussians_amd import multiview
             multiview.reduce_densification_stats(self.stats.xyz_gradient_accum, self.stats.denom, self.stats.max_radii2D)
-            torch.cuda.synchronize()
+            sync()
         t_c = time.perf_counter()
         self.calibrate()  # this synthetic schedule's thresholds (quantiles): not part of the path, excluded from the totals
-        torch.cuda.synchronize()     # (computed from the combined statistics: the same thresholds on every rank)
+        sync()     # (computed from the combined statistics: the same thresholds on every rank)
         t0 = time.perf_counter()
         self.calib_s += t0 - t_c
         t0 -= t_c - t_r  # the statistics reduce counts as densify time
         # step 2: the same densify_and_prune on every rank, with the same normals (multiview.ReplicatedNormals)
-        new_p, new_s, scal, _ = densify.densify_and_prune(self.params, self.stats.xyz_gradient_accum, self.stats.denom,
+        new_p, new_s, scal, _ = self.be.densify_and_prune(self.params, self.stats.xyz_gradient_accum, self.stats.denom,
                                                           states=self.states, normal_source=self.normals, **self.kw)
         self.params, self.states = new_p, new_s
         self._activate()
         if self.reducer is not None:
             i = self.inputs
             self.reducer.rebuild([i[k] for k in ("means3D", "scales", "rotations", "opacities")], i["shs"], i["means3D"])
-        torch.cuda.synchronize()
+        sync()
         scal = dict(scal)
         scal["ms"] = round(1e3 * (time.perf_counter() - t0), 3)
         scal["gaussians_after"] = self.P
@@ -460,37 +512,35 @@ class DensifyLoop:
 
     def run(self, fence, n_densify=3):
         every = self.every
-        # A densify step re-sizes every buffer: with an empty caching allocator each new size is a device allocation, and
-        # on some hosts hipMalloc of a multi-GB block takes tens of ms (observed: 40 allocations in the region, 20-55 ms
-        # per iteration on those boxes, 3.9 ms on others -- allocator latency, not the path).  A trainer that re-sizes
-        # under load reserves its pool once: one 48 GB block handed back to torch's caching allocator, which then serves
-        # the re-sized buffers by splitting it (288 GB of HBM: there is room).
-        try:
-            pool = torch.empty(48 << 30, dtype=torch.uint8, device=self.dev)
-            del pool
-        except RuntimeError:
-            pass
+        # A densify step re-sizes every buffer; the library's pool (street_gaussians_amd.densify.Pool) reserves 1.5 x the
+        # bytes live at the size the run will reach and hands them to torch's caching allocator (whose requests repeat thanks
+        # to the size ladder, street_gaussians_amd/_alloc.py), so that no device allocation happens inside the loop
+        # (round 4: a fixed 48 GB block reserved here)
+        be = self.be
+        pool_bytes = be.reserve(int(self.P * 1.25))
         for _ in range(every):  # untimed calibration interval (also the warm-up)
             self.step()
         self.calibrate()
         P0, self.max_R, self.calib_s = self.P, 0, 0.0
         steps = every * n_densify
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-        allocs0 = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0)
+        marks = [None] * (steps + 1)
+        allocs0 = be.allocator().get("num_device_alloc", 0)
         host_s = 0.0
         fence()
+        be.host_wait_us(1)
         t0 = time.perf_counter()
         for it in range(steps):
-            marks[it].record()
+            marks[it] = be.mark()
             th = time.perf_counter()
             self.step()
-            host_s += time.perf_counter() - th  # host time to QUEUE the iteration (no synchronisation inside)
+            host_s += time.perf_counter() - th  # wall time of the call; the forward's wait for the GPU is subtracted below
             if it == steps - 1:
-                marks[steps].record()
+                marks[steps] = be.mark()
             if (it + 1) % every == 0:
                 self.densify()
         fence()
         dt = time.perf_counter() - t0 - self.calib_s
+        wait_s = 1e-6 * float(be.host_wait_us(1))  # the host idling at the read-back of num_rendered
         d_ms = sum(x["ms"] for x in self.log)
         # per-iteration GPU time from the event marks: the iteration right after a densify step runs on re-sized buffers
         # (geometry / binning / backward scratch / gradients no longer fit the allocator's cached blocks), the others are
@@ -500,7 +550,7 @@ class DensifyLoop:
             if (it + 1) % every == 0 and it != steps - 1:
                 step_ms.append(None)  # the interval to the next mark contains the densify step
             else:
-                step_ms.append(marks[it].elapsed_time(marks[it + 1]))
+                step_ms.append(be.elapsed_ms(marks[it], marks[it + 1]))
         first_after = [step_ms[it] for it in range(steps) if it % every == 0 and it > 0 and step_ms[it] is not None]
         steady = sorted(v for it, v in enumerate(step_ms) if v is not None and not (it % every == 0 and it > 0))
         return {"config": "configs[4] 5M + densify/prune active in the loop (train.py:187-210)", "gaussians_start": P0,
@@ -510,11 +560,14 @@ class DensifyLoop:
                 "raster_ms_steady_median": round(steady[len(steady) // 2], 4) if steady else None,
                 "raster_ms_first_iteration_after_densify": [round(v, 3) for v in first_after],
                 "densify_ms_mean": round(d_ms / max(1, len(self.log)), 3), "densify_log": self.log,
-                "host_ms_to_queue_one_iteration": round(1e3 * host_s / steps, 3),
-                "device_allocations_in_region": int(torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0) - allocs0),
-                "allocator": {k: int(torch.cuda.memory_stats(self.dev).get(k, 0)) for k in
-                              ("num_alloc_retries", "num_ooms", "num_device_free", "reserved_bytes.all.peak",
-                               "allocated_bytes.all.peak")},
+                "host_ms_to_queue_one_iteration": round(1e3 * max(0.0, host_s - wait_s) / steps, 3),
+                "host_ms_in_step_call_incl_gpu_wait": round(1e3 * host_s / steps, 3),
+                "host_note": "host_ms_to_queue_one_iteration = wall time inside step() minus the time the forward spent waiting for "
+                             "the GPU at its read-back of num_rendered (sgr_profile_host_wait_us): the host's own work per iteration; "
+                             "round 4 printed the wall time, which contains the GPU's previous backward",
+                "pool_bytes_reserved": int(pool_bytes),
+                "device_allocations_in_region": int(be.allocator().get("num_device_alloc", 0) - allocs0),
+                "allocator": be.allocator(),
                 "ranks": (self.dist.get_world_size() if self.dist is not None else 1),
                 "replicas_identical": self._replicas_identical(),
                 "max_num_rendered_R": self.max_R, "thresholds_last": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in self.kw.items()},
@@ -556,18 +609,24 @@ def profiled_steps(L, wl, fence, steps, stage_mask, every=1):
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if os.environ.get("SGR_BENCH_REGION_TRACE") else None
     fence()
     t0 = time.perf_counter()
+    host, waits = [], []
     for i in range(steps):
         if marks:
             marks[i].record()
+            L.sgr_profile_host_wait_us(1)
+            th = time.perf_counter()
         wl.step()
+        if marks:
+            host.append(round(1e3 * (time.perf_counter() - th), 3))
+            waits.append(round(1e-3 * L.sgr_profile_host_wait_us(1), 3))
     wl.drain()  # the last step's exchange belongs to the timed region
     if marks:
         marks[steps].record()
     fence()
     dt = time.perf_counter() - t0
     if marks:  # debug: where a short region loses time (GPU time between the starts of consecutive steps)
-        print("[region-trace]", steps, round(1e3 * dt, 3), [round(marks[i].elapsed_time(marks[i + 1]), 3) for i in range(steps)][:40],
-              file=sys.stderr)
+        print("[region-trace]", steps, round(1e3 * dt, 3), "gpu", [round(marks[i].elapsed_time(marks[i + 1]), 3) for i in range(steps)][:24],
+              "host_call", host[:24], "of_which_wait", waits[:24], file=sys.stderr)
     sums = (C.c_double * 9)()
     counts = (C.c_int * 9)()
     L.sgr_profile_read(sums, counts)
@@ -697,6 +756,12 @@ def main():
     # milliseconds run at ramping clocks (measured: the same build reads 650 it/s in a 20-step region right after start-up and
     # 688 it/s a second later).  Reported as `device_warmup_s`; the timed region is still exactly --steps steps after exactly
     # --warmup steps.
+    L = _native.lib()
+    # the stage timer's events are created here, in front of the warm-up: their creation (2048 events, each recorded once,
+    # a device synchronisation) idles the GPU for tens of milliseconds, after which it needs ~10 steps to come back to its
+    # clocks -- round 4 did this between the warm-up steps and the timed region (the 20-step region read 4 % slow)
+    L.sgr_profile_enable(1)
+    L.sgr_profile_enable(0)
     t_w = time.perf_counter()
     n_w = 0
     while args.device_warmup > 0 and time.perf_counter() - t_w < args.device_warmup:
@@ -707,12 +772,16 @@ def main():
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         wl.step()
-    L = _native.lib()
     # ---- the timed region: EXACTLY args.steps steps between two fences; only the dominant kernel carries events
     # (at most every 8th step whatever --steps is: an event pair drains the queue ~10 us each side of the launch it
     # brackets, which taxed a 20-step region by ~1 % when every step carried one; at least 3 samples)
     every = max(1, min(8, (args.steps - 1) // 2))
     dt, timed = profiled_steps(L, wl, fence, args.steps, 1 << 7, every=every)
+    if os.environ.get("SGR_BENCH_REGION_TRACE"):  # debug: the same region again, and once more after 50 ms of host sleep
+        profiled_steps(L, wl, fence, args.steps, 1 << 7, every=every)
+        time.sleep(0.05)
+        profiled_steps(L, wl, fence, args.steps, 1 << 7, every=every)
+        profiled_steps(L, wl, fence, args.steps, 0, every=every)
     if args.step_times:
         ts = []
         for _ in range(10):

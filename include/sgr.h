@@ -212,6 +212,10 @@ int sgr_export_internal(int which, int P, int R, int width, int height, char* ge
  * mask >= 0 sets them process-wide, mask < 0 only queries; returns the previous mask.  The initial
  * value comes from the environment (SGR_NO_CULL, SGR_NO_DPP, SGR_NO_DET, SGR_NO_HITS, SGR_V2), read once. */
 int sgr_test_switches(int mask);
+/* Microseconds the process's threads have spent in sgr_forward's one host wait (the read-back of num_rendered,
+ * rasterizer_impl.cu:284 in the reference) since the last reset; reset != 0 also clears the counter.  Measurement only: the
+ * time a caller spends inside sgr_forward minus this is the host's own work. */
+int sgr_profile_host_wait_us(int reset);
 
 /* ---- primitive self-tests (used by tests/ on the GPU box) ---------------------------------------------------- */
 int sgr_test_scan(const uint32_t* in, uint32_t* out, size_t n, int inclusive, uint32_t* tmp, void* stream);

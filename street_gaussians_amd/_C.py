@@ -10,6 +10,7 @@ import ctypes as C
 import torch
 
 from . import _native
+from . import _alloc
 from ._native import ALLOC_FN, SgrError, check
 
 NUM_CHANNELS = 3  # config.h:15
@@ -104,7 +105,9 @@ class _Grow:
         self.cb = ALLOC_FN(self._alloc)
 
     def _alloc(self, nbytes, _user):
-        self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        # (a larger block than asked for is fine -- the native side carves what it needs -- and ladder sizes repeat when
+        # the number of Gaussians drifts: _alloc.py)
+        self.tensor = torch.empty(_alloc.ladder(int(nbytes)), dtype=torch.uint8, device=self.device)
         return self.tensor.data_ptr()
 
 
@@ -187,7 +190,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     with torch.cuda.device(dev):
         fopt = dict(dtype=torch.float32, device=dev)
         # every element is written by the kernels (include/sgr.h), so no torch.zeros (rasterize_points.cu:166-176)
-        mk = torch.empty if P else torch.zeros
+        mk = (lambda shape, **kw: _alloc.empty(shape, kw["dtype"], kw["device"])) if P else torch.zeros
         dL_dmeans3D = mk((P, 3), **fopt)
         dL_dmeans2D = mk((P, 3), **fopt)
         dL_dcolors = mk((P, NUM_CHANNELS), **fopt)

@@ -177,7 +177,18 @@ static hipEvent_t readback_event() {
 // queued; 0 = never spin) it falls back to the
 // event, which is also what orders everything else behind the copy.
 #define SGR_READBACK_PENDING 0xffffffffu
+// nanoseconds the calling threads have spent in the forward's host wait (process-wide, sgr_profile_host_wait_us): what a
+// measurement of "host time per step" has to subtract -- the wait is the GPU's time, not the host's
+static std::atomic<unsigned long long> g_wait_ns{0};
+static hipError_t wait_for_readback_(uint32_t* host_vals, hipEvent_t landed);
 static hipError_t wait_for_readback(uint32_t* host_vals, hipEvent_t landed) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t e = wait_for_readback_(host_vals, landed);
+    g_wait_ns.fetch_add((unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(),
+                        std::memory_order_relaxed);
+    return e;
+}
+static hipError_t wait_for_readback_(uint32_t* host_vals, hipEvent_t landed) {
     static const long spin_us = [] { const char* e = getenv("SGR_SPIN_US"); return e ? atol(e) : 2000L; }();
     if (spin_us > 0) {
         volatile uint32_t* hv = host_vals;
@@ -659,6 +670,11 @@ int sgr_sh_grad_from_views_ex(int P, int D, int M, int V, const float* means3D, 
                                   drgb_view_stride, dL_dsh, stream);
     SGR_STAGE("sh_grad_from_views_ex");
     return 0;
+}
+
+int sgr_profile_host_wait_us(int reset) {
+    const unsigned long long ns = reset ? g_wait_ns.exchange(0, std::memory_order_relaxed) : g_wait_ns.load(std::memory_order_relaxed);
+    return (int)std::min<unsigned long long>(ns / 1000ull, 0x7fffffffull);
 }
 
 int sgr_test_switches(int mask) {

@@ -23,7 +23,7 @@ from typing import Dict, Optional, Tuple
 
 import torch
 
-from . import _native
+from . import _alloc, _native
 from ._native import SgrError, check
 
 PARAMS = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "semantic")  # optimiser group names (:409-412)
@@ -40,6 +40,46 @@ _VARIANTS = {None: 0, "base": 0, "bkgd": 1, "actor": 2}
 
 def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+# ---- memory for a loop that re-sizes under load ------------------------------------------------------------------------
+# Every densify step changes N: parameters, gradients, Adam moments and the rasterizer's three scratch buffers come back in
+# new sizes, and with an empty caching allocator every new size is a device allocation (tens of ms for a multi-GB block on
+# some hosts -- in the middle of a training step).  The reference lives with that (torch.cat per parameter,
+# gaussian_model.py:363-407).  Here the trainer reserves ONE block of about twice the bytes that are live at the largest
+# size it expects and hands it straight back to torch's caching allocator, which then serves every re-sized tensor by
+# splitting it: no device allocation inside the loop.  The pool belongs to the library (round 4 left a fixed 48 GB
+# reservation in bench.py); it grows by an eighth when the estimate outgrows it and never exceeds `factor` x live.
+def live_bytes_estimate(n_points: int, sh_coeffs: int = 16, semantic_channels: int = 0, instances_per_point: float = 8.0) -> int:
+    """Bytes live at n_points Gaussians in one training iteration: raw parameters, gradients, two Adam moments, the activated
+    rasterizer inputs with their gradients, the geometry / binning buffers and the backward's partial rows
+    (140 B per Gaussian, 18.5 + 48 B per tile instance)."""
+    per_point = 4 * (3 + 3 * sh_coeffs + 1 + 3 + 4 + semantic_channels)  # one copy of the parameters
+    inst = int(instances_per_point * n_points)
+    return int(n_points * (4 * per_point + 2 * per_point + 140 + 64) + inst * (18.5 + 48 + 4 * semantic_channels))
+
+
+class Pool:
+    """reserve(n_points): makes sure torch's caching allocator holds one free block of `factor` x the live-bytes estimate
+    (head-room for the size steps of the ladder, _alloc.py, and for the densify step itself, where the old and the new
+    parameters + Adam moments are alive together)."""
+
+    def __init__(self, device, factor: float = 1.5, **estimate_kw):
+        self.device, self.factor, self.kw = torch.device(device), float(factor), estimate_kw
+        self.reserved = 0  # bytes of the block handed to the allocator so far
+
+    def reserve(self, n_points: int) -> int:
+        want = int(self.factor * live_bytes_estimate(n_points, **self.kw))
+        if want <= self.reserved:
+            return self.reserved
+        want = max(want, self.reserved + self.reserved // 8)
+        try:
+            blk = torch.empty(want, dtype=torch.uint8, device=self.device)
+            del blk  # stays with the caching allocator as one free block
+            self.reserved = want
+        except RuntimeError:
+            self.reserved = 0  # not enough memory for the head-room: the loop falls back to allocating as it goes
+        return self.reserved
 
 
 def densify_and_prune(params: Dict[str, torch.Tensor], xyz_gradient_accum: torch.Tensor, denom: torch.Tensor, *,
@@ -89,7 +129,7 @@ def densify_and_prune(params: Dict[str, torch.Tensor], xyz_gradient_accum: torch
         def gather(t, zero_new):
             t = f32(t)
             width = t[0].numel() if N else 0
-            out = torch.empty((n_out,) + tuple(t.shape[1:]), dtype=torch.float32, device=dev)
+            out = _alloc.empty((n_out,) + tuple(t.shape[1:]), torch.float32, dev)  # ladder-sized backing: see _alloc.py
             check(L.sgr_densify_gather(n_out, width, _p(t), _p(src), _p(kind), int(zero_new), _p(out), stream))
             return out
 
@@ -113,7 +153,7 @@ def densify_and_prune(params: Dict[str, torch.Tensor], xyz_gradient_accum: torch
 def _gather(L, t, src, kind, n_out, zero_new, stream, N):
     t = t.detach().to(torch.float32).contiguous()
     width = t[0].numel() if N else 0
-    out = torch.empty((n_out,) + tuple(t.shape[1:]), dtype=torch.float32, device=t.device)
+    out = _alloc.empty((n_out,) + tuple(t.shape[1:]), torch.float32, t.device)
     check(L.sgr_densify_gather(n_out, width, _p(t), _p(src), _p(kind), int(zero_new), _p(out), stream))
     return out
 

@@ -371,3 +371,158 @@ def test_replicated_densify_keeps_the_replicas_identical_world2(mode):
     for p in procs:
         p.join(timeout=60)
     assert all(not f for _, f in res), res
+
+
+# ---- bench.py's `--densify-loop` rank program (BASELINE configs[4] as worded: replicated Gaussians, one view per rank, the
+# gradient exchange every iteration, replicated densify / prune every k-th) on two gloo ranks.  bench.DensifyLoop runs
+# UNCHANGED -- step, statistics reduce, thresholds, densify_and_prune with the replicated normals, re-activation, reducer
+# rebuild, the timing / report code -- on a CPU backend: a differentiable rasterizer made of the C oracle's tile lists and
+# the float64 torch restatement (tests/torch_ref.py) that reports to the backward observers and the statistics sink the way
+# GaussianRasterizer does, and the torch restatement of the reference's densify_and_prune (tests/torch_ref_densify.py).
+class _TorchRefRasterizer:
+    def __init__(self, st, backend):
+        self.st, self.be, self.stats_sink = st, backend, None
+
+    def __call__(self, means3D, means2D, opacities, shs=None, scales=None, rotations=None, **_):
+        import numpy as np
+        import torch_ref
+        from oracle import oracle
+        from street_gaussians_amd import rasterizer
+        st = self.st
+        H, W = int(st.image_height), int(st.image_width)
+        d = lambda t: t.detach().float()
+        fw = oracle.forward(means3D=d(means3D), opacities=d(opacities), viewmatrix=st.viewmatrix, projmatrix=st.projmatrix,
+                            campos=st.campos, bg=st.bg, tanfovx=st.tanfovx, tanfovy=st.tanfovy, image_height=H, image_width=W,
+                            sh_degree=st.sh_degree, shs=d(shs), scales=d(scales), rotations=d(rotations))
+        self.be.num_rendered = int(fw.num_rendered)
+        radii = torch.from_numpy(np.asarray(fw.radii).astype(np.int32))
+        point_list = torch.from_numpy(np.asarray(fw.point_list).astype(np.int64)) if fw.num_rendered else torch.zeros(0, dtype=torch.int64)
+        ranges = torch.from_numpy(np.asarray(fw.ranges).astype(np.int64).reshape(-1, 2))
+        fw.free()
+        pre = torch_ref.preprocess(means3D.double(), st.viewmatrix, st.projmatrix, st.campos, st.tanfovx, st.tanfovy, W, H,
+                                   st.sh_degree, opacities.double(), shs=shs.double(), scales=scales.double(),
+                                   rotations=rotations.double())
+        # the screen-space handle: its gradient is dL/dmean2D (the reference's `screenspace_points`)
+        pre["pix"] = pre["pix"] + means2D[:, :2].double()
+        n, vis = means3D.shape[0], radii > 0
+        if pre["rgb"].requires_grad:
+            clamped = pre["clamped"]
+            pre["rgb"].register_hook(lambda g: [obs(grad_colors=g.float(), geomBuffer=clamped, campos=st.campos,
+                                                    sh_degree=st.sh_degree, num_points=n, means3D=means3D.detach())
+                                                for obs in list(rasterizer.BACKWARD_OBSERVERS)] and None)
+        if self.stats_sink is not None and means2D.requires_grad:
+            acc, den, mr = self.stats_sink[:3]
+
+            def stats(g):  # set_max_radii2D + add_densification_stats (street_gaussian_model.py:551-571)
+                acc[vis, 0] += g[vis, :2].norm(dim=1).float()
+                acc[vis, 1] += g[vis, 2].abs().float()
+                den[vis] += 1.0
+                mr[vis] = torch.maximum(mr[vis], radii[vis].float())
+            means2D.register_hook(stats)
+        color, depth, alpha, _, _ = torch_ref.render(pre, point_list, ranges, W, H, st.bg)
+        return color.float(), radii, depth.float(), alpha.float(), None
+
+
+class _CpuLoopBackend:
+    """bench.GpuLoopBackend's members on CPU tensors."""
+
+    def __init__(self):
+        self.device, self.num_rendered = torch.device("cpu"), 0
+        self.reducer_kw = dict(mask_fn=lambda geom, gc, n: gc * (~geom).float(), rebuild_fn=_rebuild_ref)
+
+    def settings(self, **kw):
+        from types import SimpleNamespace
+        return SimpleNamespace(**kw)
+
+    def rasterizer(self, st):
+        return _TorchRefRasterizer(st, self)
+
+    def densify_and_prune(self, params, accum, denom, **kw):
+        # (like the fused kernels, the result carries no autograd history: xyz doubles as the rasterizer's leaf input)
+        params = {k: v.detach() for k, v in params.items()}
+        params.setdefault("semantic", torch.zeros(params["xyz"].shape[0], 0))
+        states = {k: (a.detach(), b.detach()) for k, (a, b) in kw.pop("states").items()}
+        states.setdefault("semantic", (torch.zeros_like(params["semantic"]), torch.zeros_like(params["semantic"])))
+        with torch.no_grad():
+            new_p, new_s, sc, idx = _densify_cpu(params, accum, denom, states=states, **kw)
+        new_p, new_s = dict(new_p), dict(new_s)
+        new_p.pop("semantic", None), new_s.pop("semantic", None)
+        return {k: v.detach().clone() for k, v in new_p.items()}, {k: (a.detach().clone(), b.detach().clone()) for k, (a, b) in new_s.items()}, sc, idx
+
+    def last_num_rendered(self):
+        return self.num_rendered
+
+    def sync(self):
+        pass
+
+    def mark(self):
+        import time
+        return time.perf_counter()
+
+    def elapsed_ms(self, a, b):
+        return 1e3 * (b - a)
+
+    def reserve(self, n_points):
+        return 0
+
+    def allocator(self):
+        return {}
+
+    def host_wait_us(self, reset):
+        return 0
+
+
+def _loop_worker(rank, world, port, q):
+    import sys
+    from types import SimpleNamespace
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    import bench
+    args = SimpleNamespace(width=64, height=48, reduce="factored", exchange="blocking")
+    failed = []
+    try:
+        loop = bench.DensifyLoop(args, 220, torch.device("cpu"), 2, dist=dist, rank=rank, force_dist=False,
+                                 backend=_CpuLoopBackend())
+        p0 = {k: v.clone() for k, v in loop.params.items()}
+        res = loop.run(lambda: dist.barrier(), n_densify=2)
+        if not (res["ranks"] == world and res["densify_steps"] == 2 and res["steps"] == 4):
+            failed.append(("shape of the run", {k: res[k] for k in ("ranks", "densify_steps", "steps")}))
+        if res["replicas_identical"] is not True:
+            failed.append(("replicas diverged", res["replicas_identical"]))
+        if res["gaussians_end"] == res["gaussians_start"] or not all(x["points_clone"] + x["points_split"] > 0 for x in res["densify_log"]):
+            failed.append(("densify did nothing", res["densify_log"]))
+        if loop.params["xyz"].shape[0] != res["gaussians_end"] or loop.inputs["shs"].shape[0] != res["gaussians_end"]:
+            failed.append(("inputs not re-activated", loop.inputs["shs"].shape))
+        if res["max_num_rendered_R"] <= 0:
+            failed.append(("nothing rendered", res["max_num_rendered_R"]))
+        # the exchange really summed over the two views: one more step, then every rank holds the same gradients, and the SH
+        # gradient is the sum of the two views' (not this rank's own)
+        loop.step()
+        grads = [loop.inputs[k].grad for k in ("means3D", "scales", "rotations", "opacities", "shs")]
+        from street_gaussians_amd import multiview
+        if not multiview.replicas_identical(grads):
+            failed.append(("summed gradients differ between ranks", None))
+        del p0
+    except Exception as ex:  # noqa: BLE001 -- reported to the parent
+        import traceback
+        failed.append(("exception", traceback.format_exc()[-1500:]))
+    q.put((rank, failed))
+    dist.destroy_process_group()
+
+
+def test_bench_densify_loop_rank_program_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_loop_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(not f for _, f in res), res
