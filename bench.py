@@ -368,7 +368,7 @@ class GpuLoopBackend:
 
     def reserve(self, n_points):
         from street_gaussians_amd import densify
-        self.pool = densify.Pool(self.device, factor=1.5, instances_per_point=8.0)
+        self.pool = densify.Pool(self.device, factor=1.25, instances_per_point=8.0)
         nbytes = self.pool.reserve(n_points)
         torch.cuda.reset_peak_memory_stats(self.device)
         return nbytes
@@ -512,7 +512,7 @@ class DensifyLoop:
 
     def run(self, fence, n_densify=3):
         every = self.every
-        # A densify step re-sizes every buffer; the library's pool (street_gaussians_amd.densify.Pool) reserves 1.5 x the
+        # A densify step re-sizes every buffer; the library's pool (street_gaussians_amd.densify.Pool) reserves 1.25 x the
         # bytes live at the size the run will reach and hands them to torch's caching allocator (whose requests repeat thanks
         # to the size ladder, street_gaussians_amd/_alloc.py), so that no device allocation happens inside the loop
         # (round 4: a fixed 48 GB block reserved here)
@@ -865,6 +865,53 @@ def main():
         for _ in range(3):
             wl.step()
     parity_mode = modes.get("exact")
+    # ---- the step without a host wait (sgr_set_lazy, opt-in: include/sgr.h) and the same step replayed from a hipGraph:
+    # extra regions, never the reported value
+    lazy_info = None
+    if world == 1 and dist is None and S == 0:
+        try:
+            from street_gaussians_amd import _C as native_c
+            was = native_c.set_lazy(True)
+            try:
+                for _ in range(3):
+                    wl.step()
+                n_l = max(args.steps, int(0.4 / max(dt / args.steps, 1e-5)) + 1)
+                ldt, _ = profiled_steps(L, wl, fence, n_l, 0)
+                torch.cuda.synchronize()
+                R_l, cap_l, fl_l = native_c.lazy_status()
+                lazy_info = {"ms_per_step_lazy": round(1e3 * ldt / n_l, 4), "steps": n_l, "num_rendered": R_l, "capacity": cap_l,
+                             "flags": fl_l}
+                p, w = wl.params, wl.w
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    wl.step()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                for t in list(p.values()) + [wl.means2D]:
+                    t.grad = None
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    color, radii, depth, alpha, _ = wl.rast(p["means3D"], wl.means2D, p["opacities"], shs=p["shs"],
+                                                            scales=p["scales"], rotations=p["rotations"])
+                    torch.autograd.backward([color, depth, alpha], [w["color"], w["depth"], w["alpha"]])
+                for _ in range(5):
+                    g.replay()
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(n_l):
+                    g.replay()
+                fence()
+                gdt = time.perf_counter() - t0
+                lazy_info["ms_per_step_graph"] = round(1e3 * gdt / n_l, 4)
+                lazy_info["graph_status"] = dict(zip(("num_rendered", "capacity", "flags"), native_c.lazy_status()))
+                del g
+            finally:
+                native_c.set_lazy(was)
+            for _ in range(3):
+                wl.step()
+        except Exception as ex:  # an extra: never lose the headline over it
+            lazy_info = dict(lazy_info or {}, error=f"{type(ex).__name__}: {ex}"[:300])
     R, V, pairs_blended = wl.counts()
     wl_R_emitted = wl.R_emitted  # default mode (the mode regions above ran wl.counts() under their own switches)
     N = args.width * args.height
@@ -1033,6 +1080,10 @@ def main():
                                  "(+ SGR_REF_RECT=1): additionally the reference's tile rects, binning arrays entry for entry; "
                                  "`value` = default arithmetic (v_exp_f32 on a pre-scaled conic, Newton-refined reciprocal, "
                                  "contraction) on the cut-down tile lists: same algorithm, different last bits (DESIGN.md section 4)")
+        if lazy_info is not None:
+            line["lazy"] = dict(lazy_info, what="sgr_set_lazy(1): list capacity from the previous frames, no host wait in the step "
+                                "(ms_per_step_lazy: eager launches; ms_per_step_graph: forward + backward captured once in a "
+                                "hipGraph and replayed); bit-identical outputs (tests/test_gpu_graph.py); opt-in, not `value`")
         if exchange_overlap is not None:
             line["exchange_overlap"] = exchange_overlap
         if world == 1 and dist is None and not args.no_other_configs and not args.scene:
@@ -1062,6 +1113,7 @@ def main():
             "value_exact": line["value_exact"], "ms_per_step_exact": line["ms_per_step_exact"],
             "value_strict": line["value_strict"], "ms_per_step_strict": line["ms_per_step_strict"],
             "sustained_ms_per_step": g(sustained, "ms_per_step"),
+            "ms_per_step_lazy": g(lazy_info, "ms_per_step_lazy"), "ms_per_step_graph": g(lazy_info, "ms_per_step_graph"),
             "blend_bwd_ms": {"default": g(rl_default, "kernel_ms"), "exact": g(rl_modes.get("exact"), "kernel_ms"),
                              "strict": g(rl_modes.get("strict"), "kernel_ms")},
             "blend_bwd_hbm_frac_on_processed_instances": {"default": g(rl_default, "frac"), "exact": g(rl_modes.get("exact"), "frac"),

@@ -27,6 +27,7 @@ extern "C" {
 #define SGR_E_ALLOC 3     /* a scratch callback returned NULL                                   */
 #define SGR_E_PREFILTER 4 /* prefiltered=1 but a Gaussian failed the frustum test
                              (reference: device printf + __trap(), cuda_rasterizer/auxiliary.h:156-161) */
+#define SGR_E_LAZY 5      /* lazy mode (sgr_set_lazy): the PREVIOUS forward of this thread was invalid -- discard its outputs */
 
 /* Growable device scratch supplied by the caller: must return a device pointer to at least `nbytes`
  * bytes that stays valid until the matching backward has run.  Replaces std::function<char*(size_t)>
@@ -212,6 +213,25 @@ int sgr_export_internal(int which, int P, int R, int width, int height, char* ge
  * mask >= 0 sets them process-wide, mask < 0 only queries; returns the previous mask.  The initial
  * value comes from the environment (SGR_NO_CULL, SGR_NO_DPP, SGR_NO_DET, SGR_NO_HITS, SGR_V2), read once. */
 int sgr_test_switches(int mask);
+/* 1 when the library was built with -DSGR_WITH_VARIANTS=1 (tools/build_variant.py): it then also contains the designs that
+ * were measured slower and are kept as A/Bs -- the transposed-accumulation and scalar-walk blend backward, the one-sweep
+ * radix sorts, the wave-cooperative row sum (sgr_test_switches bits 4, 5, 8, 9).  The shipped library returns 0 and
+ * ignores those bits. */
+int sgr_has_variants(void);
+/* ---- the forward without a host wait (extension; the reference blocks on num_rendered, rasterizer_impl.cu:284) ---------
+ * sgr_set_lazy(1) (or SGR_LAZY=1 in the environment): from a thread's second forward on, the instance-list buffers get a
+ * capacity derived from the previous frames' num_rendered (+ 1/16), duplicate / sort / tile ranges run over the whole
+ * capacity, nothing waits for the read-back, and sgr_forward RETURNS THE CAPACITY (hand it to sgr_backward as R like any
+ * num_rendered).  The checks the host would have made at the wait happen one call late: the next lazy sgr_forward of the
+ * thread returns -SGR_E_LAZY when the previous frame had more instances than its capacity, a prefilter violation or a
+ * depth beyond the 27-bit depth keys -- that frame's outputs are invalid -- and the thread then runs one blocking forward.
+ * No call on this path synchronises, so forward + backward can be captured in a hipGraph (inside a capture the late check is
+ * skipped: ask sgr_lazy_status after a synchronisation).  on < 0 only queries; returns the previous setting. */
+int sgr_set_lazy(int on);
+/* The thread's most recent lazy forward, once its stream has been synchronised: the frame's real num_rendered, the
+ * capacity it ran with, flags (bit 0 overflow, bit 1 prefilter violation, bit 2 depth beyond the narrow depth sort). */
+int sgr_lazy_status(int* num_rendered, int* capacity, int* flags);
+
 /* Microseconds the process's threads have spent in sgr_forward's one host wait (the read-back of num_rendered,
  * rasterizer_impl.cu:284 in the reference) since the last reset; reset != 0 also clears the counter.  Measurement only: the
  * time a caller spends inside sgr_forward minus this is the host's own work. */

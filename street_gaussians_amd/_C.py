@@ -97,18 +97,28 @@ def _fptr(t, name="tensor"):
 
 
 class _Grow:
-    """Growable byte buffer handed to the C side (resizeFunctional, rasterize_points.cu:27-33)."""
+    """Growable byte buffer handed to the C side (resizeFunctional, rasterize_points.cu:27-33).
+
+    The callback closes over a one-element holder, NOT over this object: a bound method (`ALLOC_FN(self._alloc)`) made
+    `_Grow -> callback -> method -> _Grow` a reference cycle, and the buffer -- hundreds of MB of backward scratch per
+    call -- stayed allocated until Python's cyclic collector ran (round 5, tools/densify_gc_trace.py: +1.25 GB per
+    iteration at 5 M Gaussians for ~10 iterations in a row; the densify loop's "device allocations in the region")."""
 
     def __init__(self, device):
-        self.device = device
-        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
-        self.cb = ALLOC_FN(self._alloc)
+        holder = [torch.empty(0, dtype=torch.uint8, device=device)]
 
-    def _alloc(self, nbytes, _user):
-        # (a larger block than asked for is fine -- the native side carves what it needs -- and ladder sizes repeat when
-        # the number of Gaussians drifts: _alloc.py)
-        self.tensor = torch.empty(_alloc.ladder(int(nbytes)), dtype=torch.uint8, device=self.device)
-        return self.tensor.data_ptr()
+        def alloc(nbytes, _user, holder=holder, device=device):
+            # (a larger block than asked for is fine -- the native side carves what it needs -- and ladder sizes repeat
+            # when the number of Gaussians drifts: _alloc.py)
+            holder[0] = torch.empty(_alloc.ladder(int(nbytes)), dtype=torch.uint8, device=device)
+            return holder[0].data_ptr()
+
+        self._holder = holder
+        self.cb = ALLOC_FN(alloc)
+
+    @property
+    def tensor(self):
+        return self._holder[0]
 
 
 def _stream(device):
@@ -376,6 +386,24 @@ def sh_grad_from_rows(P, degree, M, V, means_ptr, means_stride, campos_ptr, camp
 
 
 NO_CULL, NO_DPP, NO_DET, NO_HITS, USE_V2, USE_ONESWEEP, PRE_STAGE_SH, EXACT, USE_SW, USE_RS_WAVE = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
+def has_variants() -> bool:
+    """True when the loaded library also holds the rejected A/B designs (USE_V2, USE_ONESWEEP, USE_SW, USE_RS_WAVE): a
+    tools/build_variant.py build with -DSGR_WITH_VARIANTS=1.  The shipped library ignores those switches."""
+    return bool(_native.lib().sgr_has_variants())
+
+
+def set_lazy(on: bool) -> bool:
+    """sgr_set_lazy: the forward without a host wait (include/sgr.h).  Returns the previous setting."""
+    return bool(_native.lib().sgr_set_lazy(1 if on else 0))
+
+
+def lazy_status():
+    """sgr_lazy_status of the calling thread -> (num_rendered, capacity, flags); synchronise the stream first."""
+    r, c, f = C.c_int(0), C.c_int(0), C.c_int(0)
+    check(_native.lib().sgr_lazy_status(C.byref(r), C.byref(c), C.byref(f)))
+    return r.value, c.value, f.value
+
+
 NO_TILE_MASK = 2048  # bounding-box rects without the per-tile mask (A/B)
 REF_RECT = 1024  # emit every Gaussian for the reference's whole tile rect (default: cut down to where alpha >= 1/255 is possible)
 

@@ -15,8 +15,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libsgr_hip.so")
-SOURCES = ["sgr_preprocess.hip", "sgr_scan_sort.hip", "sgr_blend_fwd.hip", "sgr_blend_bwd.hip", "sgr_blend_bwd_sw.hip", "sgr_gauss_bwd.hip", "sgr_gauss_bwd_strict.hip",
+SOURCES = ["sgr_preprocess.hip", "sgr_scan_sort.hip", "sgr_blend_fwd.hip", "sgr_blend_bwd.hip", "sgr_gauss_bwd.hip", "sgr_gauss_bwd_strict.hip",
            "sgr_knn.hip", "sgr_multiview.hip", "sgr_scene.hip", "sgr_loss.hip", "sgr_densify.hip", "sgr_api.hip"]
+# Designs that were built, measured slower on MI355X and kept as A/B records: the scalar-walk blend
+# backward (its own file), and -- behind `#if SGR_WITH_VARIANTS` inside the files above -- the transposed-accumulation
+# backward, the one-sweep radix sorts and the wave-cooperative row sum.  NOT part of the shipped library:
+# `python tools/build_variant.py <name> -DSGR_WITH_VARIANTS=1` builds a library that contains them (sgr_has_variants() = 1),
+# and the tests of those paths run only against such a build.
+VARIANT_SOURCES = [os.path.join("variants", "sgr_blend_bwd_sw.hip")]
 HEADERS = ["sgr_common.h", "sgr_math.h", "sgr_reduce.h", os.path.join("..", "..", "include", "sgr.h"),
            os.path.join("..", "..", "include", "sgr_scene.h"), os.path.join("..", "..", "include", "sgr_loss.h"), os.path.join("..", "..", "include", "sgr_densify.h")]
 # -fno-slp-vectorize: hipcc's SLP pass packs neighbouring scalar f32 ops into v_pk_* and pays for it with v_mov

@@ -25,8 +25,8 @@ void sgr_launch_filter(int P, const float* means3D, const float* scales, const f
                        const float* cov3D_precomp, const SgrCamArgs& ca, const SgrGeomView& gv, int* radii,
                        float* means2D, int prefiltered, hipStream_t s);
 void sgr_launch_duplicate(int P, const SgrGeomView& gv, const uint32_t* order, const uint32_t* bsum, const uint32_t* sub, uint32_t* keys,
-                          uint32_t* vals, int gx, hipStream_t s);
-void sgr_launch_tile_ranges(int L, const uint32_t* keys, uint2* ranges, uint8_t* touched, hipStream_t s);
+                          uint32_t* vals, int gx, uint32_t cap, hipStream_t s);
+void sgr_launch_tile_ranges(int L, const uint32_t* keys, uint2* ranges, uint8_t* touched, uint32_t T, hipStream_t s);
 void sgr_launch_compose_keys(int L, const uint32_t* tile_keys, const uint32_t* point_list, const float4* rec, uint64_t* out,
                              hipStream_t s);
 void sgr_launch_blend_fwd(bool cull, bool exact, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W, int H,
@@ -81,6 +81,12 @@ static bool env_flag(const char* name) {
 // sgr_test_switches(); the environment (SGR_NO_CULL / SGR_NO_DPP / SGR_NO_DET / SGR_NO_HITS / SGR_V2) only provides the
 // initial value, read ONCE -- the per-step path is one relaxed atomic load, no getenv.
 static std::atomic<int> g_switches{-1};
+#ifndef SGR_WITH_VARIANTS
+#define SGR_WITH_VARIANTS 0  // 1: the library also holds the designs that were measured slower (tools/build_variant.py)
+#endif
+// switch bits that select one of those designs: transposed backward (4), one-sweep sorts (5), scalar-walk backward (8),
+// wave-cooperative row sum (9) -- ignored by a build that does not contain them
+#define SGR_VARIANT_BITS (16 | 32 | 256 | 512)
 static int switches() {
     int v = g_switches.load(std::memory_order_relaxed);
     if (v < 0) {
@@ -88,6 +94,7 @@ static int switches() {
             (env_flag("SGR_NO_HITS") ? 8 : 0) | (env_flag("SGR_V2") ? 16 : 0) | (env_flag("SGR_PRE_STAGE") ? 64 : 0) |
             (env_flag("SGR_EXACT") ? 128 : 0) | ((env_flag("SGR_SW8") || env_flag("SGR_SW")) ? 256 : 0) | ((env_flag("SGR_SW9") || env_flag("SGR_RS_WAVE")) ? 512 : 0) |
             (env_flag("SGR_REF_RECT") ? 1024 : 0) | (env_flag("SGR_NO_TILE_MASK") ? 2048 : 0);
+        if (!SGR_WITH_VARIANTS) v &= ~SGR_VARIANT_BITS;
         g_switches.store(v, std::memory_order_relaxed);
     }
     return v;
@@ -272,6 +279,42 @@ static void pack_camera(const SgrGeomView& gv, const float* view, const float* p
                                              gx, gy, scale_modifier, gv.header, ranges, T);
 }
 
+// ---- the forward without a host wait (sgr_set_lazy) ---------------------------------------------------------------
+// The reference reads num_rendered back before it can size the binning buffer and launch the sort (rasterizer_impl.cu:284);
+// so does sgr_forward by default -- one host wait per step.  In lazy mode the list buffers get a CAPACITY derived from the
+// previous frames' R (+ 1/16 + 1024) instead: duplicate, sort and tile ranges run over all `cap` slots (the slots behind
+// the frame's instances carry a key above every tile id and sort to the end), the read-back is still queued but nobody
+// waits for it, and the value sgr_forward returns -- and sgr_backward takes -- is the capacity.  What the host would have
+// checked at the wait is checked ONE CALL LATE, at the next lazy forward of the thread (or by sgr_lazy_status after a
+// synchronisation): R > capacity, a Gaussian failing the frustum test under prefiltered = 1, a depth beyond the 27-bit
+// sort keys.  Such a frame's outputs are invalid; the call that finds out returns SGR_E_LAZY and the thread goes through
+// one blocking forward to re-seed the capacity.  The first forward of a thread is always blocking.  Nothing on this path
+// synchronises, so a step (forward + backward) can be captured in a hipGraph and replayed (tests/test_gpu_graph.py); the
+// checks are then the caller's (sgr_lazy_status).  Opt-in because of the late error: right for a fixed camera rig or a
+// captured step, wrong for a trainer that draws a new view with a very different R every iteration.
+static std::atomic<int> g_lazy{-1};
+static bool lazy_on() {
+    int v = g_lazy.load(std::memory_order_relaxed);
+    if (v < 0) {
+        v = env_flag("SGR_LAZY") ? 1 : 0;
+        g_lazy.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+struct LazyPending {
+    bool pending = false;       // a lazy forward's read-back has not been looked at yet
+    uint32_t cap = 0;           // the capacity that forward ran with
+    uint32_t* host_vals = nullptr;
+    hipEvent_t landed = nullptr;
+    bool wide = false;          // it sorted the depths on all 32 bits
+};
+static thread_local LazyPending t_lazy;
+// 0 = fine, else a bit set: 1 R > capacity, 2 prefilter violation, 4 far depth with the narrow depth sort
+static int lazy_flags(const LazyPending& lp) {
+    const uint32_t* hv = lp.host_vals;
+    return (hv[4] > lp.cap ? 1 : 0) | ((hv[0] & 1u) ? 2 : 0) | (((hv[2] & 1u) && !lp.wide) ? 4 : 0);
+}
+
 // One 256-byte device block per DEVICE for the whole process (allocated on first use, kept): the flag word of
 // sgr_visible_filter's `prefiltered` check and the counters of sgr_densify_prune_mask.  Both users finish with a stream
 // synchronisation, so the block is handed out under a mutex that is held until they return -- no per-thread allocations
@@ -358,7 +401,71 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     char* bbase = nullptr;
     size_t have_bytes = 0;
     static thread_local size_t r_hint = 0;
-    for (int attempt = 0; attempt < 2; attempt++) {
+
+    // ---- lazy mode (sgr_set_lazy): what the previous lazy forward of this thread left to check
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &cap_status);
+    const bool capturing = cap_status != hipStreamCaptureStatusNone;
+    if (t_lazy.pending && !capturing) {
+        t_lazy.pending = false;
+        SGR_HIP(wait_for_readback(t_lazy.host_vals, t_lazy.landed));  // queued a whole step ago: landed long since
+        const int fl = lazy_flags(t_lazy);
+        if (t_lazy.host_vals[2] & 1u) wide_left = 64;
+        if (fl) {
+            r_hint = 0;  // the next forward of this thread is a blocking one: it re-seeds the capacity
+            return fail(SGR_E_LAZY, std::string("the PREVIOUS lazy forward of this thread was invalid (") +
+                        ((fl & 1) ? "more tile instances than the list capacity; " : "") +
+                        ((fl & 2) ? "a Gaussian failed the frustum test although prefiltered is set; " : "") +
+                        ((fl & 4) ? "a view depth beyond the 27-bit depth keys; " : "") + "its outputs must be discarded)");
+        }
+        // high-water mark with a slow decay, as in the blocking path (lazy: 1/16 of head-room -- the sort runs over it)
+        const size_t Rp = t_lazy.host_vals[4];
+        r_hint = std::max(Rp + Rp / 16 + 1024, r_hint - r_hint / 64);
+    }
+    const bool lazy = lazy_on() && r_hint > 0;
+
+    int R = 0;
+    uint32_t cap = 0;  // lazy: slots of the instance list
+    if (lazy) {
+        prof_begin(0, stream);
+        pack_camera(gv, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, W, H, scale_modifier, iv.ranges, (int)T, stream);
+        SGR_STAGE("pack_camera");
+        sgr_launch_preprocess(P, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
+                              cam_slot(gv), gv, radii_ptr, prefiltered, (switches() & 64) != 0 || P >= pre_stage_min_p(),
+                              (switches() & 1024) ? 0 : ((switches() & 2048) ? 1 : 2), stream);
+        SGR_STAGE("preprocess");
+        prof_end(stream);
+        host_vals = pinned_pair();
+        hipEvent_t landed = readback_event();
+        if (!host_vals || !landed) return fail(SGR_E_HIP, "pinned readback slot / event creation failed");
+        if (!capturing) host_vals[0] = host_vals[2] = host_vals[4] = host_vals[5] = SGR_READBACK_PENDING;
+        SGR_HIP(hipMemcpyAsync(host_vals, gv.header, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        if (!capturing) SGR_HIP(hipEventRecord(landed, stream));
+        prof_begin(1, stream);
+        const int dcur = sgr_launch_sort_pairs32(gv.dkeys, gv.dvals, (uint32_t)P, wide_depth ? 32 : SGR_DEPTH_KEY_BITS, gv.dhist,
+                                                 gv.scan_tmp, stream, true, gv.aux, gv.aux_sorted, P < 750000 ? 9 : 8);
+        order = gv.dvals[dcur];
+        sgr_launch_scan_head(reinterpret_cast<const uint32_t*>(gv.aux_sorted), reinterpret_cast<const uint32_t*>(gv.aux), (size_t)P,
+                             2, gv.scan_tmp, gv.sub_sums, stream);
+        SGR_STAGE("depth_sort+scan");
+        prof_end(stream);
+        {   // capacity on the coarse ladder of the blocking path (consecutive calls ask for the same block size)
+            size_t hq = r_hint, step = 1;
+            while ((step << 1) <= hq) step <<= 1;
+            step = std::max<size_t>(step >> 4, 1024);
+            hq = (hq + step - 1) / step * step;
+            cap = (uint32_t)std::min<size_t>(hq, 0x7fffffffu);
+        }
+        bbase = binning_buffer(sgr_binning_bytes((int)cap), binning_user);
+        if (!bbase) return fail(SGR_E_ALLOC, "binning buffer allocation failed");
+        R = (int)cap;  // what the caller hands to sgr_backward: it sizes the same carving there
+        t_lazy.pending = !capturing;
+        t_lazy.cap = cap;
+        t_lazy.host_vals = host_vals;
+        t_lazy.landed = landed;
+        t_lazy.wide = wide_depth;
+    }
+    for (int attempt = 0; attempt < 2 && !lazy; attempt++) {
         prof_begin(0, stream);
         pack_camera(gv, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, W, H, scale_modifier, iv.ranges, (int)T, stream);
         SGR_STAGE("pack_camera");
@@ -445,35 +552,38 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
         wide_depth = true;
         wide_left = 64;
     }
-    if (host_vals[0] & 1u)
-        return fail(SGR_E_PREFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
-    // (host_vals[5], what num_rendered would be with the reference's rects, is reporting only -- export 17, best effort: it
-    // shares a 64-bit atomic with the emitted count and is not a reason to refuse a frame whose emitted list fits)
-    if (host_vals[4] > 0x7fffffffu) return fail(SGR_E_INVALID, "more than 2^31 tile instances");
-    const int R = (int)host_vals[4];
+    if (!lazy) {
+        if (host_vals[0] & 1u)
+            return fail(SGR_E_PREFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
+        // (host_vals[5], what num_rendered would be with the reference's rects, is reporting only -- export 17, best effort: it
+        // shares a 64-bit atomic with the emitted count and is not a reason to refuse a frame whose emitted list fits)
+        if (host_vals[4] > 0x7fffffffu) return fail(SGR_E_INVALID, "more than 2^31 tile instances");
+        R = (int)host_vals[4];
 
-    if (!bbase || sgr_binning_bytes(R) > have_bytes) {
-        bbase = binning_buffer(sgr_binning_bytes(R), binning_user);
-        if (!bbase) return fail(SGR_E_ALLOC, "binning buffer allocation failed");
+        if (!bbase || sgr_binning_bytes(R) > have_bytes) {
+            bbase = binning_buffer(sgr_binning_bytes(R), binning_user);
+            if (!bbase) return fail(SGR_E_ALLOC, "binning buffer allocation failed");
+        }
+        // high-water mark with a slow decay: the views of one scene differ, and a miss only costs the late allocation
+        r_hint = std::max((size_t)R + (size_t)R / 4 + 1024, r_hint - r_hint / 16);
     }
-    // high-water mark with a slow decay: the views of one scene differ, and a miss only costs the late allocation
-    r_hint = std::max((size_t)R + (size_t)R / 4 + 1024, r_hint - r_hint / 16);
     const SgrBinView bv = sgr_bin_carve(bbase, (size_t)R);
 
     int cur = 0;
     // (also with R == 0: the kernel finishes the index-order scan, SgrGeomView::u0, which the exports read)
     prof_begin(2, stream);
-    sgr_launch_duplicate(P, gv, order, gv.scan_tmp, gv.sub_sums, bv.keys[0], bv.vals[0], gx, stream);
+    sgr_launch_duplicate(P, gv, order, gv.scan_tmp, gv.sub_sums, bv.keys[0], bv.vals[0], gx, cap, stream);
     SGR_STAGE("duplicate");
     prof_end(stream);
     if (R > 0) {
         prof_begin(3, stream);
         const int bit = (int)getHigherMsb((uint32_t)T);  // rasterizer_impl.cu:303
+        // (lazy: over all `cap` slots; the padding's keys are all ones in every sorted bit and stay behind the instances)
         cur = sgr_launch_sort_pairs32(bv.keys, bv.vals, (uint32_t)R, bit, bv.hist, bv.scan_tmp, stream);
         SGR_STAGE("sort");
         prof_end(stream);
         prof_begin(4, stream);
-        sgr_launch_tile_ranges(R, bv.keys[cur], iv.ranges, bv.touched, stream);
+        sgr_launch_tile_ranges(R, bv.keys[cur], iv.ranges, bv.touched, lazy ? (uint32_t)T : 0xffffffffu, stream);
         SGR_STAGE("tile_ranges");
         prof_end(stream);
     }
@@ -583,7 +693,7 @@ int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, 
     // measured 11 % slower per step: both kernels sit at the VALU issue bound of the same per-visit
     // arithmetic, and the per-quadrant rows cost the row sum more than the barriers cost the LDS kernel.
     const int sw_all = switches();
-    const bool quad = S == 0 && R > 0 && (sw_all & 256) != 0 && (sw_all & (1 | 2 | 4 | 8 | 16)) == 0;
+    const bool quad = SGR_WITH_VARIANTS && S == 0 && R > 0 && (sw_all & 256) != 0 && (sw_all & (1 | 2 | 4 | 8 | 16)) == 0;
     // scratch = [P float4: conic + depth terms between the two per-Gaussian stages][R (or 4 R) partial rows]
     const size_t cd_bytes = sgr_align_up((size_t)P * sizeof(float4), 256);
     const size_t bytes = sgr_align_up((size_t)R * (quad ? 4u : 1u) * stride * sizeof(float), 256);
@@ -612,10 +722,12 @@ int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, 
         // the forward's record of which (quadrant, instance) pairs blended at all; switch 8: the kernel redoes the
         // geometric cull instead (A/B and tests: the two walks must give bit-identical gradients)
         const uint8_t* hits = (sw & 8) ? nullptr : bv.hit4;
+#if SGR_WITH_VARIANTS
         if (quad)
             sgr_launch_blend_bwd_sw((sw & 128) != 0, gx, gy, iv.ranges, bv.vals[cur], W, H, background, gv.rec, gv.u0, gv.tmask, alphas,
                                     iv.n_contrib, bv.hit4, dL_dpix, dL_dpix_depth, dL_dalphas, partials, stride, touched, stream);
         else
+#endif
             sgr_launch_blend_bwd(cull, dpp, det, (sw & 16) != 0, (sw & 128) != 0, gx, gy, iv.ranges, bv.vals[cur], W, H, S, background, gv.rec, gv.u0, gv.tmask, semantics,
                                  alphas, iv.n_contrib, hits, dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, partials,
                                  touched, stream);
@@ -672,14 +784,31 @@ int sgr_sh_grad_from_views_ex(int P, int D, int M, int V, const float* means3D, 
     return 0;
 }
 
+int sgr_set_lazy(int on) {
+    const int prev = lazy_on() ? 1 : 0;
+    if (on >= 0) g_lazy.store(on ? 1 : 0, std::memory_order_relaxed);
+    return prev;
+}
+
+int sgr_lazy_status(int* num_rendered, int* capacity, int* flags) {
+    if (!t_lazy.host_vals || t_lazy.cap == 0) return fail(SGR_E_INVALID, "no lazy forward has run on this thread");
+    if (num_rendered) *num_rendered = (int)t_lazy.host_vals[4];
+    if (capacity) *capacity = (int)t_lazy.cap;
+    if (flags) *flags = lazy_flags(t_lazy);
+    return 0;
+}
+
 int sgr_profile_host_wait_us(int reset) {
     const unsigned long long ns = reset ? g_wait_ns.exchange(0, std::memory_order_relaxed) : g_wait_ns.load(std::memory_order_relaxed);
     return (int)std::min<unsigned long long>(ns / 1000ull, 0x7fffffffull);
 }
 
+int sgr_has_variants(void) { return SGR_WITH_VARIANTS ? 1 : 0; }
+
 int sgr_test_switches(int mask) {
-    const int prev = switches() | (sgr_sort_get_one_sweep() ? 32 : 0);
+    const int prev = switches() | ((SGR_WITH_VARIANTS && sgr_sort_get_one_sweep()) ? 32 : 0);
     if (mask >= 0) {
+        if (!SGR_WITH_VARIANTS) mask &= ~SGR_VARIANT_BITS;
         g_switches.store(mask & ~32, std::memory_order_relaxed);
         sgr_sort_set_one_sweep((mask >> 5) & 1);
     }

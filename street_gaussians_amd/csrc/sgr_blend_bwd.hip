@@ -20,6 +20,10 @@
 
 #include <type_traits>
 
+#ifndef SGR_WITH_VARIANTS
+#define SGR_WITH_VARIANTS 0  // 1: also build the designs that were measured slower and kept as A/Bs (tools/build_variant.py)
+#endif
+
 #define SGR_TILE_THREADS 256
 typedef float sgr_f2 __attribute__((ext_vector_type(2)));
 // list entries staged in LDS per round.  128 (not 256) keeps the S = 0 workgroup at 20 KB of LDS so that occupancy is
@@ -782,6 +786,7 @@ sgr_blend_bwd_kernel_exact(SGR_BWD_ARGS) {
     sgr_blend_bwd_body<SMAX, true, true, true, SgrBwdBatch<SMAX>::value, true>(SGR_BWD_PASS);
 }
 
+#if SGR_WITH_VARIANTS  // rejected A/B design, built only by tools/build_variant.py (-DSGR_WITH_VARIANTS=1): DESIGN.md section 10
 // =====================================================================================================================
 // S = 0, second design ("transposed accumulation").  The kernel above spends ~60 of its ~100 VALU instructions per
 // (quadrant, instance) visit on turning 64 per-pixel terms into 11 sums: the gradient products are formed on every
@@ -1047,6 +1052,8 @@ sgr_blend_bwd_kernel_v2(SGR_BWD_ARGS) {
     }
 }
 
+#endif  // SGR_WITH_VARIANTS
+
 template <int SMAX>
 static void launch_bwd(bool cull, bool dpp, bool det, bool v2, bool exact, unsigned tiles, hipStream_t s, const uint2* ranges, const uint32_t* point_list,
                        int W, int H, int S, int gx, int gy, const float* bg, const float4* rec, const uint32_t* u0, const uint64_t* tmask, const float* semantics,
@@ -1060,6 +1067,7 @@ static void launch_bwd(bool cull, bool dpp, bool det, bool v2, bool exact, unsig
             dL_dsem, partials, row_stride, touched);
         return;
     }
+#if SGR_WITH_VARIANTS
     if constexpr (SMAX == 0) {
         if (v2 && dpp) {  // transposed accumulation (S = 0)
 #define SGR_V2(C, D) sgr_blend_bwd_kernel_v2<C, D><<<tiles, SGR_TILE_THREADS, 0, s>>>(                                    \
@@ -1071,6 +1079,9 @@ static void launch_bwd(bool cull, bool dpp, bool det, bool v2, bool exact, unsig
             return;
         }
     }
+#else
+    (void)v2;
+#endif
     if (SMAX > 4) { cull = true; dpp = true; }  // the A/B switches (tests) exist for the small instantiations only
 #define SGR_GO(C, D)                                                                                                 \
     do {                                                                                                             \

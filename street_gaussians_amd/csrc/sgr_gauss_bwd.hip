@@ -11,6 +11,10 @@
 
 #include <cstdlib>
 
+#ifndef SGR_WITH_VARIANTS
+#define SGR_WITH_VARIANTS 0  // 1: also build the designs that were measured slower and kept as A/Bs (tools/build_variant.py)
+#endif
+
 #ifndef SGR_GB_THREADS
 #define SGR_GB_THREADS 256
 #endif
@@ -167,6 +171,7 @@ sgr_row_sum_kernel(int P, int S, const int* __restrict__ radii, SgrGeomView gv, 
     }
 }
 
+#if SGR_WITH_VARIANTS  // rejected A/B design, built only by tools/build_variant.py (-DSGR_WITH_VARIANTS=1)
 // ---- stage 1, wave-cooperative form (round 4; A/B behind SGR_RS_WAVE=1: measured slower, see the launcher) ----------------
 // The rows are in INDEX order (u0 = exclusive scan of tiles_touched over the Gaussians, culled ones contributing none), so
 // the 64 Gaussians of a wave own ONE contiguous row range [ua, ub).  The wave streams it 64 rows at a time -- lane l takes
@@ -304,6 +309,8 @@ sgr_row_sum_wave_kernel(int P, int S, const int* __restrict__ radii, SgrGeomView
         }
     }
 }
+
+#endif  // SGR_WITH_VARIANTS
 
 // ---- stage 2: K12 + K13 ----------------------------------------------------------------------------------------
 #ifndef SGR_GB_WAVES
@@ -522,6 +529,8 @@ int sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const
     // switch bit 9 / SGR_RS_WAVE=1: the wave-cooperative row sum instead of the four-lanes-per-Gaussian one (A/B: measured SLOWER on MI355X --
     // per-Gaussian backward stage 0.258 vs 0.213 ms at 1 M Gaussians, 1.14 vs 0.76 ms at 5 M, 0.83 vs 0.57 ms at 2 M + 19
     // channels: its segmented scan is 13 ds_bpermute per step and row chunk, more than the gather chains it removes)
+    // (both A/B forms exist only in a -DSGR_WITH_VARIANTS=1 build: tools/build_variant.py)
+#if SGR_WITH_VARIANTS
     const bool quads = !rs_wave;  // (sgr_test_switches bit 9)
     const unsigned nbw = (unsigned)((P + 64 * SGR_RSW_WAVES - 1) / (64 * SGR_RSW_WAVES));
 #define SGR_RSW(N)                                                                                                   \
@@ -539,7 +548,12 @@ int sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const
         else if (S <= 20) SGR_RSW(20);
         else if (S <= 24) SGR_RSW(24);
         else SGR_RSW(32);
-    } else if (S == 0) SGR_RS(0);
+    } else
+#undef SGR_RSW
+#else
+    (void)quad; (void)rs_wave;
+#endif
+    if (S == 0) SGR_RS(0);
     else if (S <= 4) SGR_RS(4);
     else if (S <= 8) SGR_RS(8);
     else if (S <= 12) SGR_RS(12);
@@ -548,7 +562,6 @@ int sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const
     else if (S <= 24) SGR_RS(24);
     else SGR_RS(32);
 #undef SGR_RS
-#undef SGR_RSW
     // dL/dmean2D, dL/dopacity, dL/dcolour are final from here on.  A failed record must not pass silently: the reducer's side
     // stream would wait on a stale record and read the colour gradient unsynchronised -- the error is picked up by the
     // failure is returned to sgr_backward_ex, which reports SGR_E_HIP

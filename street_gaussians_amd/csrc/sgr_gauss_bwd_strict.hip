@@ -7,6 +7,7 @@
 #pragma clang fp contract(off)
 #define SGR_GB_STRICT 1
 #define sgr_row_sum_kernel sgr_row_sum_kernel_strict
+#define sgr_row_sum_wave_kernel sgr_row_sum_wave_kernel_strict  // (exists in -DSGR_WITH_VARIANTS=1 builds only)
 #define sgr_gauss_bwd_kernel sgr_gauss_bwd_kernel_strict
 #define sgr_launch_gauss_bwd sgr_launch_gauss_bwd_strict
 #include "sgr_gauss_bwd.hip"

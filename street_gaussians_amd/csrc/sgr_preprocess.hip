@@ -314,7 +314,17 @@ static_assert(SGR_PRE_THREADS == 256 && SGR_SCAN_ITEMS == 8 * SGR_PRE_THREADS, "
 __global__ void __launch_bounds__(SGR_PRE_THREADS)
 sgr_duplicate_kernel(int P, SgrGeomView gv, const uint32_t* __restrict__ order, const uint32_t* __restrict__ bsum,
                      const uint32_t* __restrict__ sub, uint32_t nb, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                     int gx) {
+                     int gx, uint32_t cap) {
+    // cap != 0 (the forward without a host wait, sgr_set_lazy): the list buffers hold `cap` slots whatever the frame's
+    // instance count R turns out to be (bsum[nb], known to the device only) -- nothing is written past them, and the slots
+    // [R, cap) get a key above every tile id, so that the sort over all `cap` slots leaves them at the end
+    if (cap != 0) {
+        const uint32_t R = bsum[nb];
+        for (uint32_t s = R + blockIdx.x * SGR_PRE_THREADS + threadIdx.x; s < cap; s += gridDim.x * SGR_PRE_THREADS) {
+            keys[s] = 0xffffffffu;
+            vals[s] = 0u;
+        }
+    }
     __shared__ uint32_t sOff[SGR_PRE_THREADS / 64][64];
     __shared__ uint32_t sRect[SGR_PRE_THREADS / 64][64];
     __shared__ uint32_t sIdx[SGR_PRE_THREADS / 64][64];
@@ -349,7 +359,8 @@ sgr_duplicate_kernel(int P, SgrGeomView gv, const uint32_t* __restrict__ order, 
     const uint32_t start = __builtin_amdgcn_readfirstlane(off);
     const int last = min(63, P - 1 - (blockIdx.x * SGR_PRE_THREADS + wave * 64));
     if (last < 0) return;  // whole wave past P
-    const uint32_t end = __builtin_amdgcn_readlane(incl, last);
+    uint32_t end = __builtin_amdgcn_readlane(incl, last);
+    if (cap != 0 && end > cap) end = cap;  // (an overflowing frame is reported by the host once R has landed)
     __builtin_amdgcn_wave_barrier();  // LDS of this wave only: program order + s_waitcnt is enough
     for (uint32_t s = start + lane; s < end; s += 64) {
         // owner = largest l with sOff[l] <= s (offsets are non-decreasing; Gaussians without tiles share the next
@@ -374,23 +385,25 @@ sgr_duplicate_kernel(int P, SgrGeomView gv, const uint32_t* __restrict__ order, 
 
 // ---- K9: tile ranges from the sorted tile keys (rasterizer_impl.cu:116-138) -------------------
 __global__ void __launch_bounds__(256)
-sgr_tile_ranges_kernel(int L, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges, uint8_t* __restrict__ touched) {
+sgr_tile_ranges_kernel(int L, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges, uint8_t* __restrict__ touched,
+                       uint32_t T) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= L) return;
     // one byte per partial-gradient row of the backward ("row written"), cleared here instead of by a memset dispatch
     // in front of the backward's dominant kernel (the index spaces coincide: one row per instance)
     touched[idx] = 0;
+    // keys >= T: the padding behind the frame's instances when the list has a fixed capacity (sgr_duplicate_kernel, cap)
     const uint32_t currtile = keys[idx];
     if (idx == 0) {
-        ranges[currtile].x = 0;
+        if (currtile < T) ranges[currtile].x = 0;
     } else {
         const uint32_t prevtile = keys[idx - 1];
         if (currtile != prevtile) {
-            ranges[prevtile].y = idx;
-            ranges[currtile].x = idx;
+            if (prevtile < T) ranges[prevtile].y = idx;
+            if (currtile < T) ranges[currtile].x = idx;
         }
     }
-    if (idx == L - 1) ranges[currtile].y = L;
+    if (idx == L - 1 && currtile < T) ranges[currtile].y = L;
 }
 
 // parity introspection: the reference's 64-bit sorted keys, recomposed from tile id and depth bits
@@ -431,16 +444,16 @@ void sgr_launch_filter(int P, const float* means3D, const float* scales, const f
 
 // bsum / sub: what sgr_launch_scan_head left for the two count sequences (aux_sorted in depth order, aux in index order)
 void sgr_launch_duplicate(int P, const SgrGeomView& gv, const uint32_t* order, const uint32_t* bsum, const uint32_t* sub,
-                          uint32_t* keys, uint32_t* vals, int gx, hipStream_t s) {
+                          uint32_t* keys, uint32_t* vals, int gx, uint32_t cap, hipStream_t s) {
     if (P <= 0) return;
     const uint32_t nb = (uint32_t)(((size_t)P + SGR_SCAN_ITEMS - 1) / SGR_SCAN_ITEMS);
     sgr_duplicate_kernel<<<(P + SGR_PRE_THREADS - 1) / SGR_PRE_THREADS, SGR_PRE_THREADS, 0, s>>>(P, gv, order, bsum, sub, nb, keys,
-                                                                                             vals, gx);
+                                                                                             vals, gx, cap);
 }
 
-void sgr_launch_tile_ranges(int L, const uint32_t* keys, uint2* ranges, uint8_t* touched, hipStream_t s) {
+void sgr_launch_tile_ranges(int L, const uint32_t* keys, uint2* ranges, uint8_t* touched, uint32_t T, hipStream_t s) {
     if (L <= 0) return;
-    sgr_tile_ranges_kernel<<<(L + 255) / 256, 256, 0, s>>>(L, keys, ranges, touched);
+    sgr_tile_ranges_kernel<<<(L + 255) / 256, 256, 0, s>>>(L, keys, ranges, touched, T);
 }
 
 void sgr_launch_compose_keys(int L, const uint32_t* tile_keys, const uint32_t* point_list, const float4* rec, uint64_t* out,

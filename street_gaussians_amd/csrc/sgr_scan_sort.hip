@@ -23,6 +23,10 @@
 #include <atomic>
 #include <cstdlib>
 
+#ifndef SGR_WITH_VARIANTS
+#define SGR_WITH_VARIANTS 0  // 1: also build the designs that were measured slower and kept as A/Bs (tools/build_variant.py)
+#endif
+
 
 // ------------------------------------------------------------------------------------------------
 // scan kernels: ITEMS = 2048 per block = 256 threads x 8 consecutive elements
@@ -349,6 +353,7 @@ sgr_sort_scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ 
     }
 }
 
+#if SGR_WITH_VARIANTS  // the one-sweep A/B form is built only by tools/build_variant.py (-DSGR_WITH_VARIANTS=1)
 // One-sweep prologue: the global digit counts of every pass in one read of the keys (LDS-privatised, one atomic per
 // non-empty (pass, digit) per workgroup), and the look-back table zeroed.  Workgroups stride over 4096-key chunks.
 template <typename K>
@@ -377,6 +382,8 @@ sgr_sort_hist_all_kernel(const K* __restrict__ keys, uint32_t n, int npass, uint
 }
 
 // 0 = three launches per pass (default), 1 = one sweep; set through sgr_test_switches bit 5 / SGR_ONESWEEP
+#endif  // SGR_WITH_VARIANTS
+
 static std::atomic<int> g_sort_one_sweep{-1};
 void sgr_sort_set_one_sweep(int on) { g_sort_one_sweep.store(on ? 1 : 0, std::memory_order_relaxed); }
 int sgr_sort_get_one_sweep() {
@@ -444,6 +451,7 @@ static int sort_pairs_impl(K* const keys[2], uint32_t* const vals[2], uint32_t n
     if (n == 0) return 0;
     int npass = (end_bit + 7) / 8;
     int cur = 0;
+#if SGR_WITH_VARIANTS
     if (sgr_sort_get_one_sweep() && npass <= SGR_SORT_MAX_PASS && !iota && !aux_in) {
         const uint32_t nblocks = (n + SGR_SORT_ITEMS - 1) / SGR_SORT_ITEMS;
         uint32_t* ghist = hist;
@@ -462,6 +470,7 @@ static int sort_pairs_impl(K* const keys[2], uint32_t* const vals[2], uint32_t n
         }
         return cur;
     }
+#endif
     const int bits = sizeof(K) == 8 ? 8 : sort_pass_bits(end_bit, max_bits);
     const int ipt = sizeof(K) == 8 ? 8 : sort_ipt(n);
     if (sizeof(K) == 4) npass = sort_passes(end_bit, max_bits);

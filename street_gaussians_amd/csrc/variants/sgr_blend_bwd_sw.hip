@@ -19,8 +19,8 @@
 //     (order-free) by the lanes that scanned the entry.
 // Bit-reproducible like the LDS kernel: every float sum has a fixed order (lanes of a wave by the reduction tree, rows of
 // a Gaussian by (tile, quadrant) in the row sum).
-#include "sgr_math.h"
-#include "sgr_reduce.h"
+#include "../sgr_math.h"
+#include "../sgr_reduce.h"
 
 typedef int sgr_i16 __attribute__((ext_vector_type(16)));
 // element of a record as float.  By VALUE: __builtin_bit_cast applied to a vector-element lvalue (R[i]) reads element 0

@@ -160,6 +160,8 @@ def test_backward_matches_oracle(name):
 
 @pytest.mark.parametrize("name", [n for n in CASES if n not in ILL_CONDITIONED and CASES[n][1].semantics.shape[1] == 0])
 def test_scalar_walk_backward_matches_oracle(name):
+    if not _C.has_variants():
+        pytest.skip("the scalar-walk backward is an A/B design outside the shipped library (tools/build_variant.py -DSGR_WITH_VARIANTS=1)")
     """The second blend-backward design (csrc/sgr_blend_bwd_sw.hip, switch USE_SW / SGR_SW=1: a wave owns its quadrant, records
     through the scalar cache, four rows per instance) is held to the same gates as the shipped kernel, in both modes."""
     cam, sc, kw = _kw(name)
@@ -222,22 +224,24 @@ def test_culling_is_invisible_and_backward_is_deterministic(name):
     # the scalar-walk kernel (switch USE_SW; S = 0 only, other widths fall through to the LDS kernel): the same terms summed
     # in another order (per quadrant, moments -> gradients once per Gaussian) -- deterministic, equal up to rounding, and
     # the row flags of the two kernels do not leak into each other when they follow one another over one forward
-    with switches(_C.USE_SW):
-        g_s = raw_backward(kw, res_a, wts)
-        g_s2 = raw_backward(kw, res_a, wts)
-    g_a3 = raw_backward(kw, res_a, wts)
-    for k in g_a:
-        assert torch.equal(g_s[k], g_s2[k]), f"{k} not deterministic (scalar walk)"
-        assert torch.equal(g_a[k], g_a3[k]), f"{k} changed after a scalar-walk backward over the same forward"
-        if name not in ILL_CONDITIONED:
-            grad_close(npy(g_s[k]), npy(g_a[k]), rel=1e-4, abs_frac=2e-5, name=f"scalar walk vs LDS kernel:{k}", max_outlier_frac=0.0)
-    with switches(_C.USE_RS_WAVE):  # the wave-cooperative row sum (A/B form): another fixed summation order
-        g_w = raw_backward(kw, res_a, wts)
-        g_w2 = raw_backward(kw, res_a, wts)
-    for k in g_a:
-        assert torch.equal(g_w[k], g_w2[k]), f"{k} not deterministic (wave-cooperative row sum)"
-        if name not in ILL_CONDITIONED:
-            grad_close(npy(g_w[k]), npy(g_a[k]), rel=1e-4, abs_frac=2e-5, name=f"wave row sum vs quads:{k}", max_outlier_frac=0.0)
+    if _C.has_variants():  # an A/B design outside the shipped library (tools/build_variant.py -DSGR_WITH_VARIANTS=1)
+        with switches(_C.USE_SW):
+            g_s = raw_backward(kw, res_a, wts)
+            g_s2 = raw_backward(kw, res_a, wts)
+        g_a3 = raw_backward(kw, res_a, wts)
+        for k in g_a:
+            assert torch.equal(g_s[k], g_s2[k]), f"{k} not deterministic (scalar walk)"
+            assert torch.equal(g_a[k], g_a3[k]), f"{k} changed after a scalar-walk backward over the same forward"
+            if name not in ILL_CONDITIONED:
+                grad_close(npy(g_s[k]), npy(g_a[k]), rel=1e-4, abs_frac=2e-5, name=f"scalar walk vs LDS kernel:{k}", max_outlier_frac=0.0)
+    if _C.has_variants():  # an A/B design outside the shipped library (tools/build_variant.py -DSGR_WITH_VARIANTS=1)
+        with switches(_C.USE_RS_WAVE):  # the wave-cooperative row sum (A/B form): another fixed summation order
+            g_w = raw_backward(kw, res_a, wts)
+            g_w2 = raw_backward(kw, res_a, wts)
+        for k in g_a:
+            assert torch.equal(g_w[k], g_w2[k]), f"{k} not deterministic (wave-cooperative row sum)"
+            if name not in ILL_CONDITIONED:
+                grad_close(npy(g_w[k]), npy(g_a[k]), rel=1e-4, abs_frac=2e-5, name=f"wave row sum vs quads:{k}", max_outlier_frac=0.0)
     with switches(_C.NO_HITS):  # geometric cull instead of the hit record: a superset of the same visits
         g_h = raw_backward(kw, res_a, wts)
     for k in g_a:
@@ -253,16 +257,18 @@ def test_culling_is_invisible_and_backward_is_deterministic(name):
     g_b2 = raw_backward(kw, res_b, wts)  # hit record written by the un-culled forward
     for k in g_a:
         assert torch.equal(g_a[k], g_b2[k]), f"hit record of the un-culled forward changed dL/d{k}"
-    with switches(_C.USE_SW):  # ... and walked by the scalar-walk kernel
-        g_b3 = raw_backward(kw, res_b, wts)
-    for k in g_s:
-        assert torch.equal(g_s[k], g_b3[k]), f"scalar walk: hit record of the un-culled forward changed dL/d{k}"
-    with switches(_C.USE_ONESWEEP):  # the radix sorts in their one-sweep A/B form: the same order, bit for bit
-        res_s, int_s = raw_forward(kw)
-        for k in ["keys", "point_list", "ranges", "point_offsets"]:
-            assert torch.equal(int_a(k), int_s(k)), f"sort form changed {k}"
-        for k in ["color", "depth", "alpha", "semantic"]:
-            assert torch.equal(res_a[k], res_s[k]), f"sort form changed {k}"
+    if _C.has_variants():  # an A/B design outside the shipped library (tools/build_variant.py -DSGR_WITH_VARIANTS=1)
+        with switches(_C.USE_SW):  # ... and walked by the scalar-walk kernel
+            g_b3 = raw_backward(kw, res_b, wts)
+        for k in g_s:
+            assert torch.equal(g_s[k], g_b3[k]), f"scalar walk: hit record of the un-culled forward changed dL/d{k}"
+    if _C.has_variants():  # an A/B design outside the shipped library (tools/build_variant.py -DSGR_WITH_VARIANTS=1)
+        with switches(_C.USE_ONESWEEP):  # the radix sorts in their one-sweep A/B form: the same order, bit for bit
+            res_s, int_s = raw_forward(kw)
+            for k in ["keys", "point_list", "ranges", "point_offsets"]:
+                assert torch.equal(int_a(k), int_s(k)), f"sort form changed {k}"
+            for k in ["color", "depth", "alpha", "semantic"]:
+                assert torch.equal(res_a[k], res_s[k]), f"sort form changed {k}"
     with switches(_C.PRE_STAGE_SH):  # SH rows through LDS in the preprocess (A/B form): the same operations, the same bits
         res_p, int_p = raw_forward(kw)
         vis = res_a["radii"] > 0
@@ -276,12 +282,13 @@ def test_culling_is_invisible_and_backward_is_deterministic(name):
         g_c = raw_backward(kw, res_a, wts)
     for k in g_a:  # different summation order inside a wave: equal up to fp32 rounding
         grad_close(npy(g_a[k]), npy(g_c[k]), rel=1e-4, abs_frac=2e-5, name=f"dpp:{k}", max_outlier_frac=0.0)
-    with switches(_C.USE_V2):  # S = 0: the transposed-accumulation A/B kernel (moments): equal up to rounding
-        g_d = raw_backward(kw, res_a, wts)
-        g_d2 = raw_backward(kw, res_a, wts)
-    for k in g_a:
-        assert torch.equal(g_d[k], g_d2[k]), f"{k} not deterministic (transposed accumulation)"
-        grad_close(npy(g_a[k]), npy(g_d[k]), rel=1e-4, abs_frac=2e-5, name=f"v2:{k}", max_outlier_frac=0.0)
+    if _C.has_variants():  # an A/B design outside the shipped library (tools/build_variant.py -DSGR_WITH_VARIANTS=1)
+        with switches(_C.USE_V2):  # S = 0: the transposed-accumulation A/B kernel (moments): equal up to rounding
+            g_d = raw_backward(kw, res_a, wts)
+            g_d2 = raw_backward(kw, res_a, wts)
+        for k in g_a:
+            assert torch.equal(g_d[k], g_d2[k]), f"{k} not deterministic (transposed accumulation)"
+            grad_close(npy(g_a[k]), npy(g_d[k]), rel=1e-4, abs_frac=2e-5, name=f"v2:{k}", max_outlier_frac=0.0)
 
 
 @pytest.mark.parametrize("mode", ["default", "exact"])

@@ -38,8 +38,12 @@ def one(src):
     return o
 
 
+sources = list(b.SOURCES)
+if any(f.replace(" ", "") == "-DSGR_WITH_VARIANTS=1" for f in flags):  # the rejected A/B designs ride along
+    sources += b.VARIANT_SOURCES
+    os.makedirs(os.path.join(obj_dir, "variants"), exist_ok=True)
 with ThreadPoolExecutor(max_workers=8) as ex:
-    objs = list(ex.map(one, b.SOURCES))
+    objs = list(ex.map(one, sources))
 lib = os.path.join(out_dir, f"libsgr_hip_{name}.so")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
 print(lib)
