@@ -219,7 +219,8 @@ int sgr_test_switches(int mask);
  * ignores those bits. */
 int sgr_has_variants(void);
 /* ---- the forward without a host wait (extension; the reference blocks on num_rendered, rasterizer_impl.cu:284) ---------
- * sgr_set_lazy(1) (or SGR_LAZY=1 in the environment): from a thread's second forward on, the instance-list buffers get a
+ * sgr_set_lazy(1) (or SGR_LAZY=1 in the environment): from a thread's second forward after the call on (the first one
+ * blocks and seeds the capacity from its own frame), the instance-list buffers get a
  * capacity derived from the previous frames' num_rendered (+ 1/16), duplicate / sort / tile ranges run over the whole
  * capacity, nothing waits for the read-back, and sgr_forward RETURNS THE CAPACITY (hand it to sgr_backward as R like any
  * num_rendered).  The checks the host would have made at the wait happen one call late: the next lazy sgr_forward of the

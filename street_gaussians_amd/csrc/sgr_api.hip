@@ -293,6 +293,7 @@ static void pack_camera(const SgrGeomView& gv, const float* view, const float* p
 // checks are then the caller's (sgr_lazy_status).  Opt-in because of the late error: right for a fixed camera rig or a
 // captured step, wrong for a trainer that draws a new view with a very different R every iteration.
 static std::atomic<int> g_lazy{-1};
+static std::atomic<int> g_lazy_epoch{0};  // bumped by sgr_set_lazy: every thread's next forward is a blocking one
 static bool lazy_on() {
     int v = g_lazy.load(std::memory_order_relaxed);
     if (v < 0) {
@@ -421,6 +422,15 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
         // high-water mark with a slow decay, as in the blocking path (lazy: 1/16 of head-room -- the sort runs over it)
         const size_t Rp = t_lazy.host_vals[4];
         r_hint = std::max(Rp + Rp / 16 + 1024, r_hint - r_hint / 64);
+    }
+    {   // a change of the mode forgets the thread's capacity: its next forward blocks and seeds it from THAT frame (a
+        // high-water mark left by much larger frames would make the lazy sort run over mostly padding)
+        static thread_local int t_epoch = 0;
+        const int e = g_lazy_epoch.load(std::memory_order_relaxed);
+        if (t_epoch != e) {
+            t_epoch = e;
+            r_hint = 0;
+        }
     }
     const bool lazy = lazy_on() && r_hint > 0;
 
@@ -786,7 +796,10 @@ int sgr_sh_grad_from_views_ex(int P, int D, int M, int V, const float* means3D, 
 
 int sgr_set_lazy(int on) {
     const int prev = lazy_on() ? 1 : 0;
-    if (on >= 0) g_lazy.store(on ? 1 : 0, std::memory_order_relaxed);
+    if (on >= 0) {
+        g_lazy.store(on ? 1 : 0, std::memory_order_relaxed);
+        g_lazy_epoch.fetch_add(1, std::memory_order_relaxed);
+    }
     return prev;
 }
 

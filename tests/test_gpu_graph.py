@@ -56,7 +56,9 @@ def test_lazy_step_is_bit_identical_and_replays_from_a_graph():
         ref = _snapshot(_step(rast, t, m2d, w), t, m2d)
         R_true = rasterizer.last_num_rendered()
         _C.set_lazy(True)
-        first = _snapshot(_step(rast, t, m2d, w), t, m2d)  # (this thread has a capacity from the blocking call: lazy already)
+        seed = _snapshot(_step(rast, t, m2d, w), t, m2d)  # (the first forward after the switch blocks and seeds the capacity)
+        _same(ref, seed, "seeding step")
+        first = _snapshot(_step(rast, t, m2d, w), t, m2d)
         second = _snapshot(_step(rast, t, m2d, w), t, m2d)
         torch.cuda.synchronize()
         _same(ref, first, "first lazy step")
@@ -101,9 +103,10 @@ def test_lazy_overflow_is_reported_one_call_late_and_the_thread_recovers():
     prev = _C.set_lazy(False)
     try:
         ref_big = _snapshot(_step(*big), big[1], big[2])
-        ref_small = _snapshot(_step(*small), small[1], small[2])  # seeds the capacity with the small frame's R
+        ref_small = _snapshot(_step(*small), small[1], small[2])
         _C.set_lazy(True)
-        _step(*small)
+        _step(*small)  # blocking: seeds the capacity with the small frame's R
+        _step(*small)  # lazy
         _step(*big)  # overflows the capacity: nobody knows yet
         torch.cuda.synchronize()
         R, cap, flags = _C.lazy_status()

@@ -61,20 +61,15 @@ def derive(res):
         d["kernel_cycles"] = cyc
         if dur:
             d["effective_clock_ghz"] = round(cyc / dur, 3)
-        if res.get("sq_active_inst_valu"):
-            # AMD's VALUBusy formula (derived_counters.xml, gfx9): 4 * SQ_ACTIVE_INST_VALU / SIMDs / GRBM_GUI_ACTIVE.  On
-            # gfx950's SIMD-32 a wave64 VALU instruction issues in 2 cycles but the counter ticks in quad-cycles (>= 1 per
-            # instruction: measured 1.14 per instruction here), so the formula reads up to 2x the issue-slot occupancy
-            d["valu_busy_amd_formula"] = round(4.0 * res["sq_active_inst_valu"] / 1024.0 / cyc, 3)
         if res.get("sq_insts_valu"):
             trans = res.get("sq_insts_valu_trans_f32", 0.0)
             # issue slots at NOMINAL instruction costs: 2 cycles per wave64 VALU instruction, 8 for the quarter-rate
-            # transcendentals.  A LOWER bound of the pipe occupancy: measured on MI355X (tools/ubench/valu_rates.hip) a plain
-            # f32 op takes 2.5-2.7 cycles, a DPP add 4.4, v_permlane32/16_swap 8.6 -- the counters do not separate those
-            # classes, tools/valu_model.py does from the ISA (profiles/r4/valu_model.json: 0.87 for this kernel)
+            # transcendentals.  A LOWER bound of the pipe occupancy: measured in cycles on MI355X
+            # (tools/ubench/valu_rates2.hip) a plain f32 op takes 2.2-2.4, a DPP add 4.2, v_permlane32/16_swap 8.1 -- the
+            # counters do not separate those classes, tools/valu_model.py does from the ISA (profiles/r5/valu_model.json)
             d["valu_issue_slot_frac_at_nominal_costs"] = round((2.0 * (res["sq_insts_valu"] - trans) + 8.0 * trans) / 1024.0 / cyc, 3)
             try:
-                vm = json.load(open(os.path.join(ROOT, "profiles", "r4", "valu_model.json")))["default"]
+                vm = json.load(open(os.path.join(ROOT, "profiles", "r5", "valu_model.json")))["default"]
                 if vm.get("source_sha16") == res.get("source_sha16"):
                     d["valu_pipe_cycles_per_visit_model"] = vm["valu_pipe_cycles_per_visit"]
             except (OSError, KeyError, ValueError):
