@@ -37,14 +37,14 @@ int sgr_partial_row_stride(int S);
 void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, bool v2, bool exact, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
                           int H, int S, const float* bg, const float4* rec, const uint32_t* u0, const uint64_t* tmask, const float* semantics, const float* alphas,
                           const uint32_t* n_contrib, const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth,
-                          const float* dL_dalpha, const float* dL_dsem, float* partials, uint8_t* touched, hipStream_t s);
+                          const float* dL_dalpha, const float* dL_dsem, float* partials, uint8_t* touched, uint32_t row_limit, hipStream_t s);
 int sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const int* radii, const float* shs,
                           const float* scales, const float* rotations, const float* cov3D_precomp, const SgrCam* cam,
                           const SgrGeomView& gv, const float* partials, int row_stride, const uint8_t* touched,
                           float4* cd, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dsemantic,
                           const SgrStatSink& sink, int quad, int exact, int W, int H, hipEvent_t after_rows, int rs_wave,
-                          hipStream_t s);
+                          uint32_t row_limit, hipStream_t s);
 void sgr_launch_blend_bwd_sw(bool exact, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W, int H,
                              const float* bg, const float4* rec, const uint32_t* u0, const uint64_t* tmask, const float* alphas,
                              const uint32_t* n_contrib, const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth,
@@ -56,7 +56,7 @@ int sgr_launch_gauss_bwd_strict(int P, int D, int M, int S, const float* means3D
                                  float4* cd, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                                  float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dsemantic,
                                  const SgrStatSink& sink, int quad, int exact, int W, int H, hipEvent_t after_rows, int rs_wave,
-                                 hipStream_t s);
+                                 uint32_t row_limit, hipStream_t s);
 void sgr_launch_masked_color_grad(int P, const uint32_t* clamped, const float* dL_dcolor, float* out, hipStream_t s);
 void sgr_launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, size_t means_stride,
                                    const float* campos, size_t campos_stride, const float* drgb, size_t drgb_stride,
@@ -740,7 +740,7 @@ int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, 
 #endif
             sgr_launch_blend_bwd(cull, dpp, det, (sw & 16) != 0, (sw & 128) != 0, gx, gy, iv.ranges, bv.vals[cur], W, H, S, background, gv.rec, gv.u0, gv.tmask, semantics,
                                  alphas, iv.n_contrib, hits, dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, partials,
-                                 touched, stream);
+                                 touched, (uint32_t)R, stream);
         SGR_STAGE("blend_bwd");
         prof_end(stream);
     }
@@ -748,7 +748,8 @@ int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, 
     const int ev_failed = ((switches() & 128) ? sgr_launch_gauss_bwd_strict : sgr_launch_gauss_bwd)(
         P, D, M, S, means3D, radii_ptr, shs, scales, rotations, cov3D_precomp, cam_slot(gv), gv, partials, stride, touched, cd,
         dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, dL_dsemantic, sink, quad ? 1 : 0,
-        (switches() & 128) ? 1 : 0, W, H, extras ? (hipEvent_t)extras->color_ready_event : nullptr, (switches() & 512) ? 1 : 0, stream);
+        (switches() & 128) ? 1 : 0, W, H, extras ? (hipEvent_t)extras->color_ready_event : nullptr, (switches() & 512) ? 1 : 0,
+        (uint32_t)R, stream);
     SGR_STAGE("gauss_bwd");
     prof_end(stream);
     if (ev_failed) return fail(SGR_E_HIP, "hipEventRecord(color_ready_event) failed: is it a valid event of this device?");

@@ -183,7 +183,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                      const uint32_t* __restrict__ n_contrib, const uint8_t* __restrict__ hit4,
                      const float* __restrict__ dL_dpixels, const float* __restrict__ dL_dpixel_depths,
                      const float* __restrict__ dL_dalphas, const float* __restrict__ dL_dpixel_semantics,
-                     float* __restrict__ partials, int row_stride, uint8_t* __restrict__ touched) {
+                     float* __restrict__ partials, int row_stride, uint8_t* __restrict__ touched, uint32_t row_limit) {
     // Every fused multiply-add below is written out (fmaf / __builtin_elementwise_fma): with contraction left to the
     // optimiser, the CULL / !CULL and DPP / shuffle instantiations of this body can fuse differently and the "culling
     // is invisible, bit for bit" property (tests) would depend on code-generation luck.
@@ -336,7 +336,8 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
             const uint32_t dy_ = __float_as_uint(d4.y);
             // first row of the Gaussian (compact array, L2-resident) + rank of this tile among the tiles it is emitted for:
             // rides in the spare word of the slot's position record (written and read back by this thread only)
-            sA[tid] = make_float4(a.x, a.y, __uint_as_float(sgr_row_of(dy_, tx, ty, u0, tmask, g)), 0.0f);
+            const uint32_t urow = sgr_row_of(dy_, tx, ty, u0, tmask, g);
+            sA[tid] = make_float4(a.x, a.y, __uint_as_float(urow), 0.0f);
             if (SMAX > 0) {
 #pragma unroll
                 for (int ch = 0; ch < SMAX; ch++) sSem[tid * SMAX + ch] = ch < S ? semantics[(size_t)g * S + ch] : 0.0f;
@@ -346,6 +347,10 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
             mask4 = CULL ? (hit4 != nullptr ? (SGR_BWD_PREFETCH ? h_pre : (uint32_t)hit4[range.x + (uint32_t)pos])
                                             : sgr_quadrant_mask(a, b, tx0, ty0))
                          : 0xFu;
+            // lazy forward (sgr_set_lazy) whose frame had more instances than the list capacity: the rows are numbered over ALL
+            // instances (index-order scan), the row array holds `row_limit` of them -- rows past it are not visited (the frame
+            // is reported invalid one call later; nothing may be written outside the buffers meanwhile)
+            if (urow >= row_limit) mask4 = 0;
         }
         if (SGR_BWD_PREFETCH) {  // next round's list entries: in flight under this round's walk
             const int posn = stager ? (hi - BATCH) - tid : -1;
@@ -759,10 +764,10 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
         const float *__restrict__ dL_dpixels, const float *__restrict__ dL_dpixel_depths,                                  \
         const float *__restrict__ dL_dalphas,                                                                              \
         const float *__restrict__ dL_dpixel_semantics, float *__restrict__ partials, int row_stride,                      \
-        uint8_t *__restrict__ touched
+        uint8_t *__restrict__ touched, uint32_t row_limit
 #define SGR_BWD_PASS                                                                                                  \
     ranges, point_list, W, H, S, gx, gy, bg_color, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpixels,               \
-        dL_dpixel_depths, dL_dalphas, dL_dpixel_semantics, partials, row_stride, touched
+        dL_dpixel_depths, dL_dalphas, dL_dpixel_semantics, partials, row_stride, touched, row_limit
 template <int SMAX, bool CULL, bool DPP, bool DET>
 __global__ void __launch_bounds__(SGR_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(SGR_BWD_WAVES(SMAX))))
 sgr_blend_bwd_kernel(SGR_BWD_ARGS) {
@@ -1059,12 +1064,12 @@ static void launch_bwd(bool cull, bool dpp, bool det, bool v2, bool exact, unsig
                        int W, int H, int S, int gx, int gy, const float* bg, const float4* rec, const uint32_t* u0, const uint64_t* tmask, const float* semantics,
                        const float* alphas,
                        const uint32_t* n_contrib, const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth,
-                       const float* dL_dalpha, const float* dL_dsem, float* partials, int row_stride, uint8_t* touched) {
+                       const float* dL_dalpha, const float* dL_dsem, float* partials, int row_stride, uint8_t* touched, uint32_t row_limit) {
     constexpr bool kDet = true;  // every instantiation has the two-row deterministic combine (see SgrBwdBatch)
     if (exact) {
         sgr_blend_bwd_kernel_exact<SMAX><<<tiles, SGR_TILE_THREADS, 0, s>>>(
             ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth, dL_dalpha,
-            dL_dsem, partials, row_stride, touched);
+            dL_dsem, partials, row_stride, touched, row_limit);
         return;
     }
 #if SGR_WITH_VARIANTS
@@ -1072,7 +1077,7 @@ static void launch_bwd(bool cull, bool dpp, bool det, bool v2, bool exact, unsig
         if (v2 && dpp) {  // transposed accumulation (S = 0)
 #define SGR_V2(C, D) sgr_blend_bwd_kernel_v2<C, D><<<tiles, SGR_TILE_THREADS, 0, s>>>(                                    \
             ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,         \
-            dL_dalpha, dL_dsem, partials, row_stride, touched)
+            dL_dalpha, dL_dsem, partials, row_stride, touched, row_limit)
             if (cull) { if (det) SGR_V2(true, true); else SGR_V2(true, false); }
             else { if (det) SGR_V2(false, true); else SGR_V2(false, false); }
 #undef SGR_V2
@@ -1089,19 +1094,19 @@ static void launch_bwd(bool cull, bool dpp, bool det, bool v2, bool exact, unsig
             if (det)                                                                                                 \
                 sgr_blend_bwd_kernel_s0<C, D, true><<<tiles, SGR_TILE_THREADS, 0, s>>>(                               \
                     ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,    \
-                    dL_dalpha, dL_dsem, partials, row_stride, touched);                                               \
+                    dL_dalpha, dL_dsem, partials, row_stride, touched, row_limit);                                               \
             else                                                                                                     \
                 sgr_blend_bwd_kernel_s0<C, D, false><<<tiles, SGR_TILE_THREADS, 0, s>>>(                              \
                     ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,    \
-                    dL_dalpha, dL_dsem, partials, row_stride, touched);                                               \
+                    dL_dalpha, dL_dsem, partials, row_stride, touched, row_limit);                                               \
         } else if (kDet && det)                                                                                      \
             sgr_blend_bwd_kernel<SMAX, C, D, kDet><<<tiles, SGR_TILE_THREADS, 0, s>>>(                                \
                 ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,        \
-                dL_dalpha, dL_dsem, partials, row_stride, touched);                                                   \
+                dL_dalpha, dL_dsem, partials, row_stride, touched, row_limit);                                                   \
         else                                                                                                         \
             sgr_blend_bwd_kernel<SMAX, C, D, false><<<tiles, SGR_TILE_THREADS, 0, s>>>(                               \
                 ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,        \
-                dL_dalpha, dL_dsem, partials, row_stride, touched);                                                   \
+                dL_dalpha, dL_dsem, partials, row_stride, touched, row_limit);                                                   \
     } while (0)
     if (cull && dpp) SGR_GO(true, true);
     else if constexpr (SMAX <= 4) {
@@ -1123,12 +1128,12 @@ int sgr_partial_row_stride(int S) {
 void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, bool v2, bool exact, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
                           int H, int S, const float* bg, const float4* rec, const uint32_t* u0, const uint64_t* tmask, const float* semantics, const float* alphas, const uint32_t* n_contrib,
                           const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha,
-                          const float* dL_dsem, float* partials, uint8_t* touched, hipStream_t s) {
+                          const float* dL_dsem, float* partials, uint8_t* touched, uint32_t row_limit, hipStream_t s) {
     if (gx <= 0 || gy <= 0) return;
     const unsigned tiles = sgr_xcd_grid_blocks(gx, gy);  // supertile-ordered grid incl. padding blocks
     const int stride = sgr_partial_row_stride(S);
 #define SGR_BWD(N) launch_bwd<N>(cull, dpp, det, v2, exact, tiles, s, ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, \
-                                 n_contrib, hit4, dL_dpix, dL_ddepth, dL_dalpha, dL_dsem, partials, stride, touched)
+                                 n_contrib, hit4, dL_dpix, dL_ddepth, dL_dalpha, dL_dsem, partials, stride, touched, row_limit)
     if (S == 0) SGR_BWD(0);
     else if (S <= 4) SGR_BWD(4);
     else if (S <= 8) SGR_BWD(8);

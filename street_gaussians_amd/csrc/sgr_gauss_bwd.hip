@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(SGR_GB_THREADS)
 sgr_row_sum_kernel(int P, int S, const int* __restrict__ radii, SgrGeomView gv, const float* __restrict__ partials,
                    int row_stride, const uint8_t* __restrict__ touched, float* __restrict__ dL_dmean2D,
                    float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dsemantic,
-                   float4* __restrict__ cd, SgrStatSink sink, float kx, float ky, int exact) {
+                   float4* __restrict__ cd, SgrStatSink sink, float kx, float ky, int exact, uint32_t row_limit) {
     constexpr int NV = (SGR_ROW_BASE_N + SMAX + 3) / 4;
     const int gtid = blockIdx.x * SGR_GB_THREADS + threadIdx.x;
     const int idx = gtid / SGR_RS_LANES, q = gtid % SGR_RS_LANES;
@@ -50,8 +50,11 @@ sgr_row_sum_kernel(int P, int S, const int* __restrict__ radii, SgrGeomView gv, 
     const bool live = idx < P;  // P need not be a multiple of 16: keep whole quads alive for the DPP steps
     // tiles_touched is 0 for a culled Gaussian, so the row walk needs no look at the radius: the two loads below go out
     // together and the dependent chain is {u0, n} -> flag -> row
-    const uint32_t n = live ? gv.aux[idx].x : 0u;
+    uint32_t n = live ? gv.aux[idx].x : 0u;
     const uint32_t u0 = live ? gv.u0[idx] : 0u;  // defined for every Gaussian (exclusive scan)
+    // rows past the array's end exist only after a lazy forward that overflowed its list capacity (sgr_set_lazy): the
+    // blend backward did not write them and they are not read (that frame's results are discarded, one call later)
+    n = min(n, row_limit - min(u0, row_limit));
     if (n && QUAD) {
         const uint8_t* flag = touched + u0;
         const float* rows = partials + (size_t)u0 * 4u * row_stride;
@@ -517,7 +520,7 @@ int sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const
                           float4* cd, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dsemantic,
                           const SgrStatSink& sink, int quad, int exact, int W, int H, hipEvent_t after_rows, int rs_wave,
-                          hipStream_t s) {
+                          uint32_t row_limit, hipStream_t s) {
     if (P <= 0) return 0;
     const float lsc = exact ? 1.0f : SGR_LOG2E;
     const float kx = (0.5f * (float)W) / lsc, ky = (0.5f * (float)H) / lsc;
@@ -525,7 +528,7 @@ int sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const
     const unsigned nb4 = (unsigned)(((size_t)P * SGR_RS_LANES + SGR_GB_THREADS - 1) / SGR_GB_THREADS);
 #define SGR_RS(N)                                                                                                    \
     sgr_row_sum_kernel<N, false><<<nb4, SGR_GB_THREADS, 0, s>>>(P, S, radii, gv, partials, row_stride, touched, dL_dmean2D, \
-                                                               dL_dopacity, dL_dcolor, dL_dsemantic, cd, sink, kx, ky, exact)
+                                                               dL_dopacity, dL_dcolor, dL_dsemantic, cd, sink, kx, ky, exact, row_limit)
     // switch bit 9 / SGR_RS_WAVE=1: the wave-cooperative row sum instead of the four-lanes-per-Gaussian one (A/B: measured SLOWER on MI355X --
     // per-Gaussian backward stage 0.258 vs 0.213 ms at 1 M Gaussians, 1.14 vs 0.76 ms at 5 M, 0.83 vs 0.57 ms at 2 M + 19
     // channels: its segmented scan is 13 ds_bpermute per step and row chunk, more than the gather chains it removes)
@@ -538,7 +541,7 @@ int sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const
                                                                  dL_dopacity, dL_dcolor, dL_dsemantic, cd, sink)
     if (quad) {  // the scalar-walk blend backward's rows (S = 0 only)
         sgr_row_sum_kernel<0, true><<<nb4, SGR_GB_THREADS, 0, s>>>(P, S, radii, gv, partials, row_stride, touched, dL_dmean2D,
-                                                                  dL_dopacity, dL_dcolor, dL_dsemantic, cd, sink, kx, ky, exact);
+                                                                  dL_dopacity, dL_dcolor, dL_dsemantic, cd, sink, kx, ky, exact, 0xffffffffu);
     } else if (!quads) {
         if (S == 0) SGR_RSW(0);
         else if (S <= 4) SGR_RSW(4);

@@ -7,8 +7,13 @@ R=$GRAFT_REPO_ROOT
 TAG=${1:-r5}
 E=$R/gpurun_out/ev_$TAG
 mkdir -p $E
-rm -f $R/gpurun_out/parity_measured.jsonl $R/gpurun_out/fullsize_parity.json
+rm -f $R/gpurun_out/parity_measured.jsonl $R/gpurun_out/fullsize_parity.json $R/gpurun_out/threeway_fullsize.json
 echo "== full gpu suite"; timeout 1500 python -m pytest tests -q --tb=short -m gpu 2>&1 | grep -v amdgpu.ids | grep -v "^{" | tail -6 | tee $E/pytest_gpu.log
+if [ -f $R/street_gaussians_amd/variants/libsgr_hip_ab.so ]; then
+  echo "== the gated A/B designs (library built with -DSGR_WITH_VARIANTS=1)"
+  SGR_BINDING=ctypes SGR_LIB=$R/street_gaussians_amd/variants/libsgr_hip_ab.so timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_primitives.py -q --tb=short -m gpu -k "culling or scalar_walk or sort_pairs" 2>&1 | grep -v amdgpu.ids | tail -3 | tee $E/pytest_variants.log
+fi
+echo "== soak"; timeout 900 python tools/soak.py 100 2>&1 | grep -v amdgpu.ids | tail -12 | tee $E/soak.log
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -v amdgpu.ids | tail -2 | tee $E/smoke.log
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $E/stats -o bench -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > $E/stats.log 2>&1
@@ -33,5 +38,5 @@ rm -f $E/*/*_kernel_trace.csv
 echo "== bench (with the fresh traffic file)"; timeout 1200 python bench.py 2>&1 | grep -v amdgpu.ids | tail -1 | tee $E/bench.json | cut -c1-400
 echo "== rows next to the path (n1-n4)"
 for t in iteration scene loss densify binding; do timeout 600 python tools/bench_$t.py 2>&1 | grep -v amdgpu.ids | tail -1 > $E/$t.json; done
-cp $R/gpurun_out/parity_measured.jsonl $R/gpurun_out/fullsize_parity.json $E/ 2>/dev/null
+cp $R/gpurun_out/parity_measured.jsonl $R/gpurun_out/fullsize_parity.json $R/gpurun_out/threeway_fullsize.json $E/ 2>/dev/null
 ls $E
