@@ -871,16 +871,30 @@ def main():
     if world == 1 and dist is None and S == 0:
         try:
             from street_gaussians_amd import _C as native_c
+            # host time spent waiting for the device inside sgr_forward (the read-back of num_rendered), blocking vs lazy
+            fence()
+            L.sgr_profile_host_wait_us(1)
+            for _ in range(50):
+                wl.step()
+            fence()
+            wait_blocking = L.sgr_profile_host_wait_us(1) / 50.0
             was = native_c.set_lazy(True)
             try:
                 for _ in range(3):
                     wl.step()
                 n_l = max(args.steps, int(0.4 / max(dt / args.steps, 1e-5)) + 1)
+                fence()
+                L.sgr_profile_host_wait_us(1)
                 ldt, _ = profiled_steps(L, wl, fence, n_l, 0)
                 torch.cuda.synchronize()
+                wait_lazy = L.sgr_profile_host_wait_us(1) / float(n_l)
                 R_l, cap_l, fl_l = native_c.lazy_status()
                 lazy_info = {"ms_per_step_lazy": round(1e3 * ldt / n_l, 4), "steps": n_l, "num_rendered": R_l, "capacity": cap_l,
-                             "flags": fl_l}
+                             "flags": fl_l,
+                             "host_wait_us_per_step": {"blocking": round(wait_blocking, 1), "lazy": round(wait_lazy, 1),
+                                                       "what": "time the host spends inside sgr_forward waiting for the device "
+                                                               "(sgr_profile_host_wait_us): the GPU runs behind the host, so in the "
+                                                               "blocking mode this is mostly the host being AHEAD, not the GPU idling"}}
                 p, w = wl.params, wl.w
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())

@@ -226,8 +226,9 @@ int sgr_has_variants(void);
  * num_rendered).  The checks the host would have made at the wait happen one call late: the next lazy sgr_forward of the
  * thread returns -SGR_E_LAZY when the previous frame had more instances than its capacity, a prefilter violation or a
  * depth beyond the 27-bit depth keys -- that frame's outputs are invalid -- and the thread then runs one blocking forward.
- * No call on this path synchronises, so forward + backward can be captured in a hipGraph (inside a capture the late check is
- * skipped: ask sgr_lazy_status after a synchronisation).  on < 0 only queries; returns the previous setting. */
+ * The only wait left on this path is that late check (the previous frame's read-back: it keeps a fast host one frame ahead);
+ * inside a stream capture it is skipped and nothing synchronises, so forward + backward can be captured in a hipGraph (ask
+ * sgr_lazy_status after a synchronisation of your own).  on < 0 only queries; returns the previous setting. */
 int sgr_set_lazy(int on);
 /* The thread's most recent lazy forward, once its stream has been synchronised: the frame's real num_rendered, the
  * capacity it ran with, flags (bit 0 overflow, bit 1 prefilter violation, bit 2 depth beyond the narrow depth sort). */
