@@ -125,3 +125,32 @@ def test_lazy_overflow_is_reported_one_call_late_and_the_thread_recovers():
     finally:
         _C.set_lazy(prev)
         torch.cuda.synchronize()
+
+
+def test_lazy_frames_with_few_or_no_instances():
+    """The capacity has a floor, so a lazy frame with no visible Gaussian at all (everything behind the camera) runs over a
+    list of sentinel keys only: images = the background, every gradient zero, no flag raised; and the thread carries on with a
+    normal frame afterwards, bit-identical to the blocking result."""
+    rast, t, m2d, w = _setup(P=20_000, W=320, H=200, seed=11)
+    prev = _C.set_lazy(False)
+    try:
+        ref = _snapshot(_step(rast, t, m2d, w), t, m2d)
+        behind = {k: v.detach().clone().requires_grad_(True) for k, v in t.items()}
+        with torch.no_grad():
+            behind["means3D"][:, 2] = -behind["means3D"][:, 2].abs() - 1.0  # camera looks down +z (synthetic.make_camera)
+        ref_empty = _snapshot(_step(rast, behind, m2d, w), behind, m2d)
+        assert all(float(g.abs().max()) == 0.0 for g in ref_empty[4:]), "an empty frame has zero gradients"
+        _C.set_lazy(True)
+        _step(rast, t, m2d, w)        # blocking: seeds the capacity
+        got = _snapshot(_step(rast, behind, m2d, w), behind, m2d)  # lazy, R = 0
+        torch.cuda.synchronize()
+        _same(ref_empty, got, "lazy frame without instances")
+        R, cap, flags = _C.lazy_status()
+        assert R == 0 and cap >= 1024 and flags == 0, (R, cap, flags)
+        got = _snapshot(_step(rast, t, m2d, w), t, m2d)  # lazy again, a normal frame inside the (decayed) capacity
+        torch.cuda.synchronize()
+        _same(ref, got, "lazy frame after an empty one")
+        assert _C.lazy_status()[2] == 0
+    finally:
+        _C.set_lazy(prev)
+        torch.cuda.synchronize()
