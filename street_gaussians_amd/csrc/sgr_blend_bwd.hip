@@ -54,6 +54,19 @@ struct SgrBwdBatch { static constexpr int value = SMAX <= 8 ? SGR_BWD_BATCH : SG
 #endif
 // parity mode: 1 = expf / division written out without their range handling (sgr_math.h: sgr_expf_ref, sgr_div_by; same
 // bits for the operands of this kernel), 0 = the library's expf and the compiler's IEEE `/` (A/B: tools/build_variant.py)
+// Parity mode, backward (round 5).  What north_star asks of the gradients is rel 1e-4, not the reference's bits -- those are
+// asked of the tile / bin indices and met by the forward, whose alpha test decides them.  SGR_EXACT_BWD_FAST=1: the backward
+// of the parity mode keeps the reference's own power expression (cancellation in it is what can cost digits) but takes
+// G = exp(power) from v_exp_f32 and T / (1 - alpha) from the Newton-refined reciprocal, like the default mode -- EXCEPT that a
+// visit with any pixel whose alpha lands within 4e-6 (relative) of the 1/255 threshold recomputes G with the accurate expf for
+// the whole wave (a wave-uniform branch, taken about once in 10^4 visits): every blend / skip decision is therefore the
+// forward's, and what differs from the all-exact backward is rounding-level (<= 4e-7 relative in G, <= 1 ulp per layer in T).
+#ifndef SGR_EXACT_BWD_FAST
+#define SGR_EXACT_BWD_FAST 1  // 0: every function of the backward with the reference's bits (A/B: tools/build_variant.py)
+#endif
+#ifndef SGR_EXACT_BWD_GUARD
+#define SGR_EXACT_BWD_GUARD 1  // 0 only for tools/valu_model.py (a static count of the loop without its rare branch)
+#endif
 #ifndef SGR_EXACT_TRIM
 #define SGR_EXACT_TRIM 1
 #endif
@@ -447,7 +460,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                     inv1ma = fmaf(fmaf(-oma, inv1ma, 1.0f), inv1ma, inv1ma);  // Newton step: T recovery compounds per layer
                     // T = T / (1 - alpha) (backward.cu:547).  EXACT: the IEEE quotient, from the refined reciprocal above
                     // and two residual corrections (sgr_div_by: the bits of `/` for these operand ranges)
-                    T = EXACT ? (SGR_EXACT_TRIM ? sgr_div_by(T, oma, inv1ma) : T / oma) : T * inv1ma;
+                    T = (EXACT && !SGR_EXACT_BWD_FAST) ? (SGR_EXACT_TRIM ? sgr_div_by(T, oma, inv1ma) : T / oma) : T * inv1ma;
                     wm = alpha * T;
                     const float one_m_la = 1.0f - last_alpha;
                     float d;
@@ -501,7 +514,9 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                     d *= T;
                     // backward.cu:611-614.  EXACT with a black background (bg_zero, wave-uniform): (-T_final / oma) * 0 adds a
                     // signed zero -- the second quotient is skipped
-                    if (EXACT)
+                    if (EXACT && SGR_EXACT_BWD_FAST)
+                        Gd = bg_zero ? G * d : G * (d + (-T_final * inv1ma) * bgdot);
+                    else if (EXACT)
                         Gd = (SGR_EXACT_TRIM && bg_zero) ? G * d
                                                          : G * (d + (SGR_EXACT_TRIM ? sgr_div_by(-T_final, oma, inv1ma) : -T_final / oma) * bgdot);
                     else
@@ -639,6 +654,17 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                     for (int t = 0; t < NVAL / 4; t++) atomicAdd(&dst[4 * t], r[t]);
                 }
         };
+        // parity mode: G = exp(power), power in natural-log units (see SGR_EXACT_BWD_FAST)
+        auto exactG = [&](const float pw, const float opac) __attribute__((always_inline)) -> float {
+            if constexpr (SGR_EXACT_BWD_FAST != 0) {
+                float g = __builtin_amdgcn_exp2f(pw * SGR_LOG2E);
+                const bool near = fabsf(opac * g - SGR_ALPHA_MIN) <= 4.0e-6f * SGR_ALPHA_MIN;
+                if (SGR_EXACT_BWD_GUARD && __builtin_amdgcn_ballot_w64(near) != 0) g = SGR_EXACT_TRIM ? sgr_expf_ref(pw) : expf(pw);
+                return g;
+            } else {
+                return SGR_EXACT_TRIM ? sgr_expf_ref(pw) : expf(pw);
+            }
+        };
         for (int chunk = 0; chunk < BATCH / 64; chunk++) {
             uint64_t m;
             m = sBits[wave][chunk];
@@ -654,7 +680,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                 const float4 a0 = sA[j0], q0 = sB[j0];
                 const float dx0 = a0.x - pxf, dy0 = a0.y - pyf;
                 const float pw0 = EXACT ? sgr_power_ref_staged(q0.x, q0.y, q0.z, dx0, dy0) : sgr_power2(q0.x, q0.y, q0.z, dx0, dy0);
-                const float G0 = EXACT ? (SGR_EXACT_TRIM ? sgr_expf_ref(pw0) : expf(pw0)) : __builtin_amdgcn_exp2f(pw0);
+                const float G0 = EXACT ? exactG(pw0, q0.w) : __builtin_amdgcn_exp2f(pw0);
                 process(j0, q0, dx0, dy0, pw0, G0, fminf(0.99f, q0.w * G0));
             }
             while (m) {
@@ -667,7 +693,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                 const float dx0 = a0.x - pxf, dy0 = a0.y - pyf, dx1 = a1.x - pxf, dy1 = a1.y - pyf;
                 const float pw0 = EXACT ? sgr_power_ref_staged(q0.x, q0.y, q0.z, dx0, dy0) : sgr_power2(q0.x, q0.y, q0.z, dx0, dy0);
                 const float pw1 = EXACT ? sgr_power_ref_staged(q1.x, q1.y, q1.z, dx1, dy1) : sgr_power2(q1.x, q1.y, q1.z, dx1, dy1);
-                const float G0 = EXACT ? (SGR_EXACT_TRIM ? sgr_expf_ref(pw0) : expf(pw0)) : __builtin_amdgcn_exp2f(pw0), G1 = EXACT ? (SGR_EXACT_TRIM ? sgr_expf_ref(pw1) : expf(pw1)) : __builtin_amdgcn_exp2f(pw1);
+                const float G0 = EXACT ? exactG(pw0, q0.w) : __builtin_amdgcn_exp2f(pw0), G1 = EXACT ? exactG(pw1, q1.w) : __builtin_amdgcn_exp2f(pw1);
                 const float al0 = fminf(0.99f, q0.w * G0), al1 = fminf(0.99f, q1.w * G1);
                 process(j0, q0, dx0, dy0, pw0, G0, al0);
                 process(j1, q1, dx1, dy1, pw1, G1, al1);

@@ -23,6 +23,9 @@ __device__ __forceinline__ float sgr_sel_mask(uint64_t m, float a, float b) {
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
     return r;
 }
+#ifndef SGR_EXACT_COLOR_FUSED
+#define SGR_EXACT_COLOR_FUSED 1  // parity mode: the three colour sums as FMAs (see blend_one); 0: unfused like depth (A/B)
+#endif
 #ifndef SGR_EXACT_TRIM
 #define SGR_EXACT_TRIM 1  // parity mode: sgr_expf_ref instead of the library's expf (same bits, sgr_math.h)
 #endif
@@ -160,11 +163,20 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                     const float4 c = sC[j];
                     const float w = SGR_BLEND_SEL(alpha * T, 0.0f);
                     if (EXACT) {
-                        // the reference's association, unfused: C[ch] += features[ch] * alpha * T (forward.cu:438-441)
+                        // the reference's association, unfused: C[ch] += features[ch] * alpha * T (forward.cu:438-441) -- for the
+                        // DEPTH (and semantic) sums, whose images the parity mode reproduces bit for bit.  The colour sums take the
+                        // fused form (SGR_EXACT_COLOR_FUSED): their inputs already differ from the reference's in the last bit
+                        // (the SH evaluation), the image is held to rel 1e-4, and no gradient depends on it
                         const float ae = SGR_BLEND_SEL(alpha, 0.0f);
-                        C0 = C0 + (c.x * ae) * T;
-                        C1 = C1 + (c.y * ae) * T;
-                        C2 = C2 + (c.z * ae) * T;
+                        if (SGR_EXACT_COLOR_FUSED) {
+                            C0 = fmaf(c.x, w, C0);
+                            C1 = fmaf(c.y, w, C1);
+                            C2 = fmaf(c.z, w, C2);
+                        } else {
+                            C0 = C0 + (c.x * ae) * T;
+                            C1 = C1 + (c.y * ae) * T;
+                            C2 = C2 + (c.z * ae) * T;
+                        }
                         Dp = Dp + (c.w * ae) * T;
                     } else {
                         C0 = fmaf(c.x, w, C0);
