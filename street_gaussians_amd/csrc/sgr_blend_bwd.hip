@@ -64,6 +64,9 @@ struct SgrBwdBatch { static constexpr int value = SMAX <= 8 ? SGR_BWD_BATCH : SG
 #ifndef SGR_EXACT_BWD_FAST
 #define SGR_EXACT_BWD_FAST 1  // 0: every function of the backward with the reference's bits (A/B: tools/build_variant.py)
 #endif
+#ifndef SGR_BWD_NEWTON
+#define SGR_BWD_NEWTON 0  // 1: a Newton step on v_rcp_f32(1 - alpha) before the T recovery (rounds 1-4; measured in round 5: no parity figure moves without it)
+#endif
 #ifndef SGR_EXACT_BWD_GUARD
 #define SGR_EXACT_BWD_GUARD 1  // 0 only for tools/valu_model.py (a static count of the loop without its rare branch)
 #endif
@@ -457,7 +460,8 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                 if (hit) {
                     const float oma = 1.0f - alpha;
                     float inv1ma = __builtin_amdgcn_rcpf(oma);
-                    inv1ma = fmaf(fmaf(-oma, inv1ma, 1.0f), inv1ma, inv1ma);  // Newton step: T recovery compounds per layer
+                    if (SGR_BWD_NEWTON || (EXACT && !SGR_EXACT_BWD_FAST))
+                        inv1ma = fmaf(fmaf(-oma, inv1ma, 1.0f), inv1ma, inv1ma);  // Newton step: T recovery compounds per layer
                     // T = T / (1 - alpha) (backward.cu:547).  EXACT: the IEEE quotient, from the refined reciprocal above
                     // and two residual corrections (sgr_div_by: the bits of `/` for these operand ranges)
                     T = (EXACT && !SGR_EXACT_BWD_FAST) ? (SGR_EXACT_TRIM ? sgr_div_by(T, oma, inv1ma) : T / oma) : T * inv1ma;
