@@ -171,3 +171,20 @@ def test_parity_mode_elementary_functions_have_the_bits_of_expf_and_division():
     # and the quotient really is the correctly rounded one
     q64 = (a.double() / b.double()).float()
     assert (outs[3].cpu() == q64).all()
+
+
+def test_fast_exp_stays_well_inside_the_guard_band_of_the_parity_backward():
+    """The parity mode's backward takes G = exp(power) from exp2(power * log2 e) and falls back to the accurate expf for a
+    visit with a pixel whose alpha is within 4e-6 (relative) of the 1/255 threshold (csrc/sgr_blend_bwd.hip,
+    SGR_EXACT_BWD_FAST).  That keeps every blend / skip decision the forward's as long as the fast G is much closer than
+    4e-6 to the true one WHERE ALPHA CAN SIT AT THE THRESHOLD: alpha = o * G = 1/255 with o <= 1 means power >= -ln 255 =
+    -5.54.  Swept here with the GPU's own exp2 (f32) against float64: measured 4.3e-7 at worst (the rounding of the product
+    below 8, the f32 constant, 0.08e-6 from the exp2 instruction itself), held to 6e-7 -- a seventh of the band."""
+    g = torch.Generator().manual_seed(11)
+    x = -(torch.rand(1 << 24, generator=g) * 5.6).cuda()  # power in (-5.6, 0]
+    log2e = torch.tensor(1.4426950408889634, dtype=torch.float32, device="cuda")
+    fast = torch.exp2(x * log2e)  # f32 product rounded once, then the exp2 instruction: the kernel's sequence
+    ref = torch.exp(x.double())
+    rel = ((fast.double() - ref).abs() / ref).max().item()
+    assert rel < 6.0e-7, rel
+    # and the accurate path the guard falls back to is expf itself (bit-checked in the test above)
