@@ -836,9 +836,10 @@ def main():
             kernel_samples, kernel_region = (n + 7) // 8, f"the sustained region of {n} steps"
     # The CONFORMING configurations (north_star: "tile/bin indices bit-exact ... within 1e-4 rel"), measured on the same
     # workload in regions of their own so that their cost is in the line next to `value`:
-    #   exact  = sgr_test_switches bit 7 (SGR_EXACT=1): the reference's power expression, the device library's expf, the IEEE
-    #            quotient T / (1 - alpha), unfused; K12/K13 without FP contraction -- alpha / depth / semantic images
-    #            bit-identical to the reference's strict build, every gradient within rel 1e-4 END TO END;
+    #   exact  = sgr_test_switches bit 7 (SGR_EXACT=1): the forward with the reference's power expression, the device library's
+    #            expf and the unfused depth / alpha / semantic sums; the backward with the reference's power expression and every
+    #            blend / skip decision guarded to be the forward's; K12/K13 without FP contraction -- alpha / depth / semantic
+    #            images bit-identical to the reference's strict build, every gradient within rel 1e-4 END TO END;
     #   strict = bits 7 + 10 (SGR_EXACT=1 SGR_REF_RECT=1): additionally the reference's own tile rects, so that
     #            num_rendered / point_list / keys / ranges / n_contrib are the reference's ENTRY FOR ENTRY
     #            (tests/test_gpu_fullsize.py: test_threeway_against_reference_kernels_at_baseline_size).
@@ -1092,10 +1093,13 @@ def main():
             line["modes"] = dict(modes, what="exact = sgr_test_switches bit 7 (SGR_EXACT=1): meets north_star's 1e-4 gate END TO END "
                                  "against the reference's kernels (alpha / depth / semantic images bit-identical); strict = bits 7 + 10 "
                                  "(+ SGR_REF_RECT=1): additionally the reference's tile rects, binning arrays entry for entry; "
-                                 "`value` = default arithmetic (v_exp_f32 on a pre-scaled conic, Newton-refined reciprocal, "
-                                 "contraction) on the cut-down tile lists: same algorithm, different last bits (DESIGN.md section 4)")
+                                 "`value` = default arithmetic (v_exp_f32 on a pre-scaled conic, v_rcp_f32, contraction) on the cut-down "
+                                 "tile lists: same algorithm, different last bits (DESIGN.md section 4).  In the parity mode the forward "
+                                 "has the reference's bits in every function that decides an index or one of those images; the "
+                                 "backward evaluates the reference's power expression and makes every blend / skip decision as the "
+                                 "forward did (a guard around the fast exp), which is what the 1e-4 gate on the gradients needs")
         if lazy_info is not None:
-            line["lazy"] = dict(lazy_info, what="sgr_set_lazy(1): list capacity from the previous frames, no host wait in the step "
+            line["lazy"] = dict(lazy_info, what="sgr_set_lazy(1): list capacity from the previous frames, no wait for the frame's own num_rendered "
                                 "(ms_per_step_lazy: eager launches; ms_per_step_graph: forward + backward captured once in a "
                                 "hipGraph and replayed); bit-identical outputs (tests/test_gpu_graph.py); opt-in, not `value`")
         if exchange_overlap is not None:
