@@ -71,3 +71,22 @@ def test_product_has_no_cpu_fallback():
         losses.ssim(z(3, 8, 8), z(3, 8, 8))
     with pytest.raises(SgrError):
         scene.compose([scene.Segment(z(2, 3), z(2, 4), z(2, 3), z(2, 1), z(2, 1, 3), z(2, 15, 3))], 16, 0)
+
+
+def test_host_only_entry_points_answer_without_a_gpu(lib):
+    """The entry points that only read or set process-wide host state make no HIP call: the ABI version (bumped whenever a
+    struct of include/sgr.h grows: sgr_backward_extras), whether the A/B designs are compiled in (not in the shipped build),
+    and the lazy switch (query, set, restore; its status call reports that no lazy forward has run on this thread)."""
+    lib.sgr_version.restype = C.c_int
+    assert lib.sgr_version() >= 101
+    assert lib.sgr_has_variants() == 0
+    prev = lib.sgr_set_lazy(-1)
+    assert prev in (0, 1)
+    assert lib.sgr_set_lazy(1) == prev
+    assert lib.sgr_set_lazy(-1) == 1
+    r, c, f = C.c_int(), C.c_int(), C.c_int()
+    assert lib.sgr_lazy_status(C.byref(r), C.byref(c), C.byref(f)) < 0
+    lib.sgr_last_error.restype = C.c_char_p
+    assert b"lazy" in lib.sgr_last_error()
+    lib.sgr_set_lazy(prev)
+    assert lib.sgr_set_lazy(-1) == prev
