@@ -62,6 +62,13 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1280)
     ap.add_argument("--semantics", type=int, default=0)
+    ap.add_argument("--mode", choices=["strict", "exact", "fast"], default="strict",
+                    help="which configuration the timed region (`value`) runs in.  strict (default): parity arithmetic on the "
+                         "reference's own tile rects (sgr_test_switches bits 7 + 10) -- the configuration that meets north_star's "
+                         "parity sentence as worded (binning arrays the reference's entry for entry, images / gradients within "
+                         "rel 1e-4 end to end); exact: parity arithmetic on the cut-down tile lists (bit 7); fast: the library's "
+                         "default arithmetic on the cut-down lists.  The other two are measured in extra regions of the same run "
+                         "(value_strict / value_exact / value_fast)")
     ap.add_argument("--loss", choices=["grads", "scalar"], default="grads",
                     help="grads: backward from fixed upstream gradients; scalar: torch-built loss sum(out*w)")
     ap.add_argument("--reduce", choices=["factored", "bucket"], default="factored",
@@ -86,6 +93,29 @@ def parse():
                     "read with street_gaussians_amd.plyio) to render instead of the synthetic Gaussians")
     ap.add_argument("--cpu-sample-gaussians", type=int, default=0, help="override the CPU sample size")
     return ap.parse_args()
+
+
+def host_cpu():
+    """(model name, {"threads": hardware threads, "sockets": packages, "physical_cores": distinct (package, core) pairs}) from
+    /proc/cpuinfo: `cpu_baseline.cores` counts THREADS the oracle used; SMT siblings are not cores."""
+    model, sockets, phys, threads = "unknown", set(), set(), 0
+    try:
+        pid = None
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name") and model == "unknown":
+                    model = ln.split(":", 1)[1].strip()
+                elif ln.startswith("processor"):
+                    threads += 1
+                elif ln.startswith("physical id"):
+                    pid = ln.split(":", 1)[1].strip()
+                    sockets.add(pid)
+                elif ln.startswith("core id"):
+                    phys.add((pid, ln.split(":", 1)[1].strip()))
+    except OSError:
+        pass
+    return model, {"threads": threads or (os.cpu_count() or 1), "sockets": len(sockets) or None,
+                   "physical_cores": len(phys) or None}
 
 
 def cpu_baseline(args, cam, sc):
@@ -113,16 +143,8 @@ def cpu_baseline(args, cam, sc):
                 break
         return best, R
 
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    model = "unknown"
-    try:
-        with open("/proc/cpuinfo") as f:
-            for ln in f:
-                if ln.startswith("model name"):
-                    model = ln.split(":", 1)[1].strip()
-                    break
-    except OSError:
-        pass
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))  # OpenMP THREADS the oracle runs on
+    model, topo = host_cpu()
     Ws, Hs = max(16, args.width // 4), max(16, args.height // 4)
     small = syn.make_camera(Ws, Hs, fx=args.width / (2.0 * cam.tanfovx))
     t_small, R_small = run(Ws, Hs, small, 2)
@@ -144,12 +166,14 @@ def cpu_baseline(args, cam, sc):
         one = {"error": str(ex)[:120]}
     if 16.0 * t_small <= 30.0:  # the whole frame fits the budget: report the real thing
         t_full, R_full = run(args.width, args.height, cam, 2)
-        return {"value": round(1.0 / t_full, 4), "unit": "iters/s", "cores": cores, "cpu_model": model, "kind": "port",
+        return {"value": round(1.0 / t_full, 4), "unit": "iters/s", "cores": cores, "threads": cores, "host": topo,
+                "cores_note": "`cores` = OpenMP threads used (= hardware threads incl. SMT siblings); host.physical_cores / "
+                              "host.sockets describe the box", "cpu_model": model, "kind": "port",
                 "sample": f"oracle fwd+bwd (OpenMP), the full workload: all {sc.P} Gaussians, {args.width}x{args.height} "
                           f"(R={R_full}), best of 2", "seconds": round(t_full, 3),
                 "window_1_16_seconds": round(t_small, 3), "one_thread": one}
-    return {"value": round(1.0 / t_small, 4), "unit": "iters/s on the sample", "cores": cores, "cpu_model": model,
-            "kind": "port",
+    return {"value": round(1.0 / t_small, 4), "unit": "iters/s on the sample", "cores": cores, "threads": cores, "host": topo,
+            "cpu_model": model, "kind": "port",
             "sample": f"oracle fwd+bwd (OpenMP), all {sc.P} Gaussians, central {Ws}x{Hs} window = 1/16 of the "
                       f"{args.width}x{args.height} pixels (R={R_small}); full-frame rate ~ value/16",
             "seconds": round(t_small, 3), "one_thread": one}
@@ -701,7 +725,11 @@ def launch_plan(n_gpus, env, device_count, argv, port=None):
         return None
     if n_gpus < 1:
         raise SystemExit(f"--gpus {n_gpus}: need at least one GPU")
-    if device_count < n_gpus:
+    share = bool(env.get("SGR_BENCH_SHARE_GPU"))
+    if share and env.get("SGR_BENCH_BACKEND", "nccl") != "gloo":
+        raise SystemExit("SGR_BENCH_SHARE_GPU=1 (all ranks on cuda:0: a TEST of the N > 1 rank program on a one-GPU box) needs "
+                         "SGR_BENCH_BACKEND=gloo -- RCCL refuses two ranks on one device")
+    if device_count < n_gpus and not (share and device_count >= 1):
         raise SystemExit(f"--gpus {n_gpus} but only {device_count} GPU(s) are visible: refusing to run on fewer ranks")
     if n_gpus == 1:
         return None
@@ -727,6 +755,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    # SGR_BENCH_SHARE_GPU=1 + SGR_BENCH_BACKEND=gloo: every rank on cuda:0, collectives over gloo (CUDA tensors staged through
+    # the host) -- the N > 1 rank program end to end on a one-GPU box (tests/test_gpu_multiview.py); never a measurement
+    backend = os.environ.get("SGR_BENCH_BACKEND", "nccl")
+    share_gpu = bool(os.environ.get("SGR_BENCH_SHARE_GPU"))
+    if share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -736,12 +770,20 @@ def main():
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29511"
             os.environ.setdefault("RANK", "0"), os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from street_gaussians_amd import _native
     from street_gaussians_amd import build as sgr_build
 
     S = args.semantics
+    # the configuration of the timed region (every rank sets the same process-wide switches)
+    from street_gaussians_amd import _C as native_c
+    MODE_MASK = {"strict": native_c.EXACT | native_c.REF_RECT, "exact": native_c.EXACT, "fast": 0}
+    base_switches = native_c.test_switches(-1) & ~(native_c.EXACT | native_c.REF_RECT)
+    native_c.test_switches(base_switches | MODE_MASK[args.mode])
     wl = Workload(args, args.gaussians, S, rank, dev, dist=dist, force_dist=force_dist, scene_file=args.scene)
     args.gaussians = wl.P
     reducer = wl.reducer
@@ -795,6 +837,12 @@ def main():
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    # after a blocking exchange every rank holds the SAME summed gradients, bit for bit (checksums, MIN == MAX over ranks)
+    grads_identical = None
+    if dist is not None and reducer is not None and args.exchange == "blocking":
+        from street_gaussians_amd import multiview
+        gl = [p.grad for p in wl.params.values()]
+        grads_identical = bool(all(g is not None for g in gl) and multiview.replicas_identical(gl))
 
     # ---- N > 1, extra: the OTHER exchange schedule on the same workload (the reported value is the blocking one: the
     # optimiser sees this step's summed gradients; "overlap" hides the exchange under the next step's forward, i.e. the
@@ -834,27 +882,31 @@ def main():
         if kernel_samples < 16 and s_timed.get("blend_bwd"):
             timed = dict(timed, blend_bwd=s_timed["blend_bwd"])
             kernel_samples, kernel_region = (n + 7) // 8, f"the sustained region of {n} steps"
-    # The CONFORMING configurations (north_star: "tile/bin indices bit-exact ... within 1e-4 rel"), measured on the same
-    # workload in regions of their own so that their cost is in the line next to `value`:
-    #   exact  = sgr_test_switches bit 7 (SGR_EXACT=1): the forward with the reference's power expression, the device library's
-    #            expf and the unfused depth / alpha / semantic sums; the backward with the reference's power expression and every
-    #            blend / skip decision guarded to be the forward's; K12/K13 without FP contraction -- alpha / depth / semantic
-    #            images bit-identical to the reference's strict build, every gradient within rel 1e-4 END TO END;
-    #   strict = bits 7 + 10 (SGR_EXACT=1 SGR_REF_RECT=1): additionally the reference's own tile rects, so that
-    #            num_rendered / point_list / keys / ranges / n_contrib are the reference's ENTRY FOR ENTRY
-    #            (tests/test_gpu_fullsize.py: test_threeway_against_reference_kernels_at_baseline_size).
-    # `value` itself is the default arithmetic on the cut-down tile lists (same images bit for bit, same sums regrouped).
+    # The three configurations, measured on the same workload.  The timed region above ran in `args.mode` (default strict);
+    # the other two get regions of their own so that their cost is in the line next to `value`:
+    #   strict = sgr_test_switches bits 7 + 10 (SGR_EXACT=1 SGR_REF_RECT=1): the forward with the reference's power expression,
+    #            the device library's expf and the unfused depth / alpha / semantic sums; the backward with the reference's power
+    #            expression and every blend / skip decision guarded to be the forward's; K12/K13 without FP contraction; AND the
+    #            reference's own tile rects, so that num_rendered / point_list / keys / ranges / n_contrib are the reference's
+    #            ENTRY FOR ENTRY, alpha / depth / semantic images bit-identical to the reference's strict build, every gradient
+    #            within rel 1e-4 END TO END (tests/test_gpu_fullsize.py: test_threeway_against_reference_kernels_at_baseline_size)
+    #   exact  = bit 7 alone: the same arithmetic on the cut-down tile lists (the reference's lists minus the instances that
+    #            cannot blend);
+    #   fast   = the library's default arithmetic (v_exp_f32 on a pre-scaled conic, v_rcp_f32, contraction) on the cut-down
+    #            lists: same algorithm, different last bits.
     modes = {}
     if world == 1 and dist is None:
-        from street_gaussians_amd import _C as native_c
-        prev = native_c.test_switches(-1)
-        for label, mask in (("exact", native_c.EXACT), ("strict", native_c.EXACT | native_c.REF_RECT)):
-            native_c.test_switches(prev | mask)
+        for label in ("strict", "exact", "fast"):
+            mask = MODE_MASK[label]
+            native_c.test_switches(base_switches | mask)
             try:
                 for _ in range(5):
                     wl.step()
-                n_p = max(args.steps, int(0.6 / max(dt / args.steps, 1e-5)) + 1)  # the same kind of region as `sustained`
-                pdt, _ = profiled_steps(L, wl, fence, n_p, 0)
+                if label == args.mode:  # the headline region itself; only its stage pass is added here
+                    n_p, pdt = args.steps, dt
+                else:
+                    n_p = max(args.steps, int(0.6 / max(dt / args.steps, 1e-5)) + 1)  # the same kind of region as `sustained`
+                    pdt, _ = profiled_steps(L, wl, fence, n_p, 0)
                 _, p_stage = profiled_steps(L, wl, fence, 16, 0x1FF)
                 m_R, m_V, _ = wl.counts()  # under the switch: what this mode emits
                 modes[label] = {"steps": n_p, "ms_per_step": round(1e3 * pdt / n_p, 4), "iters_per_s": round(n_p / pdt, 3),
@@ -862,7 +914,7 @@ def main():
                                                                                  for k, v in p_stage.items()},
                                 "switches": int(mask)}
             finally:
-                native_c.test_switches(prev)
+                native_c.test_switches(base_switches | MODE_MASK[args.mode])
         for _ in range(3):
             wl.step()
     parity_mode = modes.get("exact")
@@ -871,7 +923,6 @@ def main():
     lazy_info = None
     if world == 1 and dist is None and S == 0:
         try:
-            from street_gaussians_amd import _C as native_c
             # host time spent waiting for the device inside sgr_forward (the read-back of num_rendered), blocking vs lazy
             fence()
             L.sgr_profile_host_wait_us(1)
@@ -952,14 +1003,16 @@ def main():
         fwd_ms = stage_ms["blend_fwd"]
         traffic, valu, traffic_note, pmc_derived = None, None, None, None
         tfile = os.path.join(ROOT, "profiles", "pmc_blend_bwd.json")
-        kernel_name = "sgr_blend_bwd_kernel_s0" if S == 0 else "sgr_blend_bwd_kernel"
+        exact_arith = args.mode in ("strict", "exact")
+        kernel_name = ("sgr_blend_bwd_kernel_exact" if exact_arith else
+                       ("sgr_blend_bwd_kernel_s0" if S == 0 else "sgr_blend_bwd_kernel"))
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
                 sha = sgr_build.source_sha16()
                 same_cfg = (tj.get("gaussians") == args.gaussians and tj.get("width") == args.width and
                             tj.get("height") == args.height and kernel_name in str(tj.get("kernel", "")) and
-                            (S == 0) == ("_s0" in str(tj.get("kernel", ""))) and not args.scene)
+                            tj.get("mode", "fast") == args.mode and tj.get("semantics", 0) == S and not args.scene)
                 if not same_cfg:
                     traffic_note = "profiles/pmc_blend_bwd.json was measured on another kernel / configuration"
                 elif tj.get("source_sha16") != sha:
@@ -967,7 +1020,7 @@ def main():
                                     f"this build is {sha}: re-run tools/gpu_evidence.sh + tools/pmc_summary.py")
                 else:
                     traffic = tj.get("hbm_bytes_per_launch")
-                    pmc_derived = tj.get("derived")
+                    pmc_derived = {k: v for k, v in (tj.get("derived") or {}).items() if "nominal" not in k}
                     traffic_note = "rocprofv3 PMC, 2*FETCH_SIZE + WRITE_SIZE per launch, " + str(tj.get("source", ""))[:120]
                     if tj.get("sq_insts_valu") and bwd_ms:
                         # what actually bounds the kernel: VALU wave-instructions (rocprofv3 SQ_INSTS_VALU) against
@@ -987,17 +1040,21 @@ def main():
         # s_memtime in the kernel, clock reported), times the visits of this frame, over the 1024 SIMDs at the ubench's clock
         valu_issue = None
         try:
-            vm = json.load(open(os.path.join(ROOT, "profiles", "r5", "valu_model.json")))
-            if S == 0 and bwd_ms and vm["default"].get("source_sha16") == sgr_build.source_sha16():
+            vm_path = os.path.join("profiles", "r6", "valu_model.json")
+            vm = json.load(open(os.path.join(ROOT, vm_path)))
+            vm_k = vm["parity_mode" if exact_arith else "default"]
+            if S == 0 and bwd_ms and vm_k.get("source_sha16") == sgr_build.source_sha16():
                 visits = count_visits(wl, R)
-                cyc, ghz = vm["default"]["valu_pipe_cycles_per_visit"], vm["default"]["clock_ghz"]
+                cyc, ghz = vm_k["valu_pipe_cycles_per_visit"], vm_k["clock_ghz"]
                 bound_ms = visits * cyc / (1024 * ghz * 1e9) * 1e3
                 valu_issue = {"bound": "valu_issue", "visits": visits, "valu_pipe_cycles_per_visit": cyc, "clock_ghz": ghz,
                               "bound_ms": round(bound_ms, 4), "kernel_ms": round(bwd_ms, 4), "frac": round(bound_ms / bwd_ms, 3),
-                              "source": "profiles/r5/valu_model.json (static ISA model x instruction costs in cycles, "
+                              "achieved_gcycles_per_s": round(visits * cyc / (bwd_ms * 1e-3) / 1e9, 1),
+                              "peak_gcycles_per_s": round(1024 * ghz, 1),
+                              "source": vm_path + " (static ISA model x instruction costs in cycles, "
                                         "profiles/r5/valu_rates2.jsonl); time bound = visits * cycles / (1024 SIMDs * measured clock)"}
             elif S == 0:
-                valu_issue = {"note": "profiles/r5/valu_model.json was made for other kernel sources: re-run tools/valu_model.py"}
+                valu_issue = {"note": vm_path + " was made for other kernel sources: re-run tools/valu_model.py"}
         except Exception as ex:
             valu_issue = {"note": f"unavailable: {ex}"[:160]}
 
@@ -1011,23 +1068,49 @@ def main():
                     "achieved": round(be / (kms * 1e-3) / 1e9, 2), "frac": round(be / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                     "frac_on_reference_R": round(br / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
 
-        rl_default = kernel_roofline(bwd_ms, wl_R_emitted)
+        rl_head = kernel_roofline(bwd_ms, wl_R_emitted)  # the timed region's mode
         rl_modes = {k: kernel_roofline(m["stages_ms"].get("blend_bwd"), m["instances_emitted"]) for k, m in modes.items()}
+        rl_modes[args.mode] = rl_head
         g = lambda d, k: (d or {}).get(k)
+        mode_val = lambda k, f: (value if f == "iters_per_s" else ms_per_step) if k == args.mode else g(modes.get(k), f)
         line = {
             "metric": "train iters/s (fwd+bwd) @1M Gaussians 1920x1280 SH3",
             "value": value,
-            "value_exact": g(modes.get("exact"), "iters_per_s"),
-            "value_strict": g(modes.get("strict"), "iters_per_s"),
+            "mode": args.mode,
+            "conforming": args.mode == "strict",
+            "mode_note": {"strict": "`value` is the STRICTLY CONFORMING configuration: parity arithmetic on the reference's own tile "
+                                    "rects (SGR_EXACT=1 SGR_REF_RECT=1) -- binning arrays the reference's entry for entry, alpha / depth "
+                                    "/ semantic images bit-identical, colour and all nine gradient tensors within rel 1e-4 end to end "
+                                    "(gated at all four BASELINE sizes); value_fast = the library's default mode on the same workload",
+                          "exact": "`value` is the parity arithmetic on the cut-down tile lists (SGR_EXACT=1)",
+                          "fast": "`value` is the library's DEFAULT mode (fast arithmetic, cut-down tile lists), NOT the "
+                                  "conforming one: see value_strict"}[args.mode],
+            "value_strict": mode_val("strict", "iters_per_s"),
+            "value_exact": mode_val("exact", "iters_per_s"),
+            "value_fast": mode_val("fast", "iters_per_s"),
             "unit": "iters/s",
             "n_gpus": world,
-            "rccl_ranks": (dist.get_world_size() if dist is not None else 0),
+            "rccl_ranks": (dist.get_world_size() if (dist is not None and backend == "nccl") else 0),
+            "dist_ranks": (dist.get_world_size() if dist is not None else 0),
+            "dist_backend": (backend if dist is not None else None),
+            "ranks_share_one_gpu": share_gpu if dist is not None else None,
+            "summed_gradients_identical_on_all_ranks": grads_identical,
+            "exchange_direct_bucket_writes": (None if reducer is None else {
+                "dense_tensors_copied_into_the_bucket_last_step": getattr(getattr(reducer, "dense", reducer), "copied_last", None),
+                "what": "0 = the rasterizer backward wrote every dense gradient straight into the all-reduce bucket "
+                        "(multiview.GradReducer._sink); the masked dRGB goes straight into the all-gather payload and this "
+                        "view's own dL/dSH is not written (sgr_backward_extras.masked_color_out / skip_sh_grad)"}),
             "steps": args.steps,
             "warmup": args.warmup,
             "device_warmup_s": args.device_warmup,
             "ms_per_step": ms_per_step,
-            "ms_per_step_exact": g(modes.get("exact"), "ms_per_step"),
-            "ms_per_step_strict": g(modes.get("strict"), "ms_per_step"),
+            "ms_per_step_strict": mode_val("strict", "ms_per_step"),
+            "ms_per_step_exact": mode_val("exact", "ms_per_step"),
+            "ms_per_step_fast": mode_val("fast", "ms_per_step"),
+            "blend_bwd_kernel_ms": round(bwd_ms, 4) if bwd_ms else None,
+            "blend_bwd_kernel_ms_strict": g(rl_modes.get("strict"), "kernel_ms"),
+            "blend_bwd_kernel_ms_exact": g(rl_modes.get("exact"), "kernel_ms"),
+            "blend_bwd_kernel_ms_fast": g(rl_modes.get("fast"), "kernel_ms"),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -1036,15 +1119,15 @@ def main():
             "config": {"workload": f"{args.gaussians} " + ("synthetic Gaussians (SURVEY 8d recipe, seed 0)" if not args.scene
                                    else f"Gaussians of {os.path.basename(args.scene)}") +
                                    f", {args.width}x{args.height}, SH degree 3, S={S} semantic channels, "
-                                   f"rasterizer forward+backward, one camera view per GPU",
+                                   f"rasterizer forward+backward, one camera view per GPU, mode {args.mode}",
                        "gaussians": args.gaussians, "width": args.width, "height": args.height, "sh_degree": 3,
                        "semantic_channels": S, "loss": args.loss, "views_per_step": world, "num_rendered_R": R, "visible_V": V,
                        "R_over_P": round(R / args.gaussians, 3), "V_over_P": round(V / args.gaussians, 3),
                        "instances_emitted": wl_R_emitted,
                        "instances_note": "num_rendered_R = the reference's num_rendered (3-sigma squares, auxiliary.h getRect), the "
-                                         "unit of SURVEY 8d's byte formulas; instances_emitted = what the default mode duplicates, sorts "
-                                         "and blends (rects cut down to the tiles where the Gaussian can reach alpha >= 1/255, with a tile mask inside them; "
-                                         "bit-identical images); value_strict runs on the reference's rects (SGR_REF_RECT=1)",
+                                         "unit of SURVEY 8d's byte formulas; instances_emitted = what this mode duplicates, sorts and "
+                                         "blends (strict: the same number; exact / fast: rects cut down to the tiles where the Gaussian "
+                                         "can reach alpha >= 1/255, with a tile mask inside them -- bit-identical images)",
                        "parallelism": f"view-dp{world}" + ((" + RCCL all-reduce of Gaussian grads" + (
                            " (dense 44 B/Gaussian; SH gradient rebuilt from an all-gather of per-view dRGB, 12 B/Gaussian/view)"
                            if args.reduce == "factored" else " (one 236 B/Gaussian bucket)")) if world > 1 else ""),
@@ -1053,22 +1136,32 @@ def main():
                            "side stream, overlapped with the next step's forward (one-step-delayed gradients in training)"
                            if args.exchange == "overlap" else "blocking, inside the step")),
                        "kernel_sources_sha16": sgr_build.source_sha16()},
-            # scalars first (the driver's record keeps the scalar fields of this object): `frac` is on the instances the
-            # launch processes; the three modes side by side
-            "roofline": {"bound": "hbm", "kernel": kernel_name,
-                         "achieved": g(rl_default, "achieved"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": g(rl_default, "frac"), "frac_on_reference_R": g(rl_default, "frac_on_reference_R"),
+            # The dominant kernel (blend backward) is bound by VALU ISSUE, not by HBM: `bound` says so and the
+            # valu_* scalars are its roofline; achieved / peak / unit / frac / traffic are the HBM figures the metric asks for
+            # (algorithmic bytes of the instances the launch processes / kernel time, against 8 TB/s).
+            "roofline": {"bound": "valu_issue", "kernel": kernel_name, "mode": args.mode,
+                         "achieved": g(rl_head, "achieved"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": g(rl_head, "frac"), "frac_on_reference_R": g(rl_head, "frac_on_reference_R"),
                          "traffic": traffic,
-                         "kernel_ms": g(rl_default, "kernel_ms"),
-                         "kernel_ms_exact": g(rl_modes.get("exact"), "kernel_ms"), "frac_exact": g(rl_modes.get("exact"), "frac"),
-                         "kernel_ms_strict": g(rl_modes.get("strict"), "kernel_ms"), "frac_strict": g(rl_modes.get("strict"), "frac"),
                          "valu_issue_frac": g(valu_issue, "frac"),
-                         "algorithmic_bytes_per_launch": g(rl_default, "algorithmic_bytes_per_launch"),
+                         "valu_achieved_gcycles_per_s": g(valu_issue, "achieved_gcycles_per_s"),
+                         "valu_peak_gcycles_per_s": g(valu_issue, "peak_gcycles_per_s"),
+                         "kernel_ms": g(rl_head, "kernel_ms"),
+                         "kernel_ms_strict": g(rl_modes.get("strict"), "kernel_ms"), "frac_strict": g(rl_modes.get("strict"), "frac"),
+                         "kernel_ms_exact": g(rl_modes.get("exact"), "kernel_ms"), "frac_exact": g(rl_modes.get("exact"), "frac"),
+                         "kernel_ms_fast": g(rl_modes.get("fast"), "kernel_ms"), "frac_fast": g(rl_modes.get("fast"), "frac"),
+                         "algorithmic_bytes_per_launch": g(rl_head, "algorithmic_bytes_per_launch"),
                          "algorithmic_bytes_note": "SURVEY 8d: (44+4S) R + (28+4S) N + (48+4S) V with R = the instances the launch "
                                                    "processes (config.instances_emitted); frac_on_reference_R: the same with the "
                                                    "reference's num_rendered",
+                         "bound_note": "`frac` (and achieved / peak / unit / traffic) is the HBM figure BASELINE.json's metric asks "
+                                       "for; the kernel's own bound is VALU issue: valu_issue_frac = (visits x pipe cycles per visit "
+                                       "of its instruction stream at measured instruction costs) / (1024 SIMDs x measured clock x "
+                                       "kernel time).  north_star's '>= 60 % of the HBM roofline in the blend kernel' is not reachable "
+                                       "by this algorithm (0.45 GB of compulsory bytes against ~1.6e8 (pixel, Gaussian) pairs of ~80 "
+                                       "flops each; SURVEY 8d)",
                          "traffic_note": traffic_note, "valu": valu, "valu_issue": valu_issue, "pmc": pmc_derived,
-                         "modes": {"default": rl_default, **rl_modes},
+                         "modes": rl_modes,
                          "kernel_ms_source": f"HIP events around the kernel on its launch stream, mean over "
                                              f"{kernel_samples} launches of {kernel_region} "
                                              f"(every 8th step at most carries the event pair)",
@@ -1082,22 +1175,14 @@ def main():
                          "stages_bytes_source": "SURVEY 8d algorithmic bytes (B_pre, B_scan, B_dup, B_sort = 24 R, B_rng, "
                                                 "B_blend_f, B_blend_b, B_pre_b) with R = the emitted instances; frac = bytes / "
                                                 "stage time / 8 TB/s",
-                         "sum_n_contrib_pairs": pairs_blended,
-                         "note": "the blend kernels are VALU-issue bound (SURVEY 8d; `valu_issue`: the backward runs at that "
-                                 "fraction of its pipes' capacity at measured instruction costs); the HBM fraction is reported "
-                                 "as the metric demands"},
+                         "sum_n_contrib_pairs": pairs_blended},
         }
         if sustained is not None:
             line["sustained"] = sustained
         if modes:
-            line["modes"] = dict(modes, what="exact = sgr_test_switches bit 7 (SGR_EXACT=1): meets north_star's 1e-4 gate END TO END "
-                                 "against the reference's kernels (alpha / depth / semantic images bit-identical); strict = bits 7 + 10 "
-                                 "(+ SGR_REF_RECT=1): additionally the reference's tile rects, binning arrays entry for entry; "
-                                 "`value` = default arithmetic (v_exp_f32 on a pre-scaled conic, v_rcp_f32, contraction) on the cut-down "
-                                 "tile lists: same algorithm, different last bits (DESIGN.md section 4).  In the parity mode the forward "
-                                 "has the reference's bits in every function that decides an index or one of those images; the "
-                                 "backward evaluates the reference's power expression and makes every blend / skip decision as the "
-                                 "forward did (a guard around the fast exp), which is what the 1e-4 gate on the gradients needs")
+            line["modes"] = dict(modes, what="strict = sgr_test_switches bits 7 + 10 (SGR_EXACT=1 SGR_REF_RECT=1): north_star's parity "
+                                 "sentence as worded; exact = bit 7 alone (cut-down tile lists); fast = the library's default "
+                                 "arithmetic on the cut-down lists (DESIGN.md section 4)")
         if lazy_info is not None:
             line["lazy"] = dict(lazy_info, what="sgr_set_lazy(1): list capacity from the previous frames, no wait for the frame's own num_rendered "
                                 "(ms_per_step_lazy: eager launches; ms_per_step_graph: forward + backward captured once in a "
@@ -1127,18 +1212,18 @@ def main():
                 line["cpu_baseline"]["configs0_smoke_recipe"] = {"error": str(ex)[:160]}
         # LAST key: the figures a reader of the tail of this line needs, in one short object
         line["summary"] = {
-            "value": value, "ms_per_step": ms_per_step, "steps": args.steps,
-            "value_exact": line["value_exact"], "ms_per_step_exact": line["ms_per_step_exact"],
+            "value": value, "mode": args.mode, "conforming": args.mode == "strict", "ms_per_step": ms_per_step, "steps": args.steps,
             "value_strict": line["value_strict"], "ms_per_step_strict": line["ms_per_step_strict"],
+            "value_exact": line["value_exact"], "ms_per_step_exact": line["ms_per_step_exact"],
+            "value_fast": line["value_fast"], "ms_per_step_fast": line["ms_per_step_fast"],
             "sustained_ms_per_step": g(sustained, "ms_per_step"),
             "ms_per_step_lazy": g(lazy_info, "ms_per_step_lazy"), "ms_per_step_graph": g(lazy_info, "ms_per_step_graph"),
-            "blend_bwd_ms": {"default": g(rl_default, "kernel_ms"), "exact": g(rl_modes.get("exact"), "kernel_ms"),
-                             "strict": g(rl_modes.get("strict"), "kernel_ms")},
-            "blend_bwd_hbm_frac_on_processed_instances": {"default": g(rl_default, "frac"), "exact": g(rl_modes.get("exact"), "frac"),
-                                                          "strict": g(rl_modes.get("strict"), "frac")},
-            "blend_bwd_hbm_frac_on_reference_R": g(rl_default, "frac_on_reference_R"),
+            "blend_bwd_ms": {k: g(rl_modes.get(k), "kernel_ms") for k in ("strict", "exact", "fast")},
+            "blend_bwd_hbm_frac_on_processed_instances": {k: g(rl_modes.get(k), "frac") for k in ("strict", "exact", "fast")},
+            "blend_bwd_hbm_frac_on_reference_R": g(rl_head, "frac_on_reference_R"),
             "valu_issue_frac": g(valu_issue, "frac"),
-            "instances": {"reference_R": R, "emitted_default": wl_R_emitted},
+            "stages_ms": line["roofline"]["stages_ms"],
+            "instances": {"reference_R": R, "emitted": wl_R_emitted},
             "cpu_baseline_iters_per_s": g(line.get("cpu_baseline"), "value"),
             "reference_kernels_on_this_gpu_iters_per_s": g(line.get("reference_kernels_mi355x"), "iters_per_s")}
         try:  # RCCL prints a version banner through C stdio; flush it so the JSON line stays the last line
@@ -1174,13 +1259,29 @@ def other_configs(args, L, dev, fence):
             dt, _ = profiled_steps(L, wl, fence, steps, 0)
             _, st = profiled_steps(L, wl, fence, 10, 0x1FF)
             R, V, _ = wl.counts()
+            # the same in the library's default (fast) mode, when the run's mode is another one
+            fast = None
+            from street_gaussians_amd import _C as native_c
+            cur = native_c.test_switches(-1)
+            if cur & (native_c.EXACT | native_c.REF_RECT):
+                native_c.test_switches(cur & ~(native_c.EXACT | native_c.REF_RECT))
+                try:
+                    for _ in range(5):
+                        wl.step()
+                    fdt, _ = profiled_steps(L, wl, fence, steps, 0)
+                    _, fst = profiled_steps(L, wl, fence, 10, 0x1FF)
+                    fast = {"ms_per_step": round(1e3 * fdt / steps, 4),
+                            "stages_ms": {k: (round(v, 4) if v is not None else None) for k, v in fst.items()}}
+                finally:
+                    native_c.test_switches(cur)
             bb, fb = blend_bytes(S, R, args.width * args.height, V)
             sb = stage_bytes(P, wl.V_in, V, R, args.width * args.height, ((args.width + 15) // 16) * ((args.height + 15) // 16), S)
             Npx, Tt = args.width * args.height, ((args.width + 15) // 16) * ((args.height + 15) // 16)
             sbe = stage_bytes(P, wl.V_in, V, wl.R_emitted, Npx, Tt, S)  # on the instances the kernels process
             bbe = blend_bytes(S, wl.R_emitted, Npx, V)[0]
-            out.append({"config": name, "gaussians": P, "semantic_channels": S, "steps": steps,
+            out.append({"config": name, "gaussians": P, "semantic_channels": S, "steps": steps, "mode": args.mode,
                         "ms_per_step": round(1e3 * dt / steps, 4), "iters_per_s": round(steps / dt, 3),
+                        "ms_per_step_fast": (fast or {}).get("ms_per_step"), "fast": fast,
                         "num_rendered_R": R, "instances_emitted": wl.R_emitted, "visible_V": V,
                         "stages_hbm_frac": stage_hbm_frac(st, sbe), "stages_hbm_frac_on_reference_R": stage_hbm_frac(st, sb),
                         "blend_bwd_ms": round(st["blend_bwd"], 4) if st["blend_bwd"] else None,

@@ -111,8 +111,15 @@ typedef struct sgr_backward_extras {
     int rows; /* length of the three persistent arrays (rows); with segments every [dst_offset, dst_offset + count) must lie
                * inside [0, rows) and the destination ranges must be pairwise disjoint (two segments on the same rows would be
                * a racy read-modify-write) -- checked on the host, SGR_E_INVALID otherwise.  0 = unknown: not checked. */
-} sgr_backward_extras; /* layout of sgr_version() >= 101 (100 ended at n_segments: a caller built against that header must
-                        * not be run against this library -- check sgr_version() before passing the struct) */
+    float* masked_color_out; /* optional [P,3]: dL_dcolor with the channels the forward clamped at zero set to 0
+                              * (backward.cu:40-44) -- what sgr_masked_color_grad computes, written by the row-sum stage while
+                              * dL_dcolor is in registers (final at color_ready_event): the view-sharded exchange hands a slot
+                              * of its all-gather payload here and saves a launch and a 12 B/Gaussian copy.  NULL: not written. */
+    int skip_sh_grad; /* != 0: dL_dsh is NOT written (the pointer may be NULL although shs is given) -- the factored exchange
+                       * rebuilds the SH gradient of ALL views from the gathered dRGB (sgr_sh_grad_from_views), so this view's
+                       * own 12*M B/Gaussian would be written only to be overwritten.  Every other output is unchanged. */
+} sgr_backward_extras; /* layout of sgr_version() >= 102 (101 ended at rows, 100 at n_segments: a caller built against an
+                        * older header must not be run against this library -- check sgr_version() before passing the struct) */
 int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, int width, int height,
                     const float* means3D, const float* shs, const float* colors_precomp, const float* semantics,
                     const float* alphas, const float* scales, float scale_modifier, const float* rotations,

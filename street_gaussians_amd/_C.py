@@ -72,7 +72,7 @@ class _StatSegment(C.Structure):  # sgr_stat_segment (include/sgr.h)
 class _BackwardExtras(C.Structure):  # sgr_backward_extras (include/sgr.h)
     _fields_ = [("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p), ("max_radii2D", C.c_void_p),
                 ("segments", C.POINTER(_StatSegment)), ("n_segments", C.c_int), ("color_ready_event", C.c_void_p),
-                ("rows", C.c_int)]
+                ("rows", C.c_int), ("masked_color_out", C.c_void_p), ("skip_sh_grad", C.c_int)]
 
 
 MAX_STAT_SEGMENTS = 128  # SGR_MAX_STAT_SEGMENTS
@@ -173,7 +173,8 @@ def rasterize_gaussians(background, means3D, colors, semantics, opacity, scales,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                  dL_dout_alpha, dL_dout_semantic, sh, degree, campos, geomBuffer, R, binningBuffer,
-                                 imageBuffer, alphas, semantics, debug, stats=None, color_event=None):
+                                 imageBuffer, alphas, semantics, debug, stats=None, color_event=None, out=None,
+                                 masked_color_out=None, skip_sh_grad=False):
     """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:126-220).  Returns
     (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dsemantic).
     stats (extension): (xyz_gradient_accum [P,2], denom [P,1], max_radii2D [P]) contiguous float32 tensors updated in
@@ -181,10 +182,15 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     (src_start, count, dst_offset) segments mapping this call's Gaussians to rows of PERSISTENT statistics tensors of
     any length (a frame renders a subset of the sub-models, street_gaussian_model.py:230-250).
     color_event (extension): a torch.cuda.Event recorded on the current stream right after the row-sum stage, i.e. as
-    soon as dL_dcolors is final and before the per-Gaussian stage runs (sgr_backward_extras.color_ready_event)."""
+    soon as dL_dcolors is final and before the per-Gaussian stage runs (sgr_backward_extras.color_ready_event).
+    out (extension): {"means3D" | "means2D" | "colors" | "opacity" | "cov3D" | "sh" | "scales" | "rotations" | "semantics":
+    tensor} -- caller-supplied destinations for those gradients (contiguous float32 of the gradient's shape; e.g. views of
+    a gradient-exchange bucket, street_gaussians_amd.multiview) instead of fresh allocations; they are what is returned.
+    masked_color_out (extension): [P, 3] float32 destination of the clamp-masked colour gradient
+    (sgr_backward_extras.masked_color_out).  skip_sh_grad (extension): dL_dsh is not computed, None is returned for it."""
     _dev_check(means3D, "means3D")
     ext = _pybind()
-    if ext is not None and stats is None and color_event is None:
+    if ext is not None and stats is None and color_event is None and not out and masked_color_out is None and not skip_sh_grad:
         e = torch.Tensor([])
         z = lambda t: e if t is None else t
         return _call_ext(ext.rasterize_gaussians_backward, z(background), means3D, radii, z(colors), z(scales), z(rotations),
@@ -200,16 +206,25 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     with torch.cuda.device(dev):
         fopt = dict(dtype=torch.float32, device=dev)
         # every element is written by the kernels (include/sgr.h), so no torch.zeros (rasterize_points.cu:166-176)
-        mk = (lambda shape, **kw: _alloc.empty(shape, kw["dtype"], kw["device"])) if P else torch.zeros
-        dL_dmeans3D = mk((P, 3), **fopt)
-        dL_dmeans2D = mk((P, 3), **fopt)
-        dL_dcolors = mk((P, NUM_CHANNELS), **fopt)
-        dL_dopacity = mk((P, 1), **fopt)
-        dL_dcov3D = mk((P, 6), **fopt)
-        dL_dsh = mk((P, M, 3), **fopt)
-        dL_dscales = mk((P, 3), **fopt)
-        dL_drotations = mk((P, 4), **fopt)
-        dL_dsemantic = mk((P, S), **fopt)
+        mk0 = (lambda shape, **kw: _alloc.empty(shape, kw["dtype"], kw["device"])) if P else torch.zeros
+        out = out or {}
+
+        def mk(shape, name):
+            t = out.get(name)
+            if t is None:
+                return mk0(shape, **fopt)
+            if not (t.is_cuda and t.device == dev and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == tuple(shape)):
+                raise SgrError(f"out[{name!r}] must be a contiguous float32 HIP tensor of shape {tuple(shape)}")
+            return t
+        dL_dmeans3D = mk((P, 3), "means3D")
+        dL_dmeans2D = mk((P, 3), "means2D")
+        dL_dcolors = mk((P, NUM_CHANNELS), "colors")
+        dL_dopacity = mk((P, 1), "opacity")
+        dL_dcov3D = mk((P, 6), "cov3D")
+        dL_dsh = None if (skip_sh_grad and P) else mk((P, M, 3), "sh")
+        dL_dscales = mk((P, 3), "scales")
+        dL_drotations = mk((P, 4), "rotations")
+        dL_dsemantic = mk((P, S), "semantics")
         if P == 0:
             return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations,
                     dL_dsemantic)
@@ -240,11 +255,18 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                         raise SgrError("statistics segment outside the persistent tensors")
                     seg_arr[k] = _StatSegment(int(s0), int(cnt), int(d0))
                 keep.append(seg_arr)
-            extras = _BackwardExtras(acc.data_ptr(), den.data_ptr(), mr.data_ptr(), seg_arr, nseg, None, int(rows))
-        if color_event is not None:
+            extras = _BackwardExtras(acc.data_ptr(), den.data_ptr(), mr.data_ptr(), seg_arr, nseg, None, int(rows), None, 0)
+        if color_event is not None or masked_color_out is not None or skip_sh_grad:
             if extras is None:
-                extras = _BackwardExtras(None, None, None, None, 0, None, 0)
-            extras.color_ready_event = C.c_void_p(int(color_event.cuda_event))
+                extras = _BackwardExtras(None, None, None, None, 0, None, 0, None, 0)
+            if color_event is not None:
+                extras.color_ready_event = C.c_void_p(int(color_event.cuda_event))
+            if masked_color_out is not None:
+                m = masked_color_out
+                if not (m.is_cuda and m.dtype == torch.float32 and m.is_contiguous() and m.numel() == 3 * P):
+                    raise SgrError("masked_color_out must be a contiguous float32 HIP tensor of 3 * P elements")
+                extras.masked_color_out = C.c_void_p(m.data_ptr())
+            extras.skip_sh_grad = 1 if skip_sh_grad else 0
         check(_native.lib().sgr_backward_ex(
             P, int(degree), M, int(R), S, p(background, "bg"), W, H, p(means3D, "means3D"), p(sh, "sh"),
             p(colors, "colors_precomp"), p(semantics, "semantics"), p(alphas, "alpha"), p(scales, "scales"),

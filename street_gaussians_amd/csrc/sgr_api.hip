@@ -44,7 +44,7 @@ int sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const
                           float4* cd, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dsemantic,
                           const SgrStatSink& sink, int quad, int exact, int W, int H, hipEvent_t after_rows, int rs_wave,
-                          uint32_t row_limit, hipStream_t s);
+                          uint32_t row_limit, float* masked_color_out, int skip_sh, hipStream_t s);
 void sgr_launch_blend_bwd_sw(bool exact, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W, int H,
                              const float* bg, const float4* rec, const uint32_t* u0, const uint64_t* tmask, const float* alphas,
                              const uint32_t* n_contrib, const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth,
@@ -56,7 +56,7 @@ int sgr_launch_gauss_bwd_strict(int P, int D, int M, int S, const float* means3D
                                  float4* cd, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                                  float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dsemantic,
                                  const SgrStatSink& sink, int quad, int exact, int W, int H, hipEvent_t after_rows, int rs_wave,
-                                 uint32_t row_limit, hipStream_t s);
+                                 uint32_t row_limit, float* masked_color_out, int skip_sh, hipStream_t s);
 void sgr_launch_masked_color_grad(int P, const uint32_t* clamped, const float* dL_dcolor, float* out, hipStream_t s);
 void sgr_launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, size_t means_stride,
                                    const float* campos, size_t campos_stride, const float* drgb, size_t drgb_stride,
@@ -335,7 +335,7 @@ SgrFlagBlock sgr_acquire_flag_block() {
 extern "C" {
 
 const char* sgr_last_error(void) { return g_err.c_str(); }
-int sgr_version(void) { return 101; }  // 101: sgr_backward_extras gained color_ready_event + rows, sgr_test_sort32 max_bits
+int sgr_version(void) { return 102; }  // 102: sgr_backward_extras gained masked_color_out + skip_sh_grad (101: color_ready_event + rows)
 
 size_t sgr_geometry_bytes(int P) {
     return sgr_required([&](char* b, char** e) { sgr_geom_carve(b, (size_t)P, e); });
@@ -690,7 +690,8 @@ int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, 
         return fail(SGR_E_INVALID, "S > 0 needs semantics, dL_dpix_semantic and dL_dsemantic");
     if (!dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot)
         return fail(SGR_E_INVALID, "all gradient outputs except dL_dsh / dL_dsemantic are required");
-    if (shs && !dL_dsh) return fail(SGR_E_INVALID, "shs given but dL_dsh is NULL");
+    const int skip_sh = (extras && extras->skip_sh_grad) ? 1 : 0;
+    if (shs && !dL_dsh && !skip_sh) return fail(SGR_E_INVALID, "shs given but dL_dsh is NULL");
     const int gx = (W + SGR_BLOCK_X - 1) / SGR_BLOCK_X, gy = (H + SGR_BLOCK_Y - 1) / SGR_BLOCK_Y;
     const size_t N = (size_t)W * H, T = (size_t)gx * gy;
     const SgrGeomView gv = sgr_geom_carve(geom_buffer, (size_t)P);
@@ -749,7 +750,7 @@ int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, 
         P, D, M, S, means3D, radii_ptr, shs, scales, rotations, cov3D_precomp, cam_slot(gv), gv, partials, stride, touched, cd,
         dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, dL_dsemantic, sink, quad ? 1 : 0,
         (switches() & 128) ? 1 : 0, W, H, extras ? (hipEvent_t)extras->color_ready_event : nullptr, (switches() & 512) ? 1 : 0,
-        (uint32_t)R, stream);
+        (uint32_t)R, extras ? extras->masked_color_out : nullptr, skip_sh, stream);
     SGR_STAGE("gauss_bwd");
     prof_end(stream);
     if (ev_failed) return fail(SGR_E_HIP, "hipEventRecord(color_ready_event) failed: is it a valid event of this device?");

@@ -40,7 +40,8 @@ __global__ void __launch_bounds__(SGR_GB_THREADS)
 sgr_row_sum_kernel(int P, int S, const int* __restrict__ radii, SgrGeomView gv, const float* __restrict__ partials,
                    int row_stride, const uint8_t* __restrict__ touched, float* __restrict__ dL_dmean2D,
                    float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dsemantic,
-                   float4* __restrict__ cd, SgrStatSink sink, float kx, float ky, int exact, uint32_t row_limit) {
+                   float4* __restrict__ cd, SgrStatSink sink, float kx, float ky, int exact, uint32_t row_limit,
+                   float* __restrict__ masked_out) {
     constexpr int NV = (SGR_ROW_BASE_N + SMAX + 3) / 4;
     const int gtid = blockIdx.x * SGR_GB_THREADS + threadIdx.x;
     const int idx = gtid / SGR_RS_LANES, q = gtid % SGR_RS_LANES;
@@ -164,6 +165,15 @@ sgr_row_sum_kernel(int P, int S, const int* __restrict__ radii, SgrGeomView gv, 
         dL_dcolor[3 * idx + 0] = acc[7];
         dL_dcolor[3 * idx + 1] = acc[8];
         dL_dcolor[3 * idx + 2] = acc[9];
+        if (masked_out != nullptr) {
+            // sgr_backward_extras.masked_color_out: the colour gradient that reaches the SH coefficients (backward.cu:40-44:
+            // channels the forward clamped at zero get none) -- the payload of the view-sharded exchange, written here
+            // instead of by a launch of its own (sgr_masked_color_grad)
+            const uint32_t cl = n ? gv.clamped[idx] : 0u;  // (culled Gaussians: acc = 0 anyway, `clamped` is not written for them)
+            masked_out[3 * idx + 0] = (cl & 1u) ? 0.f : acc[7];
+            masked_out[3 * idx + 1] = (cl & 2u) ? 0.f : acc[8];
+            masked_out[3 * idx + 2] = (cl & 4u) ? 0.f : acc[9];
+        }
     } else if (q == 2) {
         cd[idx] = make_float4(acc[3], acc[4], acc[5], acc[10]);
     }
@@ -326,7 +336,7 @@ sgr_gauss_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, con
                      const SgrCam* __restrict__ camp, SgrGeomView gv, const float4* __restrict__ cd,
                      const float* __restrict__ dL_dmean2D, const float* __restrict__ dL_dcolor,
                      float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
-                     float* __restrict__ dL_dscale, float* __restrict__ dL_drot) {
+                     float* __restrict__ dL_dscale, float* __restrict__ dL_drot, int skip_sh) {
     const SgrCam& cam = *camp;
     // lanes past P stay alive (they help with the cooperative SH copies) on a clamped index; their stores are masked
     const int gidx = blockIdx.x * SGR_GB_THREADS + threadIdx.x;
@@ -470,7 +480,9 @@ sgr_gauss_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, con
             return make_float4(Y[(4 * i) / 3] * dRGB[(4 * i) % 3], Y[(4 * i + 1) / 3] * dRGB[(4 * i + 1) % 3],
                                Y[(4 * i + 2) / 3] * dRGB[(4 * i + 2) % 3], Y[(4 * i + 3) / 3] * dRGB[(4 * i + 3) % 3]);
         };
-        if (stage) {
+        if (skip_sh) {
+            // sgr_backward_extras.skip_sh_grad: the factored exchange rebuilds dL/dSH of all views (sgr_sh_grad_from_views)
+        } else if (stage) {
             float4* dst = reinterpret_cast<float4*>(dL_dsh) + (size_t)g0 * 12;
 #pragma unroll
             for (int h = 0; h < 2; h++) {
@@ -520,7 +532,7 @@ int sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const
                           float4* cd, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dsemantic,
                           const SgrStatSink& sink, int quad, int exact, int W, int H, hipEvent_t after_rows, int rs_wave,
-                          uint32_t row_limit, hipStream_t s) {
+                          uint32_t row_limit, float* masked_color_out, int skip_sh, hipStream_t s) {
     if (P <= 0) return 0;
     const float lsc = exact ? 1.0f : SGR_LOG2E;
     const float kx = (0.5f * (float)W) / lsc, ky = (0.5f * (float)H) / lsc;
@@ -528,7 +540,8 @@ int sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const
     const unsigned nb4 = (unsigned)(((size_t)P * SGR_RS_LANES + SGR_GB_THREADS - 1) / SGR_GB_THREADS);
 #define SGR_RS(N)                                                                                                    \
     sgr_row_sum_kernel<N, false><<<nb4, SGR_GB_THREADS, 0, s>>>(P, S, radii, gv, partials, row_stride, touched, dL_dmean2D, \
-                                                               dL_dopacity, dL_dcolor, dL_dsemantic, cd, sink, kx, ky, exact, row_limit)
+                                                               dL_dopacity, dL_dcolor, dL_dsemantic, cd, sink, kx, ky, exact, row_limit, \
+                                                               masked_color_out)
     // switch bit 9 / SGR_RS_WAVE=1: the wave-cooperative row sum instead of the four-lanes-per-Gaussian one (A/B: measured SLOWER on MI355X --
     // per-Gaussian backward stage 0.258 vs 0.213 ms at 1 M Gaussians, 1.14 vs 0.76 ms at 5 M, 0.83 vs 0.57 ms at 2 M + 19
     // channels: its segmented scan is 13 ds_bpermute per step and row chunk, more than the gather chains it removes)
@@ -541,7 +554,7 @@ int sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const
                                                                  dL_dopacity, dL_dcolor, dL_dsemantic, cd, sink)
     if (quad) {  // the scalar-walk blend backward's rows (S = 0 only)
         sgr_row_sum_kernel<0, true><<<nb4, SGR_GB_THREADS, 0, s>>>(P, S, radii, gv, partials, row_stride, touched, dL_dmean2D,
-                                                                  dL_dopacity, dL_dcolor, dL_dsemantic, cd, sink, kx, ky, exact, 0xffffffffu);
+                                                                  dL_dopacity, dL_dcolor, dL_dsemantic, cd, sink, kx, ky, exact, 0xffffffffu, masked_color_out);
     } else if (!quads) {
         if (S == 0) SGR_RSW(0);
         else if (S <= 4) SGR_RSW(4);
@@ -571,6 +584,6 @@ int sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const
     const bool ev_failed = after_rows && hipEventRecord(after_rows, s) != hipSuccess;
     sgr_gauss_bwd_kernel<<<nb, SGR_GB_THREADS, 0, s>>>(P, D, M, means3D, radii, shs, scales, rotations, cov3D_precomp, cam,
                                                        gv, cd, dL_dmean2D, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
-                                                       dL_dscale, dL_drot);
+                                                       dL_dscale, dL_drot, skip_sh);
     return ev_failed ? 1 : 0;
 }

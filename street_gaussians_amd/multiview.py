@@ -51,6 +51,45 @@ class GradReducer:
         self._inflight = False
         self._store = None
         self._layout()
+        # the rasterizer backward writes the gradients of parameters it is handed DIRECTLY into the bucket (no packing copy)
+        self.direct = ref.is_cuda
+        if self.direct and type(self)._register_sink:
+            from . import rasterizer as _rast
+            self._rast_mod = _rast
+            _rast.BACKWARD_SINKS.append(self._sink)
+
+    _register_sink = True
+    _GRAD_NAME = {"means3D": "means3D", "scales": "scales", "rotations": "rotations", "sh": "sh", "semantics": "semantics",
+                  "colors": "colors", "cov3D": "cov3D"}
+
+    def _sink(self, inputs, opacities_key, num_points):
+        """rasterizer.BACKWARD_SINKS provider: for every input of this rasterizer call that IS one of the bucket's parameters
+        (same storage address and shape, no gradient accumulated yet, no exchange in flight) the matching slice of the
+        bucket becomes the backward's output tensor -- autograd then installs that very tensor as ``p.grad`` and ``begin()``
+        has nothing to copy."""
+        if not self.direct or self._inflight or (self.world == 1 and not self.force):
+            return None
+        by_ptr = {}
+        off = 0
+        for p, n in zip(self.params, self._numel):
+            if p.grad is None and p.is_leaf and p.requires_grad:
+                by_ptr[p.data_ptr()] = (off, n, tuple(p.shape))
+            off += n
+        out = {}
+        cand = [(self._GRAD_NAME[k], t.data_ptr(), tuple(t.shape)) for k, t in inputs.items()
+                if isinstance(t, torch.Tensor) and t.numel() and t.is_cuda]
+        if opacities_key is not None:
+            cand.append(("opacity", opacities_key[0], opacities_key[1]))
+        for name, ptr, shape in cand:
+            hit = by_ptr.get(ptr)
+            if hit is not None and hit[2] == shape:
+                out[name] = self.flat[hit[0]:hit[0] + hit[1]].view(shape)  # a FRESH view: autograd may adopt it as p.grad
+        return {"out": out} if out else None
+
+    def close(self) -> None:
+        m = getattr(self, "_rast_mod", None)
+        if m is not None and self._sink in m.BACKWARD_SINKS:
+            m.BACKWARD_SINKS.remove(self._sink)
 
     def _layout(self) -> None:
         """(Re)builds the flat bucket and its per-parameter views for ``self.params``.  The storage is kept when it is
@@ -119,12 +158,17 @@ class GradReducer:
         if self.world == 1 and not self.force:
             return
         grads = [p.grad if p.grad is not None else torch.zeros_like(v) for p, v in zip(self.params, self._views)]
+        # gradients the rasterizer backward wrote straight into the bucket (self._sink) are already in place
+        todo = [(v, g) for v, g in zip(self._views, grads) if g.data_ptr() != v.data_ptr()]
+        self.copied_last = len(todo)
+        views_c, grads_c = [v for v, _ in todo], [g for _, g in todo]
         if self._side is not None:
             cur = torch.cuda.current_stream(self.flat.device)
             self._side.wait_stream(cur)
             with torch.cuda.stream(self._side):
-                torch._foreach_copy_(self._views, grads)
-                for g in grads:
+                if todo:
+                    torch._foreach_copy_(views_c, grads_c)
+                for g in grads_c:
                     g.record_stream(self._side)  # the caching allocator must not hand these out before the copy ran
                 self._works = self._collective(async_op=True)
                 if self.average:
@@ -132,7 +176,8 @@ class GradReducer:
                         w.wait()
                     self.flat.div_(self.world)
         else:
-            torch._foreach_copy_(self._views, grads)
+            if todo:
+                torch._foreach_copy_(views_c, grads_c)
             self._works = self._collective(async_op=True)
         # a gradient that still IS a view of the bucket (installed by the previous wait()) must not be accumulated into
         # while the collective runs on the bucket: detach it, the next backward allocates a fresh one
@@ -239,7 +284,9 @@ class FactoredGradReducer:
         self._all_store = None
         self._configure(shs, means3D, segments)
         self._rast = _rast
+        self._direct_slot = None
         _rast.BACKWARD_OBSERVERS.append(self._observe)
+        _rast.BACKWARD_SINKS.append(self._sink)
 
     def rebuild(self, dense_params: Iterable[torch.Tensor], shs=None, means3D: Optional[torch.Tensor] = None,
                 segments: Optional[Sequence[SHSegment]] = None) -> None:
@@ -349,7 +396,39 @@ class FactoredGradReducer:
         """Gaussians of the declared frame: what the next rasterizer backward over this reducer's set must report."""
         return sum(self.segments[m].n for m in self._frame[0])
 
-    # -- rasterizer backward hook --
+    # -- rasterizer backward hooks --
+    def _sink(self, inputs, opacities_key, num_points):
+        """rasterizer.BACKWARD_SINKS provider (called BEFORE the native backward of a frame of this reducer's set): the
+        backward does not write this view's dL/dSH at all (``wait()`` rebuilds the sum over all views and replaces the
+        gradient), and -- when the frame is the whole single static model, the layout bench.py and a plain GaussianModel
+        have -- its row-sum stage writes the clamp-masked colour gradient straight into this view's payload slot
+        (sgr_backward_extras.masked_color_out) instead of a mask launch + a 12 B/Gaussian copy afterwards."""
+        self._direct_slot = None
+        models, _ = self._frame
+        if int(num_points) != sum(self.segments[m].n for m in models) or len(self._pending) >= self.k:
+            return None
+        if self._mask_fn is not None or not self._bufs[0].is_cuda:  # (CPU test backend: everything through _pack)
+            return None
+        sg0 = self.segments[0]
+        if len(self.segments) == 1 and sg0.means is not None:
+            # (shs, means3D) form: the frame must be a render of THESE positions (the hook list is process-wide, and a
+            # reducer somebody forgot to close() must not take the SH gradient away from an unrelated render of equal size)
+            m = inputs.get("means3D")
+            if m is None or m.data_ptr() != sg0.means.data_ptr():
+                return None
+        res = {"skip_sh_grad": True}
+        if len(self.segments) == 1 and models == [0] and not self._posed:
+            buf = self._bufs[self._cur]
+            ev = self._free_ev[self._cur]
+            if ev is not None and len(self._pending) == 0:
+                torch.cuda.current_stream(buf.device).wait_event(ev)  # the exchange that read this buffer has finished
+                self._free_ev[self._cur] = None
+            slot = buf[len(self._pending)]
+            o, n = self._drgb_off[0], self.segments[0].n
+            self._direct_slot = slot[o:o + 3 * n]
+            res["masked_color_out"] = self._direct_slot
+        return res
+
     def _observe(self, grad_colors, geomBuffer, campos, sh_degree, num_points, means3D=None, color_ready=None):
         # the hook list is process-wide: passes over another Gaussian set (the reference's training step also renders
         # single objects, street_gaussian_renderer.render_object) are not this reducer's business
@@ -377,6 +456,12 @@ class FactoredGradReducer:
             self._pack(grad_colors, geomBuffer, campos, sh_degree, num_points, means3D, models, idft)
 
     def _pack(self, grad_colors, geomBuffer, campos, sh_degree, num_points, means3D, models, idft):
+        direct = self._direct_slot is not None  # the backward's row sum already wrote the masked dRGB into the slot (_sink)
+        self._direct_slot = None
+        if direct:
+            self._bufs[self._cur][len(self._pending)][:3].copy_(campos.reshape(3))
+            self._pending.append(int(sh_degree))
+            return
         if self._mask_fn is not None:
             drgb = self._mask_fn(geomBuffer, grad_colors, num_points)
         else:
@@ -539,6 +624,9 @@ class FactoredGradReducer:
     def close(self) -> None:
         if self._observe in self._rast.BACKWARD_OBSERVERS:
             self._rast.BACKWARD_OBSERVERS.remove(self._observe)
+        if self._sink in self._rast.BACKWARD_SINKS:
+            self._rast.BACKWARD_SINKS.remove(self._sink)
+        self.dense.close()
 
     def __enter__(self):
         return self

@@ -39,6 +39,13 @@ def last_num_rendered() -> int:
 BACKWARD_OBSERVERS = []
 
 
+# callables invoked BEFORE the native backward with the call's input tensors; each may return a dict with
+#   "out": {gradient name: destination tensor}   (see _C.rasterize_gaussians_backward: e.g. views of an exchange bucket),
+#   "masked_color_out": [P, 3] destination of the clamp-masked colour gradient, "skip_sh_grad": True
+# (extension, not part of the reference API; empty unless a multiview reducer is alive)
+BACKWARD_SINKS = []
+
+
 _COLOR_EVENTS = {}
 
 
@@ -80,6 +87,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = raster_settings
         ctx.stats = stats  # extension: densification statistics updated by the backward (GaussianRasterizer.stats_sink)
         ctx.num_rendered = num_rendered
+        # (extension) identity of the opacity input, which the reference does not save: a BACKWARD_SINKS provider matches its
+        # parameters against the call's inputs by storage address
+        ctx.opacities_key = (opacities.data_ptr(), tuple(opacities.shape)) if isinstance(opacities, torch.Tensor) else None
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer, alpha, semantics)
         ctx.mark_non_differentiable(radii)
@@ -114,12 +124,25 @@ class _RasterizeGaussians(torch.autograd.Function):
         color_event = None
         if BACKWARD_OBSERVERS and means3D.is_cuda:
             color_event = _color_event(means3D.device)
+        kw = {}
+        if BACKWARD_SINKS and means3D.is_cuda:
+            inputs = {"means3D": means3D, "scales": scales, "rotations": rotations, "sh": sh, "semantics": semantics,
+                      "colors": colors_precomp, "cov3D": cov3Ds_precomp}
+            for sink in list(BACKWARD_SINKS):
+                d = sink(inputs=inputs, opacities_key=ctx.opacities_key, num_points=means3D.shape[0])
+                if d:
+                    if d.get("out"):
+                        kw.setdefault("out", {}).update(d["out"])
+                    if d.get("masked_color_out") is not None:
+                        kw["masked_color_out"] = d["masked_color_out"]
+                    if d.get("skip_sh_grad"):
+                        kw["skip_sh_grad"] = True
         if raster_settings.debug:
             cpu_args = cpu_deep_copy_tuple(args)
             try:
                 (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
                  grad_scales, grad_rotations, grad_semantics) = _C.rasterize_gaussians_backward(*args, stats=stats,
-                                                                                                 color_event=color_event)
+                                                                                                 color_event=color_event, **kw)
             except Exception as ex:
                 torch.save(cpu_args, "snapshot_bw.dump")
                 print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
@@ -127,7 +150,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         else:
             (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
              grad_scales, grad_rotations, grad_semantics) = _C.rasterize_gaussians_backward(*args, stats=stats,
-                                                                                             color_event=color_event)
+                                                                                             color_event=color_event, **kw)
 
         for observer in list(BACKWARD_OBSERVERS):  # view-sharded training (multiview.FactoredGradReducer)
             observer(grad_colors=grad_colors_precomp, geomBuffer=geomBuffer, campos=raster_settings.campos,

@@ -254,9 +254,12 @@ def test_threeway_against_reference_kernels_at_baseline_size(name, P, S):
     # arithmetic with the reference's rects (bit 10 alone) must produce the same lists as well (n_contrib may differ by the
     # alpha-threshold flips of v_exp_f32, counted below).
     strict = {}
+    g_s = None  # the strictly conforming configuration's gradients: gated below exactly like the parity mode's
     for label, mask in (("strict", _C.EXACT | _C.REF_RECT), ("ref_rect", _C.REF_RECT)):
         with switches(mask):
             res_s, int_s = raw_forward(kw)
+            if label == "strict":
+                g_s = {k: npy(v) for k, v in raw_backward(kw, res_s, wts).items()}
             torch.cuda.synchronize()
             assert res_s["R"] == ref_int["R"] == int(int_s("num_rendered_reference")[0]), (label, res_s["R"], ref_int["R"])
             assert np.array_equal(npy(res_s["radii"]), ref_int["radii"]), label
@@ -269,6 +272,7 @@ def test_threeway_against_reference_kernels_at_baseline_size(name, P, S):
                 assert strict[label]["n_contrib_differs"] == 0, strict
                 for k in ["alpha", "depth"] + (["semantic"] if S else []):
                     assert np.array_equal(npy(res_s[k]).reshape(-1), ref_img[k].reshape(-1)), (label, k)
+                assert _image_stats(npy(res_s["color"]), ref_img["color"])["outside"] == 0, (label, "color")
             else:
                 assert strict[label]["n_contrib_differs"] <= 1e-4 * nc_s.size, strict
             del res_s, int_s, nc_s
@@ -317,6 +321,7 @@ def test_threeway_against_reference_kernels_at_baseline_size(name, P, S):
         rec["grads"][k]["ref_rerun_vs_ref"] = ref_rerun[k]
         rec["grads"][k]["hip_exact_vs_ref"] = _outside(hx, r, 1e-4, 2e-6)
         rec["grads"][k]["hip_exact_vs_ref_1e-5"] = _outside(hx, r, 1e-4, 1e-5)
+        rec["grads"][k]["hip_strict_vs_ref"] = _outside(g_s[k].reshape(gor[k].shape), r, 1e-4, 2e-6)
     try:
         cur = {}
         if os.path.exists(THREEWAY_REPORT):
@@ -344,6 +349,9 @@ def test_threeway_against_reference_kernels_at_baseline_size(name, P, S):
     for k, st in rec["grads"].items():
         allow = max(EXACT_ALLOW.get(name, {}).get(k, 0), conditioned_allowance(k, st["hip_exact_vs_ref"]["n"], st["ref_rerun_vs_ref"]["outside"]))
         assert st["hip_exact_vs_ref"]["outside"] <= allow, ("parity mode", k, st["hip_exact_vs_ref"], st["ref_rerun_vs_ref"])
+        # ... and the same statement for the STRICTLY conforming configuration (parity arithmetic on the reference's tile
+        # rects: the bench line's headline `value`), whose lists were checked entry for entry above (backward.cu:415-641)
+        assert st["hip_strict_vs_ref"]["outside"] <= allow, ("strict mode", k, st["hip_strict_vs_ref"], st["ref_rerun_vs_ref"])
     for k, st in rec["grads"].items():
         n = st["hip_vs_ref"]["n"]
         # yardstick: how far two VALID builds of the reference's own sources are from each other (contraction off vs the

@@ -131,6 +131,78 @@ def test_bench_runs_the_replicated_densify_loop_on_a_forced_group():
     assert line["rccl_ranks"] == 1
 
 
+def test_bench_two_ranks_share_one_gpu_over_gloo():
+    """`bench.py --gpus 2` for real: the launcher spawns TWO rank processes (torch.distributed.run), both on cuda:0, with the
+    collectives over gloo on CUDA tensors (SGR_BENCH_BACKEND=gloo SGR_BENCH_SHARE_GPU=1 -- RCCL refuses two ranks on one
+    device).  The main rank program -- Workload.step with the factored exchange (all-reduce of the dense bucket the backward
+    wrote into directly + all-gather of the per-view dRGB + local SH rebuild), the barrier + MAX-over-ranks timing, the
+    overlap region -- runs with world size 2, rank 1 rendering its own view; afterwards both ranks hold the same summed
+    gradients bit for bit.  Never a measurement: the first N > 1 execution must not be the driver's 8-GPU run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SGR_BENCH_BACKEND="gloo", SGR_BENCH_SHARE_GPU="1")
+    for reduce in ("factored", "bucket"):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                              "--device-warmup", "0", "--gaussians", "100000", "--no-cpu-baseline", "--no-other-configs",
+                              "--reduce", reduce], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+        line = json.loads([ln for ln in out.stdout.strip().split("\n") if ln.startswith("{")][-1])
+        assert line["n_gpus"] == 2 and line["dist_ranks"] == 2 and line["dist_backend"] == "gloo"
+        assert line["ranks_share_one_gpu"] is True and line["rccl_ranks"] == 0
+        assert line["value"] > 0 and line["config"]["views_per_step"] == 2
+        assert line["summed_gradients_identical_on_all_ranks"] is True
+        assert line["config"]["exchange_bytes_per_rank"] > 0 and "exchange_overlap" in line
+        # the backward wrote the dense gradients straight into the bucket: nothing left to copy at begin()
+        assert line["exchange_direct_bucket_writes"]["dense_tensors_copied_into_the_bucket_last_step"] == 0, line["exchange_direct_bucket_writes"]
+
+
+def test_direct_bucket_writes_match_the_copying_exchange():
+    """The backward writing its dense gradients into the exchange bucket, the masked dRGB into the payload slot and no own
+    dL/dSH (rasterizer.BACKWARD_SINKS) gives bit-identical gradients to the round-5 path that allocated, copied, masked in a
+    launch of its own and wrote dL/dSH twice (GradReducer.direct = False + the sinks removed)."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    cam = _views(1)[0]
+    sc = syn.make_scene(30000, cam, S=0, seed=21)
+    sc.shs[::3, 0, :] -= 2.0
+    names = ["means3D", "scales", "rotations", "opacities", "shs"]
+    w = {k: dev(v) for k, v in syn.loss_weights(cam, seed=5).items()}
+    port = socket.socket()
+    port.bind(("127.0.0.1", 0))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port.getsockname()[1])
+    port.close()
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    res = {}
+    try:
+        for label in ("direct", "copying"):
+            t = {k: dev(getattr(sc, k)).requires_grad_(True) for k in names}
+            dense = [t[k] for k in names[:4]]
+            with multiview.FactoredGradReducer(dense, t["shs"], t["means3D"], force=True) as red:
+                if label == "copying":
+                    red.dense.direct = False
+                    rasterizer.BACKWARD_SINKS.remove(red._sink)
+                for rnd in range(2):
+                    for p in t.values():
+                        p.grad = None
+                    color, radii, depth, alpha, _ = GaussianRasterizer(settings(cam))(t["means3D"], None, t["opacities"], shs=t["shs"],
+                                                                                      scales=t["scales"], rotations=t["rotations"])
+                    torch.autograd.backward([color, depth, alpha], [w["color"], w["depth"], w["alpha"]])
+                    if label == "direct":  # autograd adopted the bucket slices as the parameters' gradients
+                        assert all(t[k].grad.data_ptr() == v.data_ptr() for k, v in zip(names[:4], red.dense._views))
+                        assert t["shs"].grad is None
+                    red.all_reduce()
+                    assert red.dense.copied_last == (0 if label == "direct" else 4)
+                res[label] = {k: t[k].grad.clone() for k in names}
+            assert len(rasterizer.BACKWARD_SINKS) == 0 and len(rasterizer.BACKWARD_OBSERVERS) == 0
+    finally:
+        dist.destroy_process_group()
+    for k in names:
+        assert torch.equal(res["direct"][k], res["copying"][k]), k
+
+
 def test_async_exchange_matches_blocking_exchange():
     """GradReducer / FactoredGradReducer: begin() + wait() give the same gradients as all_reduce(), also when the next
     step's work is queued in between (one-rank RCCL group)."""
