@@ -218,7 +218,10 @@ int sgr_export_internal(int which, int P, int R, int width, int height, char* ge
  * bit 10 (SGR_REF_RECT=1) every Gaussian is emitted for the reference's whole tile rect (auxiliary.h getRect), so that
  * num_rendered, point_list, the sorted keys and the ranges are the reference's arrays entry for entry; default: the rect
  * cut down to the tiles where the Gaussian can pass the alpha >= 1/255 test -- fewer instances, bit-identical images (gradients: same terms, the row sum groups its additions differently),
- * bit 11 (SGR_NO_TILE_MASK=1) the cut-down rect is the bounding box of those tiles without the per-tile mask (A/B).
+ * bit 11 (SGR_NO_TILE_MASK=1) the cut-down rect is the bounding box of those tiles without the per-tile mask (A/B),
+ * bit 12 (SGR_TILE_SORT=1) the binning chain runs in its per-tile form (csrc/sgr_tile_sort.hip: no depth pre-sort of the
+ * Gaussians, emission in index order, stable tile sort, then every tile's list radix-sorted by depth in LDS) -- the same
+ * lists entry for entry (tests/test_gpu_tile_sort.py); A/B design, measured in DESIGN.md section 3.
  * mask >= 0 sets them process-wide, mask < 0 only queries; returns the previous mask.  The initial
  * value comes from the environment (SGR_NO_CULL, SGR_NO_DPP, SGR_NO_DET, SGR_NO_HITS, SGR_V2), read once. */
 int sgr_test_switches(int mask);
@@ -260,6 +263,10 @@ int sgr_test_sort32(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t*
 size_t sgr_test_sort_hist_words(uint32_t n);
 size_t sgr_test_scan_tmp_words(size_t n);
 int sgr_test_wave_sum(const float* in, float* out_dpp, float* out_shfl, int nwaves, void* stream);
+/* the ordering property the per-tile LDS sort's ranking relies on (csrc/sgr_tile_sort.hip): trial t runs one wave64
+ * ds_add_rtn_u32 in which lane l adds 1 to LDS counter pattern[64 t + l] % 64 (all counters zero before); out[64 t + l] = the
+ * value lane l got back.  Lanes that share a counter must see 0, 1, 2, ... in ascending lane order. */
+int sgr_test_lds_atomic_order(const uint32_t* pattern, uint32_t* out, int trials, void* stream);
 /* parity-mode elementary functions against the toolchain's own (device arrays of n floats each): exp_lib[i] = expf(x[i]),
  * exp_ref[i] = the written-out sequence the blend kernels run in SGR_EXACT mode; div_lib[i] = a[i] / b[i] (hipcc's IEEE
  * expansion), div_ref[i] = the shared-reciprocal form.  The tests require bit equality over the kernels' operand ranges. */

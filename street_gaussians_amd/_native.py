@@ -22,7 +22,7 @@ SYMBOLS = [
     "sgr_last_error", "sgr_version", "sgr_forward", "sgr_backward", "sgr_backward_ex", "sgr_mark_visible", "sgr_visible_filter",
     "sgr_knn", "sgr_geometry_bytes", "sgr_binning_bytes", "sgr_image_bytes", "sgr_partial_row_floats",
     "sgr_export_internal", "sgr_test_scan", "sgr_test_sort", "sgr_test_sort32", "sgr_test_sort_hist_words", "sgr_test_scan_tmp_words",
-    "sgr_test_wave_sum", "sgr_test_exact_math", "sgr_test_switches", "sgr_has_variants", "sgr_set_lazy", "sgr_lazy_status", "sgr_profile_host_wait_us", "sgr_profile_enable", "sgr_profile_select", "sgr_profile_sample", "sgr_profile_read", "sgr_masked_color_grad",
+    "sgr_test_wave_sum", "sgr_test_exact_math", "sgr_test_lds_atomic_order", "sgr_test_switches", "sgr_has_variants", "sgr_set_lazy", "sgr_lazy_status", "sgr_profile_host_wait_us", "sgr_profile_enable", "sgr_profile_select", "sgr_profile_sample", "sgr_profile_read", "sgr_masked_color_grad",
     "sgr_sh_grad_from_views", "sgr_sh_grad_from_views_ex", "sgr_scene_compose_forward", "sgr_scene_compose_backward",
     "sgr_scene_densification_stats", "sgr_ssim_workspace_floats", "sgr_ssim_forward", "sgr_ssim_backward",
     "sgr_l1_workspace_floats", "sgr_l1_forward", "sgr_l1_backward", "sgr_color_loss_backward", "sgr_bce_forward", "sgr_bce_backward",
@@ -131,6 +131,8 @@ def lib():
         L.sgr_test_sort32.argtypes = [vp, vp, vp, vp, C.c_uint32, i, i, vp, vp, vp]
         L.sgr_test_wave_sum.restype = i
         L.sgr_test_wave_sum.argtypes = [vp, vp, vp, i, vp]
+        L.sgr_test_lds_atomic_order.restype = i
+        L.sgr_test_lds_atomic_order.argtypes = [vp, vp, i, vp]
         L.sgr_test_exact_math.restype = i
         L.sgr_test_exact_math.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, vp]
         L.sgr_test_switches.restype = i

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libsgr_hip.so")
-SOURCES = ["sgr_preprocess.hip", "sgr_scan_sort.hip", "sgr_blend_fwd.hip", "sgr_blend_bwd.hip", "sgr_gauss_bwd.hip", "sgr_gauss_bwd_strict.hip",
+SOURCES = ["sgr_preprocess.hip", "sgr_scan_sort.hip", "sgr_tile_sort.hip", "sgr_blend_fwd.hip", "sgr_blend_bwd.hip", "sgr_gauss_bwd.hip", "sgr_gauss_bwd_strict.hip",
            "sgr_knn.hip", "sgr_multiview.hip", "sgr_scene.hip", "sgr_loss.hip", "sgr_densify.hip", "sgr_api.hip"]
 # Designs that were built, measured slower on MI355X and kept as A/B records: the scalar-walk blend
 # backward (its own file), and -- behind `#if SGR_WITH_VARIANTS` inside the files above -- the transposed-accumulation

@@ -62,6 +62,7 @@ void sgr_launch_sh_grad_from_views(int P, int D, int M, int V, const float* mean
                                    const float* campos, size_t campos_stride, const float* drgb, size_t drgb_stride,
                                    float* dL_dsh, hipStream_t s);
 void sgr_launch_wave_sum_test(const float* in, float* out_dpp, float* out_shfl, int nwaves, hipStream_t s);
+void sgr_launch_lds_atomic_order_test(const uint32_t* pattern, uint32_t* out, int trials, hipStream_t s);
 int sgr_knn_impl(int P, const float* points, float* meanDists, sgr_alloc_fn scratch, void* scratch_user, hipStream_t s,
                  std::string& err);
 
@@ -93,7 +94,7 @@ static int switches() {
         v = (env_flag("SGR_NO_CULL") ? 1 : 0) | (env_flag("SGR_NO_DPP") ? 2 : 0) | (env_flag("SGR_NO_DET") ? 4 : 0) |
             (env_flag("SGR_NO_HITS") ? 8 : 0) | (env_flag("SGR_V2") ? 16 : 0) | (env_flag("SGR_PRE_STAGE") ? 64 : 0) |
             (env_flag("SGR_EXACT") ? 128 : 0) | ((env_flag("SGR_SW8") || env_flag("SGR_SW")) ? 256 : 0) | ((env_flag("SGR_SW9") || env_flag("SGR_RS_WAVE")) ? 512 : 0) |
-            (env_flag("SGR_REF_RECT") ? 1024 : 0) | (env_flag("SGR_NO_TILE_MASK") ? 2048 : 0);
+            (env_flag("SGR_REF_RECT") ? 1024 : 0) | (env_flag("SGR_NO_TILE_MASK") ? 2048 : 0) | (env_flag("SGR_TILE_SORT") ? 4096 : 0);
         if (!SGR_WITH_VARIANTS) v &= ~SGR_VARIANT_BITS;
         g_switches.store(v, std::memory_order_relaxed);
     }
@@ -220,6 +221,7 @@ static hipError_t wait_for_readback_(uint32_t* host_vals, hipEvent_t landed) {
     return hipEventSynchronize(landed);
 }
 
+static bool tile_sort_on() { return (switches() & 4096) != 0; }
 static int pre_stage_min_p() {
     static const int v = [] { const char* e = getenv("SGR_PRE_STAGE_MIN_P"); return e ? atoi(e) : 3000000; }();
     return v;
@@ -433,6 +435,7 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
         }
     }
     const bool lazy = lazy_on() && r_hint > 0;
+    const bool tile_sort = tile_sort_on() && !lazy_on();  // (the lazy mode keeps the default chain: list_index())
 
     int R = 0;
     uint32_t cap = 0;  // lazy: slots of the instance list
@@ -522,6 +525,13 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
         // of three per-stage gathers through `order`: at 5 M Gaussians those read 0.6 GB each, rocprofv3 FETCH_SIZE)
         // (27 bits: 3 passes of 9 bits while the launches are latency-bound, 4 passes of 7 bits -- longer store runs -- from
         // 750 k Gaussians on: sgr_scan_sort.hip)
+        if (tile_sort) {
+            // per-tile sort form (switch bit 12, sgr_tile_sort.hip): no depth pre-sort -- the instances are emitted in index
+            // order and every tile's list is sorted by depth in LDS after the tile sort; both scan sequences are index order
+            order = nullptr;
+            sgr_launch_scan_head(reinterpret_cast<const uint32_t*>(gv.aux), reinterpret_cast<const uint32_t*>(gv.aux), (size_t)P,
+                                 2, gv.scan_tmp, gv.sub_sums, stream);
+        } else {
         const int dcur = sgr_launch_sort_pairs32(gv.dkeys, gv.dvals, (uint32_t)P, wide_depth ? 32 : SGR_DEPTH_KEY_BITS, gv.dhist,
                                                  gv.scan_tmp, stream, true, gv.aux, gv.aux_sorted, P < 750000 ? 9 : 8);
         order = gv.dvals[dcur];
@@ -531,6 +541,7 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
         // round 4 ran a third launch that wrote them to an array)
         sgr_launch_scan_head(reinterpret_cast<const uint32_t*>(gv.aux_sorted), reinterpret_cast<const uint32_t*>(gv.aux), (size_t)P,
                              2, gv.scan_tmp, gv.sub_sums, stream);
+        }
         SGR_STAGE("depth_sort+scan");
         prof_end(stream);
         // The window between "R is known" and "the GPU runs out of queued work" is only the ~0.12 ms of sort + scan
@@ -558,7 +569,7 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
         SGR_HIP(wait_for_readback(host_vals, landed));  // the one host wait of the forward
         drain.ev = nullptr;
 
-        if (!(host_vals[2] & 1u) || wide_depth) break;
+        if (!(host_vals[2] & 1u) || wide_depth || tile_sort) break;  // (the per-tile sort reads the far-depth flag on the device)
         wide_depth = true;
         wide_left = 64;
     }
@@ -582,7 +593,9 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     int cur = 0;
     // (also with R == 0: the kernel finishes the index-order scan, SgrGeomView::u0, which the exports read)
     prof_begin(2, stream);
-    sgr_launch_duplicate(P, gv, order, gv.scan_tmp, gv.sub_sums, bv.keys[0], bv.vals[0], gx, cap, stream);
+    SgrGeomView gv_dup = gv;
+    if (tile_sort) gv_dup.aux_sorted = gv.aux;  // index-order emission: "depth order" is the identity
+    sgr_launch_duplicate(P, gv_dup, order, gv.scan_tmp, gv.sub_sums, bv.keys[0], bv.vals[0], gx, cap, stream);
     SGR_STAGE("duplicate");
     prof_end(stream);
     if (R > 0) {
@@ -595,23 +608,32 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
         prof_begin(4, stream);
         sgr_launch_tile_ranges(R, bv.keys[cur], iv.ranges, bv.touched, lazy ? (uint32_t)T : 0xffffffffu, stream);
         SGR_STAGE("tile_ranges");
+        if (tile_sort) {
+            // every tile's list (ascending id so far) into (depth, id) order: a stable radix sort on the depth keys in LDS
+            sgr_launch_tile_sort((int)T, iv.ranges, bv.vals[cur], bv.vals[cur ^ 1], gv.dkeys[0], gv.header, bv.keys[cur ^ 1], bv.tkeys, stream);
+            SGR_STAGE("tile_sort");
+        }
         prof_end(stream);
     }
+    const int lcur = tile_sort ? (cur ^ 1) : cur;  // which vals[] holds the final list (list_index())
     prof_begin(5, stream);
     const bool cull = !(switches() & 1);
-    sgr_launch_blend_fwd(cull, (switches() & 128) != 0, gx, gy, iv.ranges, bv.vals[cur], W, H, S, gv.rec, semantics,
+    sgr_launch_blend_fwd(cull, (switches() & 128) != 0, gx, gy, iv.ranges, bv.vals[lcur], W, H, S, gv.rec, semantics,
                          background, out_color, out_depth, out_alpha, out_semantic, iv.n_contrib, bv.hit4, stream);
     SGR_STAGE("blend_fwd");
     prof_end(stream);
     return R;
 }
 
-// which of the two ping-pong pairs holds the sorted list: one flip per 8-bit pass
+// which of the two ping-pong pairs holds the sorted tile keys: one flip per 8-bit pass
 static int sorted_index(int width, int height) {
     const int gx = (width + SGR_BLOCK_X - 1) / SGR_BLOCK_X, gy = (height + SGR_BLOCK_Y - 1) / SGR_BLOCK_Y;
     const int end_bit = (int)getHigherMsb((uint32_t)(gx * gy));  // the tile sort only; depth order comes from the emission order
     return sgr_sort_pass_count(end_bit) & 1;
 }
+// ... and which vals[] holds the final instance list: the per-tile sort form (switch bit 12) writes it to the other one.
+// (A forward and the backward / exports over its buffers must run under the same switch, like every other switch.)
+static int list_index(int width, int height) { return sorted_index(width, height) ^ ((tile_sort_on() && !lazy_on()) ? 1 : 0); }
 
 int sgr_backward(int P, int D, int M, int R, int S, const float* background, int width, int height,
                  const float* means3D, const float* shs, const float* colors_precomp, const float* semantics,
@@ -720,7 +742,7 @@ int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, 
     if (R > 0) {
         const SgrBinView bv = sgr_bin_carve(binning_buffer, (size_t)R);
         touched = bv.touched;
-        const int cur = sorted_index(W, H);
+        const int cur = list_index(W, H);
         // (the scalar walk leaves quadrant MASKS in these bytes and the LDS kernel ones: a scalar-walk backward clears them
         // before and after itself, so that the two kernels can follow each other over one forward)
         const bool odd_set = (switches() & (1 | 8)) != 0 || quad;
@@ -992,12 +1014,12 @@ int sgr_export_internal(int which, int P, int R, int width, int height, char* ge
         if (R <= 0) return 0;
         const SgrBinView bv = sgr_bin_carve(binning_buffer, (size_t)R);
         if (which == 15) { SGR_HIP(hipMemcpyAsync(dst, bv.hit4, (size_t)R, hipMemcpyDeviceToDevice, stream)); return 0; }
-        const int cur = sorted_index(width, height);
+        const int cur = sorted_index(width, height), lcur = list_index(width, height);
         if (which == 8) {
-            SGR_HIP(hipMemcpyAsync(dst, bv.vals[cur], (size_t)R * 4, hipMemcpyDeviceToDevice, stream));
+            SGR_HIP(hipMemcpyAsync(dst, bv.vals[lcur], (size_t)R * 4, hipMemcpyDeviceToDevice, stream));
         } else {
             const SgrGeomView gv = sgr_geom_carve(geom_buffer, (size_t)P);
-            sgr_launch_compose_keys(R, bv.keys[cur], bv.vals[cur], gv.rec, (uint64_t*)dst, stream);
+            sgr_launch_compose_keys(R, bv.keys[cur], bv.vals[lcur], gv.rec, (uint64_t*)dst, stream);
             SGR_STAGE("export keys");
         }
         return 0;
@@ -1069,6 +1091,13 @@ int sgr_test_exact_math(int n, const float* x, float* exp_lib, float* exp_ref, c
     if (n <= 0) return 0;
     sgr_exact_math_test_kernel<<<(n + 255) / 256, 256, 0, stream>>>(n, x, exp_lib, exp_ref, a, b, div_lib, div_ref);
     SGR_STAGE("exact_math");
+    return 0;
+}
+int sgr_test_lds_atomic_order(const uint32_t* pattern, uint32_t* out, int trials, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int debug = 1;
+    sgr_launch_lds_atomic_order_test(pattern, out, trials, stream);
+    SGR_STAGE("lds_atomic_order");
     return 0;
 }
 int sgr_test_wave_sum(const float* in, float* out_dpp, float* out_shfl, int nwaves, void* stream_) {

@@ -68,6 +68,7 @@ struct SgrBinView {
     uint32_t* header;    // [0]=index (0/1) of the buffer pair holding the sorted result
     uint8_t* hit4;       // per sorted instance: bit q = the forward blended it into >= 1 pixel of quadrant q of its tile
     uint8_t* touched;    // per partial-gradient row: written by the backward (cleared by the forward's tile-ranges launch)
+    uint32_t* tkeys;     // per-tile LDS sort (sgr_tile_sort.hip, switch bit 12): depth-key scratch of the lists too long for LDS
 };
 
 // optional sink of the backward for this view's densification statistics (sgr_backward_ex); all three or none
@@ -159,6 +160,7 @@ static inline SgrBinView sgr_bin_carve(char* base, size_t R, char** end = nullpt
     sgr_carve(p, v.scan_tmp, sgr_scan_tmp_count(nh));
     sgr_carve(p, v.hit4, Rn);
     sgr_carve(p, v.touched, Rn);
+    sgr_carve(p, v.tkeys, Rn);
     if (end) *end = p;
     return v;
 }
@@ -216,6 +218,9 @@ int sgr_launch_sort_pairs32(uint32_t* const keys[2], uint32_t* const vals[2], ui
                             uint32_t* scan_tmp, hipStream_t s, bool iota = false, const uint2* aux_in = nullptr,
                             uint2* aux_out = nullptr, int max_bits = 8);  // max_bits: digit width cap, 8 or 9
 int sgr_sort_pass_count(int end_bit);  // passes (= buffer flips) of a sort on key bits [0, end_bit)
+// per-tile LDS sort by depth (sgr_tile_sort.hip): vals_in (tile-major, ascending id inside a tile) -> vals_out in (depth, id) order
+void sgr_launch_tile_sort(int T, const uint2* ranges, uint32_t* vals_in, uint32_t* vals_out, const uint32_t* dkeys,
+                          const uint32_t* header, uint32_t* gk0, uint32_t* gk1, hipStream_t s);
 
 // ---- wave / block scan primitives (sgr_scan_sort.hip, sgr_preprocess.hip) ----
 __device__ __forceinline__ uint32_t sgr_wave_incl_scan(uint32_t v, int lane) {

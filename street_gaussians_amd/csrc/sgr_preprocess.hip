@@ -343,7 +343,7 @@ sgr_duplicate_kernel(int P, SgrGeomView gv, const uint32_t* __restrict__ order, 
     const uint32_t ex2 = sgr_block_excl_scan256(t2, lds4, total) + bsum[nb + 1 + (blockIdx.x >> 3)] + sub[8 * nb + blockIdx.x];
     if (i < P) {
         gv.u0[i] = ex2;
-        idx = order[i];
+        idx = order ? order[i] : (uint32_t)i;  // order == nullptr: emission in index order (per-tile sort form, sgr_tile_sort.hip)
         off = ex1;
         incl = ex1 + as.x;
         if (incl != off) {  // tiles_touched > 0

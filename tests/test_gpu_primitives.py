@@ -131,6 +131,33 @@ def test_wave_sum_dpp_equals_shuffle():
     assert (b.cpu().numpy() == ref).all()
 
 
+def test_lds_returning_atomics_serve_equal_addresses_in_lane_order():
+    """What the per-tile LDS sort's ranking relies on (csrc/sgr_tile_sort.hip): within ONE wave64 ds_add_rtn_u32 the lanes
+    that hit the same counter get 0, 1, 2, ... back in ASCENDING LANE ORDER.  Patterns: all lanes on one counter, two / four /
+    sixteen counters in every interleaving, random counters."""
+    L, check = _lib()
+    g = torch.Generator().manual_seed(3)
+    pats = [torch.zeros(64, dtype=torch.int64), torch.arange(64) % 2, torch.arange(64) // 32, torch.arange(64) % 4,
+            torch.arange(64) // 16, torch.arange(64) % 16, torch.arange(64), 63 - torch.arange(64), (63 - torch.arange(64)) // 8]
+    pats += [torch.randint(0, k, (64,), generator=g) for k in (2, 3, 5, 8, 16, 32, 64) for _ in range(200)]
+    pat = torch.stack(pats).to(torch.int32)
+    trials = pat.shape[0]
+    out = torch.zeros(trials, 64, dtype=torch.int32, device="cuda")
+    pd = pat.cuda().contiguous()
+    check(L.sgr_test_lds_atomic_order(_vp(pd), _vp(out), trials, None))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    p = pat.numpy()
+    # expected: rank of the lane among the lanes with the same counter, in lane order
+    want = np.zeros_like(p)
+    for t in range(trials):
+        seen = {}
+        for l in range(64):
+            want[t, l] = seen.get(p[t, l], 0)
+            seen[p[t, l]] = want[t, l] + 1
+    assert (got == want).all(), int((got != want).sum())
+
+
 def test_parity_mode_elementary_functions_have_the_bits_of_expf_and_division():
     """SGR_EXACT mode runs expf and T / (1 - alpha) written out without their range handling (sgr_math.h: sgr_expf_ref,
     sgr_div_by).  They must have the bits of the device library's expf and of hipcc's IEEE `/`: dense sweeps of the operand

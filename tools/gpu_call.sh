@@ -20,13 +20,14 @@ E=$R/gpurun_out/$TAG; mkdir -p $E; cd $R
 V=$R/street_gaussians_amd/variants
 clean() { grep -v amdgpu.ids; }
 lib_env() { if [ "$1" = shipped ]; then echo "SGR_BINDING=ctypes"; else echo "SGR_BINDING=ctypes SGR_LIB=$V/libsgr_hip_$1.so"; fi; }
-stage_line() {  # one bench run -> one JSON line of the figures the A/Bs compare
-  python $R/bench.py --no-cpu-baseline --no-other-configs $2 2>/dev/null | tail -1 | python -c "
+stage_line() {  # one bench run -> one JSON line of the figures the A/Bs compare (SGR_AB_MODE: bench --mode, default strict)
+  python $R/bench.py --no-cpu-baseline --no-other-configs --mode ${SGR_AB_MODE:-strict} $2 2>/dev/null | tail -1 | python -c "
 import sys, json
-b = json.loads(sys.stdin.read()); pm = b.get('parity_mode') or {}; st = b['roofline']['stages_ms']
-print(json.dumps({'variant': '$1', 'ms': b['ms_per_step'], 'timed': (b.get('timed_region') or {}).get('ms_per_step'),
-                  'exact_ms': b.get('ms_per_step_exact'), 'strict_ms': b.get('ms_per_step_strict'), 'stages': st,
-                  'exact_bwd': pm.get('blend_bwd_ms'), 'exact_fwd': pm.get('blend_fwd_ms'), 'kernel_ms': b['roofline']['kernel_ms']}))"
+b = json.loads(sys.stdin.read()); st = b['roofline']['stages_ms']; m = b.get('modes') or {}
+chain = sum(st[k] or 0 for k in ('scan', 'duplicate', 'sort', 'tile_ranges'))
+print(json.dumps({'variant': '$1', 'mode': b['mode'], 'ms': b['ms_per_step'], 'strict_ms': b.get('ms_per_step_strict'),
+                  'exact_ms': b.get('ms_per_step_exact'), 'fast_ms': b.get('ms_per_step_fast'), 'binning_chain_ms': round(chain, 4),
+                  'stages': st, 'stages_fast': (m.get('fast') or {}).get('stages_ms'), 'kernel_ms': b['roofline']['kernel_ms']}))"
 }
 recipe_check() {
   rm -f gpurun_out/parity_measured.jsonl gpurun_out/threeway_fullsize.json gpurun_out/fullsize_parity.json
