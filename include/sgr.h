@@ -219,6 +219,11 @@ int sgr_export_internal(int which, int P, int R, int width, int height, char* ge
  * num_rendered, point_list, the sorted keys and the ranges are the reference's arrays entry for entry; default: the rect
  * cut down to the tiles where the Gaussian can pass the alpha >= 1/255 test -- fewer instances, bit-identical images (gradients: same terms, the row sum groups its additions differently),
  * bit 11 (SGR_NO_TILE_MASK=1) the cut-down rect is the bounding box of those tiles without the per-tile mask (A/B),
+ * bit 13 (SGR_REF_RECT_PLAIN=1, with bit 10) the reference's rects without the marks described next (round-5 form, A/B).
+ * Since round 6 bit 10 emits the reference's list with the instances that lie outside the cut-down rect / tile mask MARKED
+ * (bit 31 of the internal list entry; export 8 strips it): they are counted, sorted and ranged exactly like the reference's
+ * -- num_rendered, point_list, keys, ranges, n_contrib entry for entry -- but the blend kernels skip them without fetching
+ * their record and they own no partial-gradient row.
  * bit 12 (SGR_TILE_SORT=1) the binning chain runs in its per-tile form (csrc/sgr_tile_sort.hip: no depth pre-sort of the
  * Gaussians, emission in index order, stable tile sort, then every tile's list radix-sorted by depth in LDS) -- the same
  * lists entry for entry (tests/test_gpu_tile_sort.py); A/B design, measured in DESIGN.md section 3.

@@ -25,7 +25,7 @@ void sgr_launch_filter(int P, const float* means3D, const float* scales, const f
                        const float* cov3D_precomp, const SgrCamArgs& ca, const SgrGeomView& gv, int* radii,
                        float* means2D, int prefiltered, hipStream_t s);
 void sgr_launch_duplicate(int P, const SgrGeomView& gv, const uint32_t* order, const uint32_t* bsum, const uint32_t* sub, uint32_t* keys,
-                          uint32_t* vals, int gx, uint32_t cap, hipStream_t s);
+                          uint32_t* vals, int gx, uint32_t cap, int marks, hipStream_t s);
 void sgr_launch_tile_ranges(int L, const uint32_t* keys, uint2* ranges, uint8_t* touched, uint32_t T, hipStream_t s);
 void sgr_launch_compose_keys(int L, const uint32_t* tile_keys, const uint32_t* point_list, const float4* rec, uint64_t* out,
                              hipStream_t s);
@@ -94,7 +94,8 @@ static int switches() {
         v = (env_flag("SGR_NO_CULL") ? 1 : 0) | (env_flag("SGR_NO_DPP") ? 2 : 0) | (env_flag("SGR_NO_DET") ? 4 : 0) |
             (env_flag("SGR_NO_HITS") ? 8 : 0) | (env_flag("SGR_V2") ? 16 : 0) | (env_flag("SGR_PRE_STAGE") ? 64 : 0) |
             (env_flag("SGR_EXACT") ? 128 : 0) | ((env_flag("SGR_SW8") || env_flag("SGR_SW")) ? 256 : 0) | ((env_flag("SGR_SW9") || env_flag("SGR_RS_WAVE")) ? 512 : 0) |
-            (env_flag("SGR_REF_RECT") ? 1024 : 0) | (env_flag("SGR_NO_TILE_MASK") ? 2048 : 0) | (env_flag("SGR_TILE_SORT") ? 4096 : 0);
+            (env_flag("SGR_REF_RECT") ? 1024 : 0) | (env_flag("SGR_NO_TILE_MASK") ? 2048 : 0) | (env_flag("SGR_TILE_SORT") ? 4096 : 0) |
+            (env_flag("SGR_REF_RECT_PLAIN") ? 8192 : 0);
         if (!SGR_WITH_VARIANTS) v &= ~SGR_VARIANT_BITS;
         g_switches.store(v, std::memory_order_relaxed);
     }
@@ -222,6 +223,16 @@ static hipError_t wait_for_readback_(uint32_t* host_vals, hipEvent_t landed) {
 }
 
 static bool tile_sort_on() { return (switches() & 4096) != 0; }
+// Tile rects of a frame (sgr_preprocess.hip `tight`): 2 = the reference's rect cut down to the bounding box of the tiles where
+// alpha >= 1/255 is possible + a tile mask inside it (default), 1 = the box alone (switch bit 11), 3 = switch bit 10
+// (SGR_REF_RECT): the reference's rects, i.e. its lists entry for entry, with the instances outside box / mask MARKED dead
+// (they are sorted and counted like the reference's, but the blend kernels skip them and they own no gradient row), 0 = bits
+// 10 + 13 (SGR_REF_RECT_PLAIN): the reference's rects without marks (round-5 form of the strict mode, A/B).
+static int rect_mode() {
+    const int sw = switches();
+    if (sw & 1024) return (sw & 8192) ? 0 : 3;
+    return (sw & 2048) ? 1 : 2;
+}
 static int pre_stage_min_p() {
     static const int v = [] { const char* e = getenv("SGR_PRE_STAGE_MIN_P"); return e ? atoi(e) : 3000000; }();
     return v;
@@ -247,12 +258,12 @@ static uint32_t getHigherMsb(uint32_t n) {
 __global__ void __launch_bounds__(256)
 sgr_pack_camera_kernel(SgrCam* cam, const float* view, const float* proj, const float* campos, float tan_fovx,
                        float tan_fovy, float focal_x, float focal_y, int W, int H, int gx, int gy, float scale_modifier,
-                       uint32_t* header, uint2* ranges, int T) {
+                       uint32_t* header, uint2* ranges, int T, uint32_t rect_mode) {
     const int t = threadIdx.x;
     for (int i = blockIdx.x * 256 + t; i < T; i += gridDim.x * 256) ranges[i] = make_uint2(0u, 0u);
     if (blockIdx.x != 0) return;
     if (t < 16) {
-        header[t] = 0u;
+        header[t] = t == 6 ? rect_mode : 0u;
         cam->view[t] = view[t];
         cam->proj[t] = proj ? proj[t] : 0.f;
     }
@@ -272,13 +283,13 @@ static_assert(SGR_STAT_SEG_MAX == SGR_MAX_STAT_SEGMENTS, "sgr_common.h and inclu
 
 static void pack_camera(const SgrGeomView& gv, const float* view, const float* proj, const float* campos,
                         float tan_fovx, float tan_fovy, int W, int H, float scale_modifier, uint2* ranges, int T,
-                        hipStream_t s) {
+                        int rect_mode, hipStream_t s) {
     const float focal_y = H / (2.0f * tan_fovy);  // rasterizer_impl.cu:225-226
     const float focal_x = W / (2.0f * tan_fovx);
     const int gx = (W + SGR_BLOCK_X - 1) / SGR_BLOCK_X, gy = (H + SGR_BLOCK_Y - 1) / SGR_BLOCK_Y;
     const int nb = std::max(1, std::min(64, (T + 255) / 256));
     sgr_pack_camera_kernel<<<nb, 256, 0, s>>>(cam_slot(gv), view, proj, campos, tan_fovx, tan_fovy, focal_x, focal_y, W, H,
-                                             gx, gy, scale_modifier, gv.header, ranges, T);
+                                             gx, gy, scale_modifier, gv.header, ranges, T, (uint32_t)rect_mode);
 }
 
 // ---- the forward without a host wait (sgr_set_lazy) ---------------------------------------------------------------
@@ -436,16 +447,21 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     }
     const bool lazy = lazy_on() && r_hint > 0;
     const bool tile_sort = tile_sort_on() && !lazy_on();  // (the lazy mode keeps the default chain: list_index())
+    const int rmode = rect_mode();
+    // what the list is made of, in index order: {count, rect} records of 8 bytes, or (marked-list mode) 16-byte records whose
+    // first half is the reference's count + rect and whose second half is the live part
+    const int aux16 = rmode == 3 ? 1 : 0;
+    const uint2* aux_emit = aux16 ? reinterpret_cast<const uint2*>(gv.aux_ref) : gv.aux;
 
     int R = 0;
     uint32_t cap = 0;  // lazy: slots of the instance list
     if (lazy) {
         prof_begin(0, stream);
-        pack_camera(gv, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, W, H, scale_modifier, iv.ranges, (int)T, stream);
+        pack_camera(gv, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, W, H, scale_modifier, iv.ranges, (int)T, rmode, stream);
         SGR_STAGE("pack_camera");
         sgr_launch_preprocess(P, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
                               cam_slot(gv), gv, radii_ptr, prefiltered, (switches() & 64) != 0 || P >= pre_stage_min_p(),
-                              (switches() & 1024) ? 0 : ((switches() & 2048) ? 1 : 2), stream);
+                              rmode, stream);
         SGR_STAGE("preprocess");
         prof_end(stream);
         host_vals = pinned_pair();
@@ -456,10 +472,10 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
         if (!capturing) SGR_HIP(hipEventRecord(landed, stream));
         prof_begin(1, stream);
         const int dcur = sgr_launch_sort_pairs32(gv.dkeys, gv.dvals, (uint32_t)P, wide_depth ? 32 : SGR_DEPTH_KEY_BITS, gv.dhist,
-                                                 gv.scan_tmp, stream, true, gv.aux, gv.aux_sorted, P < 750000 ? 9 : 8);
+                                                 gv.scan_tmp, stream, true, aux_emit, gv.aux_sorted, P < 750000 ? 9 : 8, aux16);
         order = gv.dvals[dcur];
         sgr_launch_scan_head(reinterpret_cast<const uint32_t*>(gv.aux_sorted), reinterpret_cast<const uint32_t*>(gv.aux), (size_t)P,
-                             2, gv.scan_tmp, gv.sub_sums, stream);
+                             aux16 ? 4 : 2, gv.scan_tmp, gv.sub_sums, stream, 2);
         SGR_STAGE("depth_sort+scan");
         prof_end(stream);
         {   // capacity on the coarse ladder of the blocking path (consecutive calls ask for the same block size)
@@ -480,7 +496,7 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     }
     for (int attempt = 0; attempt < 2 && !lazy; attempt++) {
         prof_begin(0, stream);
-        pack_camera(gv, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, W, H, scale_modifier, iv.ranges, (int)T, stream);
+        pack_camera(gv, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, W, H, scale_modifier, iv.ranges, (int)T, rmode, stream);
         SGR_STAGE("pack_camera");
 
         sgr_launch_preprocess(P, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
@@ -493,7 +509,7 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
                               // tile rects: the reference's 3-sigma squares cut down to the tiles the Gaussian can reach
                               // alpha >= 1/255 in (sgr_preprocess.hip: 2 = bounding box + tile mask, 1 = bounding box only,
                               // switch bit 11); switch bit 10 keeps the reference's rects
-                              (switches() & 1024) ? 0 : ((switches() & 2048) ? 1 : 2), stream);
+                              rmode, stream);
         SGR_STAGE("preprocess");
         prof_end(stream);
 
@@ -529,18 +545,18 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
             // per-tile sort form (switch bit 12, sgr_tile_sort.hip): no depth pre-sort -- the instances are emitted in index
             // order and every tile's list is sorted by depth in LDS after the tile sort; both scan sequences are index order
             order = nullptr;
-            sgr_launch_scan_head(reinterpret_cast<const uint32_t*>(gv.aux), reinterpret_cast<const uint32_t*>(gv.aux), (size_t)P,
-                                 2, gv.scan_tmp, gv.sub_sums, stream);
+            sgr_launch_scan_head(reinterpret_cast<const uint32_t*>(aux_emit), reinterpret_cast<const uint32_t*>(gv.aux), (size_t)P,
+                                 aux16 ? 4 : 2, gv.scan_tmp, gv.sub_sums, stream, 2);
         } else {
         const int dcur = sgr_launch_sort_pairs32(gv.dkeys, gv.dvals, (uint32_t)P, wide_depth ? 32 : SGR_DEPTH_KEY_BITS, gv.dhist,
-                                                 gv.scan_tmp, stream, true, gv.aux, gv.aux_sorted, P < 750000 ? 9 : 8);
+                                                 gv.scan_tmp, stream, true, aux_emit, gv.aux_sorted, P < 750000 ? 9 : 8, aux16);
         order = gv.dvals[dcur];
         // (second sequence of the same launches: the exclusive scan in index order = every Gaussian's first partial-gradient
         // row of the backward, SgrGeomView::u0)
         // (the scan's last step -- offsets of the individual Gaussians -- is done by the duplicate kernel, which needs them:
         // round 4 ran a third launch that wrote them to an array)
         sgr_launch_scan_head(reinterpret_cast<const uint32_t*>(gv.aux_sorted), reinterpret_cast<const uint32_t*>(gv.aux), (size_t)P,
-                             2, gv.scan_tmp, gv.sub_sums, stream);
+                             aux16 ? 4 : 2, gv.scan_tmp, gv.sub_sums, stream, 2);
         }
         SGR_STAGE("depth_sort+scan");
         prof_end(stream);
@@ -594,8 +610,8 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     // (also with R == 0: the kernel finishes the index-order scan, SgrGeomView::u0, which the exports read)
     prof_begin(2, stream);
     SgrGeomView gv_dup = gv;
-    if (tile_sort) gv_dup.aux_sorted = gv.aux;  // index-order emission: "depth order" is the identity
-    sgr_launch_duplicate(P, gv_dup, order, gv.scan_tmp, gv.sub_sums, bv.keys[0], bv.vals[0], gx, cap, stream);
+    if (tile_sort) gv_dup.aux_sorted = const_cast<uint2*>(aux_emit);  // index-order emission: "depth order" is the identity
+    sgr_launch_duplicate(P, gv_dup, order, gv.scan_tmp, gv.sub_sums, bv.keys[0], bv.vals[0], gx, cap, rmode == 3 ? 1 : 0, stream);
     SGR_STAGE("duplicate");
     prof_end(stream);
     if (R > 0) {
@@ -965,6 +981,10 @@ int sgr_knn(int P, const float* points, float* meanDists, sgr_alloc_fn scratch, 
 
 // ------------------------------------------------------------------------------------------------
 // introspection
+__global__ void sgr_strip_dead_kernel(uint32_t* v, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) v[i] &= ~SGR_DEAD;
+}
 __global__ void sgr_export_kernel(int which, int P, SgrGeomView gv, void* dst) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
@@ -977,11 +997,12 @@ __global__ void sgr_export_kernel(int which, int P, SgrGeomView gv, void* dst) {
         case 2: { const float4 a = gv.rec[4 * (size_t)i]; ((float*)dst)[2 * i] = a.x; ((float*)dst)[2 * i + 1] = a.y; } break;
         case 4: ((float4*)dst)[i] = gv.rec[4 * (size_t)i + 1]; break;
         case 5: { const float4 c = gv.rec[4 * (size_t)i + 2]; ((float*)dst)[3 * i] = c.x; ((float*)dst)[3 * i + 1] = c.y; ((float*)dst)[3 * i + 2] = c.z; } break;
-        case 6: ((uint32_t*)dst)[i] = gv.aux[i].x; break;
-        case 7: ((uint32_t*)dst)[i] = gv.u0[i] + gv.aux[i].x; break;  // the reference's inclusive index-order scan
+        // (marked-list mode, header[6] == 3: the list is made of the reference's rects, gv.aux_ref; gv.aux / u0 number the rows)
+        case 6: ((uint32_t*)dst)[i] = gv.header[6] == 3u ? gv.aux_ref[i].x : gv.aux[i].x; break;
+        case 7: ((uint32_t*)dst)[i] = gv.u0[i] + gv.aux[i].x; break;  // the reference's inclusive index-order scan (mode 3: by a scan, below)
         case 14: { const float4 a = gv.rec[4 * (size_t)i]; ((float*)dst)[2 * i] = a.z; ((float*)dst)[2 * i + 1] = a.w; } break;
         case 16: {  // tile rect {x0, y0, x1, y1} (exclusive upper corner); all zero for a culled Gaussian
-            const uint2 a = gv.aux[i];
+            const uint2 a = gv.header[6] == 3u ? make_uint2(gv.aux_ref[i].x, gv.aux_ref[i].y) : gv.aux[i];
             // (a masked rect of at most 64 tiles does not store its height: the highest set bit of the mask gives the last row
             // that matters, and rows above it hold no emitted tile)
             const uint32_t x0 = a.y & 1023u, y0 = (a.y >> 10) & 1023u, w = (a.y >> 20) & 1023u;
@@ -990,7 +1011,7 @@ __global__ void sgr_export_kernel(int which, int P, SgrGeomView gv, void* dst) {
             ((uint4*)dst)[i] = a.x ? make_uint4(x0, y0, x0 + w, y0 + h) : make_uint4(0u, 0u, 0u, 0u);
         } break;
         case 18:  // tile mask (0 = every tile of the rect is emitted)
-            ((uint64_t*)dst)[i] = (gv.aux[i].x && (gv.aux[i].y & SGR_RECT_MASKED)) ? gv.tmask[i] : 0ull;
+            ((uint64_t*)dst)[i] = (gv.header[6] != 3u && gv.aux[i].x && (gv.aux[i].y & SGR_RECT_MASKED)) ? gv.tmask[i] : 0ull;
             break;
     }
 }
@@ -1006,6 +1027,17 @@ int sgr_export_internal(int which, int P, int R, int width, int height, char* ge
         const SgrGeomView gv = sgr_geom_carve(geom_buffer, (size_t)P);
         if (which == 17) { SGR_HIP(hipMemcpyAsync(dst, gv.header + 5, 4, hipMemcpyDeviceToDevice, stream)); return 0; }
         if (which == 3) return fail(SGR_E_INVALID, "cov3D is not materialised (the backward recomputes it)");
+        if (which == 7) {
+            uint32_t mode = 0;
+            SGR_HIP(hipMemcpyAsync(&mode, gv.header + 6, 4, hipMemcpyDeviceToHost, stream));
+            SGR_HIP(hipStreamSynchronize(stream));
+            if (mode == 3u) {  // the reference's point_offsets = inclusive scan of ITS tiles_touched (the forward scans them in depth order only)
+                sgr_launch_scan(reinterpret_cast<const uint32_t*>(gv.aux_ref), (uint32_t*)dst, (size_t)P, gv.scan_tmp, true, stream,
+                                nullptr, nullptr, 4);
+                SGR_STAGE("export scan");
+                return 0;
+            }
+        }
         sgr_export_kernel<<<(P + 255) / 256, 256, 0, stream>>>(which, P, gv, dst);
         SGR_STAGE("export");
         return 0;
@@ -1017,6 +1049,8 @@ int sgr_export_internal(int which, int P, int R, int width, int height, char* ge
         const int cur = sorted_index(width, height), lcur = list_index(width, height);
         if (which == 8) {
             SGR_HIP(hipMemcpyAsync(dst, bv.vals[lcur], (size_t)R * 4, hipMemcpyDeviceToDevice, stream));
+            sgr_strip_dead_kernel<<<(R + 255) / 256, 256, 0, stream>>>((uint32_t*)dst, R);  // marked-list mode: bit 31 = cannot blend
+            SGR_STAGE("export point_list");
         } else {
             const SgrGeomView gv = sgr_geom_carve(geom_buffer, (size_t)P);
             sgr_launch_compose_keys(R, bv.keys[cur], bv.vals[lcur], gv.rec, (uint64_t*)dst, stream);

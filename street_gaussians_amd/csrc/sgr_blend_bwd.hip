@@ -340,8 +340,13 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                 for (int k4 = 0; k4 < ACCW / 4; k4++) z[k4] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        if (pos >= 0) {
-            const uint32_t g = SGR_BWD_PREFETCH ? g_pre : point_list[range.x + (uint32_t)pos];
+        // An entry no quadrant has to visit is not staged at all -- no record gather, no row: with the forward's hit record
+        // that is every instance the forward blended nowhere (hit byte 0), among them the ones the marked-list mode flags as
+        // unable to blend (SGR_DEAD, bit 31 of the list entry: sgr_duplicate_kernel)
+        const uint32_t g_raw = pos >= 0 ? (SGR_BWD_PREFETCH ? g_pre : point_list[range.x + (uint32_t)pos]) : SGR_DEAD;
+        const uint32_t h_raw = (pos >= 0 && CULL && hit4 != nullptr) ? (SGR_BWD_PREFETCH ? h_pre : (uint32_t)hit4[range.x + (uint32_t)pos]) : 0xFu;
+        if (pos >= 0 && !(g_raw & SGR_DEAD) && h_raw != 0u) {
+            const uint32_t g = g_raw;
             const float4* r = rec + 4 * (size_t)g;  // one 64-byte line
             const float4 a = r[0];
             const float4 b = r[1];
@@ -360,9 +365,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
             }
             // which quadrants to walk: the forward's record of the quadrants it blended this instance into (exactly the
             // visits that can contribute; nothing to compute), else the geometric cull the forward uses
-            mask4 = CULL ? (hit4 != nullptr ? (SGR_BWD_PREFETCH ? h_pre : (uint32_t)hit4[range.x + (uint32_t)pos])
-                                            : sgr_quadrant_mask(a, b, tx0, ty0))
-                         : 0xFu;
+            mask4 = CULL ? (hit4 != nullptr ? h_raw : sgr_quadrant_mask(a, b, tx0, ty0)) : 0xFu;
             // lazy forward (sgr_set_lazy) whose frame had more instances than the list capacity: the rows are numbered over ALL
             // instances (index-order scan), the row array holds `row_limit` of them -- rows past it are not visited (the frame
             // is reported invalid one call later; nothing may be written outside the buffers meanwhile)
@@ -913,7 +916,7 @@ sgr_blend_bwd_kernel_v2(SGR_BWD_ARGS) {
             z[2] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (pos >= 0) {
-            const uint32_t g = point_list[range.x + (uint32_t)pos];
+            const uint32_t g = point_list[range.x + (uint32_t)pos] & ~SGR_DEAD;
             const float4* r = rec + 4 * (size_t)g;  // one 64-byte line
             const float4 a = r[0];
             const float4 b = r[1];

@@ -104,8 +104,10 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
 
         const uint32_t idx = base + tid;
         uint32_t mask4 = 0;
-        if (idx < range.y) {
-            const uint32_t g = point_list[idx];
+        // (marked-list mode: an entry flagged SGR_DEAD lies outside its Gaussian's cut-down rect / tile mask -- the cull below
+        // would reject it for all four quadrants; it is skipped without fetching its record)
+        const uint32_t g = idx < range.y ? point_list[idx] : SGR_DEAD;
+        if (!(g & SGR_DEAD)) {
             const float4* r = rec + 4 * (size_t)g;  // one 64-byte line
             const float4 a = r[0];
             const float4 b = r[1];

@@ -30,6 +30,9 @@
 #define SGR_MAX_GRID_DIM 1023  // tiles per axis representable in the packed rect (10 bits)
 #define SGR_SEM_MAX 32         // semantic channels supported by the blend kernels
 #define SGR_ROW_BASE_N 11      // non-semantic floats of a partial-gradient row (see sgr_blend_bwd.hip)
+#define SGR_DEAD 0x80000000u  // marked-list mode: bit 31 of a point_list entry = the instance lies outside the Gaussian's cut-down
+                              // rect / tile mask: it cannot pass the alpha test anywhere in its tile (the blend kernels skip it
+                              // without fetching its record; it owns no partial-gradient row)
 #define SGR_RECT_MASKED 0x80000000u  // packed tile rect, bit 31: the Gaussian is emitted for the tiles of SgrGeomView::tmask only
 
 #define SGR_ALPHA_MIN (1.0f / 255.0f)
@@ -43,7 +46,12 @@ struct SgrGeomView {
                               // w << 20, bit 31 = "only the tiles set in tmask[g] are emitted" (SGR_RECT_MASKED)
     uint64_t* tmask;          // per Gaussian with bit 31 of its rect word set: bit j = tile (x0 + j % w, y0 + j / w) of the rect
                               // is emitted (rects of at most 64 tiles; written for those Gaussians only)
-    uint2* aux_sorted;        // the same in (depth, id) order (written by the last pass of the depth sort)
+    uint4* aux_ref;           // marked-list mode (preprocess `tight` = 3: the reference's list with the instances that cannot blend
+                              // MARKED, switch bit 10): {tiles of the reference's rect, that rect, live tiles, cut-down rect} --
+                              // .xy is what is scanned in depth order and emitted, .zw (= aux) says which of those instances
+                              // are live; aux / tmask describe the cut-down rect, i.e. the rows
+    uint2* aux_sorted;        // aux (marked-list mode: the 16-byte aux_ref records) in (depth, id) order (written by the last pass
+                              // of the depth sort); 16 bytes per Gaussian are reserved
     uint32_t* u0;             // per Gaussian: its first partial-gradient row of the backward = EXCLUSIVE scan of
                               // tiles_touched in INDEX order (the reference's point_offsets minus tiles_touched), made by
                               // the second sequence of the forward's scan launches.  Rows in index order: the row sum
@@ -57,7 +65,7 @@ struct SgrGeomView {
     uint32_t* clamped;  // 3-bit mask per Gaussian, one u32 each (keeps stores simple and aligned)
     int* internal_radii;
     uint32_t* scan_tmp;   // block sums of the device-wide scan
-    uint32_t* header;     // [0]=error flag, [2]=depth beyond the 27-bit sort keys, [4]=num_rendered, [5]=num_rendered with the reference rects (one u64 counter), [16..]=SgrCam
+    uint32_t* header;     // [6]=tile-rect mode of the frame (0 reference rects, 1 bounding box, 2 box + mask, 3 marked list), [0]=error flag, [2]=depth beyond the 27-bit sort keys, [4]=num_rendered, [5]=num_rendered with the reference rects (one u64 counter), [16..]=SgrCam
 };
 
 struct SgrBinView {
@@ -123,7 +131,8 @@ static inline SgrGeomView sgr_geom_carve(char* base, size_t P, char** end = null
     sgr_carve(p, v.header, 64);
     sgr_carve(p, v.rec, Pn * 4);
     sgr_carve(p, v.aux, Pn);
-    sgr_carve(p, v.aux_sorted, Pn);
+    sgr_carve(p, v.aux_sorted, 2 * Pn);
+    sgr_carve(p, v.aux_ref, Pn);
     sgr_carve(p, v.tmask, Pn);
     sgr_carve(p, v.u0, Pn);
     sgr_carve(p, v.clamped, Pn);
@@ -206,7 +215,7 @@ void sgr_launch_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp,
 // the last step itself: element i = tmp[i / 2048] + sub[i / 256] + its exclusive prefix inside its 256-element sub-block
 // (the forward's duplicate kernel: no third launch, no scanned array written and read back).
 void sgr_launch_scan_head(const uint32_t* in, const uint32_t* in2, size_t n, int in_stride, uint32_t* tmp, uint32_t* sub,
-                          hipStream_t s);
+                          hipStream_t s, int in2_stride = 0);  // in2_stride: stride of the second sequence (0: in_stride)
 // stable LSD radix sorts on key bits [0, end_bit); return the index (0/1) of the buffer pair holding the result
 int sgr_sort_get_one_sweep();
 void sgr_sort_set_one_sweep(int on);  // A/B: 1 = the one-sweep form instead of histogram + row scan + scatter per pass
@@ -216,7 +225,8 @@ int sgr_launch_sort_pairs(uint64_t* const keys[2], uint32_t* const vals[2], uint
 // into sorted order, aux_out[sorted position] = aux_in[value]
 int sgr_launch_sort_pairs32(uint32_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
                             uint32_t* scan_tmp, hipStream_t s, bool iota = false, const uint2* aux_in = nullptr,
-                            uint2* aux_out = nullptr, int max_bits = 8);  // max_bits: digit width cap, 8 or 9
+                            uint2* aux_out = nullptr, int max_bits = 8, int aux16 = 0);  // max_bits: digit width cap, 8 or 9;
+                            // aux16: the aux records are 16 bytes (uint4) instead of 8
 int sgr_sort_pass_count(int end_bit);  // passes (= buffer flips) of a sort on key bits [0, end_bit)
 // per-tile LDS sort by depth (sgr_tile_sort.hip): vals_in (tile-major, ascending id inside a tile) -> vals_out in (depth, id) order
 void sgr_launch_tile_sort(int T, const uint2* ranges, uint32_t* vals_in, uint32_t* vals_out, const uint32_t* dkeys,

@@ -161,6 +161,7 @@ sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     if (live && !ok) {
         radii[idx] = 0;
         gv.aux[idx] = make_uint2(0u, 0u);
+        if (tight == 3) gv.aux_ref[idx] = make_uint4(0u, 0u, 0u, 0u);
         gv.dkeys[0][idx] = 0xffffffffu;  // sorts behind every real depth (> 0.2 => sign bit clear)
     }
     if (ok) {
@@ -239,6 +240,8 @@ sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, co
             if (!(fy0 < fy1)) { fy0 = fminf(fmaxf(floorf(pr.py * inv), (float)y0), (float)(y1 - 1)); fy1 = fy0 + 1.0f; }
             x0 = (uint32_t)fx0; x1 = (uint32_t)fx1; y0 = (uint32_t)fy0; y1 = (uint32_t)fy1;
         }
+        // tight == 3 (marked-list mode): the reference's rect is what gets emitted (aux_ref); the cut-down rect + mask below
+        // say which of those instances are live and number the Gaussian's partial-gradient rows
         const uint32_t w = x1 - x0, h = y1 - y0;
         uint32_t rect = sgr_pack_rect(x0, y0, w);
         uint32_t nemit = w * h;
@@ -271,6 +274,9 @@ sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         rec[3] = make_float4(st.x, __uint_as_float(rect), st.y, st.z);
         gv.clamped[idx] = clamped;
         gv.aux[idx] = make_uint2(nemit, rect);
+        // tight == 3 (marked-list mode): the reference's rect is what gets emitted; the cut-down rect + mask say which of those
+        // instances are live and number the Gaussian's partial-gradient rows
+        if (tight == 3) gv.aux_ref[idx] = make_uint4(rn, sgr_pack_rect(pr.rx0, pr.ry0, pr.rx1 - pr.rx0), nemit, rect);
         // depth-sort key: the bits of the view depth minus the bits of 0.2 (every Gaussian that gets here has depth > 0.2):
         // monotone in the depth, and below 2^27 for depths under 13 107 -- sixteen octaves -- so that the sort takes THREE 9-bit
         // passes instead of four 8-bit ones.  A depth beyond that raises header[2]; the host reads it back together with
@@ -279,7 +285,7 @@ sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, co
         if (dkey >> SGR_DEPTH_KEY_BITS) atomicOr(&gv.header[2], 1u);
         gv.dkeys[0][idx] = dkey;
         radii[idx] = pr.radius;
-        n = nemit;
+        n = tight == 3 ? rn : nemit;  // the length of the list
     }
     // device-scope atomics on one address are resolved beyond the per-XCD L2s (~6 ns each, serialised): one per
     // workgroup, not one per wave (16k of them cost 0.1 ms at P = 1M)
@@ -314,7 +320,7 @@ static_assert(SGR_PRE_THREADS == 256 && SGR_SCAN_ITEMS == 8 * SGR_PRE_THREADS, "
 __global__ void __launch_bounds__(SGR_PRE_THREADS)
 sgr_duplicate_kernel(int P, SgrGeomView gv, const uint32_t* __restrict__ order, const uint32_t* __restrict__ bsum,
                      const uint32_t* __restrict__ sub, uint32_t nb, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                     int gx, uint32_t cap) {
+                     int gx, uint32_t cap, int marks) {
     // cap != 0 (the forward without a host wait, sgr_set_lazy): the list buffers hold `cap` slots whatever the frame's
     // instance count R turns out to be (bsum[nb], known to the device only) -- nothing is written past them, and the slots
     // [R, cap) get a key above every tile id, so that the sort over all `cap` slots leaves them at the end
@@ -329,15 +335,24 @@ sgr_duplicate_kernel(int P, SgrGeomView gv, const uint32_t* __restrict__ order, 
     __shared__ uint32_t sRect[SGR_PRE_THREADS / 64][64];
     __shared__ uint32_t sIdx[SGR_PRE_THREADS / 64][64];
     __shared__ uint64_t sMask[SGR_PRE_THREADS / 64][64];
+    __shared__ uint32_t sLive[SGR_PRE_THREADS / 64][64];   // marked-list mode: the owner's cut-down rect word
+    __shared__ uint32_t sLiveN[SGR_PRE_THREADS / 64][64];  // ... and its number of live tiles
     __shared__ uint32_t lds4[4];
     const int i = blockIdx.x * SGR_PRE_THREADS + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t off = 0xffffffffu, incl = 0, idx = 0, rect = 0;
+    uint32_t off = 0xffffffffu, incl = 0, idx = 0, rect = 0, live_rect = 0, live_n = 0;
     uint64_t tmask = 0;
     // everything in depth order and coalesced: the id, and {tiles_touched, tile rect} the depth sort's last pass carried
     // along (aux_sorted) -- no gather of the Gaussian's record
-    const uint2 as = (i < P) ? gv.aux_sorted[i] : make_uint2(0u, 0u);
-    const uint32_t t2 = (i < P) ? gv.aux[i].x : 0u;  // the same count in index order
+    uint2 as = make_uint2(0u, 0u), lv = make_uint2(0u, 0u);
+    if (i < P) {
+        if (marks) {  // 16-byte records {reference count, reference rect, live tiles, cut-down rect}
+            const uint4 t = reinterpret_cast<const uint4*>(gv.aux_sorted)[i];
+            as = make_uint2(t.x, t.y);
+            lv = make_uint2(t.z, t.w);
+        } else as = gv.aux_sorted[i];
+    }
+    const uint32_t t2 = (i < P) ? gv.aux[i].x : 0u;  // the count of rows in index order (marked-list mode: of the LIVE tiles)
     uint32_t total;
     const uint32_t ex1 = sgr_block_excl_scan256(as.x, lds4, total) + bsum[blockIdx.x >> 3] + sub[blockIdx.x];
     const uint32_t ex2 = sgr_block_excl_scan256(t2, lds4, total) + bsum[nb + 1 + (blockIdx.x >> 3)] + sub[8 * nb + blockIdx.x];
@@ -348,13 +363,18 @@ sgr_duplicate_kernel(int P, SgrGeomView gv, const uint32_t* __restrict__ order, 
         incl = ex1 + as.x;
         if (incl != off) {  // tiles_touched > 0
             rect = as.y;
-            if (rect & SGR_RECT_MASKED) tmask = gv.tmask[idx];  // (by id: 8 bytes, masked Gaussians only)
+            if (marks) {  // the cut-down rect and its mask: which tiles of the reference's rect are live
+                live_rect = lv.y;
+                live_n = lv.x;
+                if (live_rect & SGR_RECT_MASKED) tmask = gv.tmask[idx];
+            } else if (rect & SGR_RECT_MASKED) tmask = gv.tmask[idx];  // (by id: 8 bytes, masked Gaussians only)
         }
     }
     sOff[wave][lane] = off;  // lanes past P: 0xffffffff, never <= a slot
     sRect[wave][lane] = rect;
     sIdx[wave][lane] = idx;
     sMask[wave][lane] = tmask;
+    if (marks) { sLive[wave][lane] = live_rect; sLiveN[wave][lane] = live_n; }
     // wave-uniform slot range: exclusive offset of lane 0, inclusive offset of the last lane below P
     const uint32_t start = __builtin_amdgcn_readfirstlane(off);
     const int last = min(63, P - 1 - (blockIdx.x * SGR_PRE_THREADS + wave * 64));
@@ -372,14 +392,28 @@ sgr_duplicate_kernel(int P, SgrGeomView gv, const uint32_t* __restrict__ order, 
         const uint32_t r = sRect[wave][o];
         const uint32_t x0 = r & 1023u, y0 = (r >> 10) & 1023u, w = (r >> 20) & 1023u;
         uint32_t k = s - sOff[wave][o];
-        if (r & SGR_RECT_MASKED) k = sgr_select_bit(sMask[wave][o], k);  // the k-th tile of the mask, as an index into the rect
+        if (!marks && (r & SGR_RECT_MASKED)) k = sgr_select_bit(sMask[wave][o], k);  // the k-th tile of the mask, as an index into the rect
         // k / w with one v_rcp_f32 and an exact fix-up (k < 2^20)
         uint32_t q = (uint32_t)((float)k * __builtin_amdgcn_rcpf((float)w));
         int rem = (int)k - (int)(q * w);
         if (rem < 0) { q--; rem += (int)w; }
         if (rem >= (int)w) { q++; rem -= (int)w; }
-        keys[s] = (y0 + q) * (uint32_t)gx + x0 + (uint32_t)rem;
-        vals[s] = sIdx[wave][o];
+        const uint32_t tx = x0 + (uint32_t)rem, ty = y0 + q;
+        keys[s] = ty * (uint32_t)gx + tx;
+        uint32_t v = sIdx[wave][o];
+        if (marks) {
+            // live = inside the cut-down rect and, with a mask, one of its set tiles (index j inside that rect: below the
+            // number of its tiles without a mask -- which bounds the row -- or a set bit with one)
+            const uint32_t lr = sLive[wave][o];
+            const uint32_t lx0 = lr & 1023u, ly0 = (lr >> 10) & 1023u, lw = (lr >> 20) & 1023u;
+            const uint32_t dxl = tx - lx0, dyl = ty - ly0;  // (wrap around for tiles left of / above the rect: >= lw / huge)
+            const uint32_t j = dyl * lw + dxl;
+            bool live = dxl < lw && ty >= ly0;
+            if (lr & SGR_RECT_MASKED) live = live && j < 64u && ((sMask[wave][o] >> (j & 63u)) & 1ull);
+            else live = live && j < sLiveN[wave][o];
+            if (!live) v |= SGR_DEAD;
+        }
+        vals[s] = v;
     }
 }
 
@@ -412,7 +446,7 @@ sgr_compose_keys_kernel(int L, const uint32_t* __restrict__ tile_keys, const uin
                         const float4* __restrict__ rec, uint64_t* __restrict__ out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= L) return;
-    out[i] = ((uint64_t)tile_keys[i] << 32) | (uint64_t)__float_as_uint(rec[4 * (size_t)point_list[i] + 2].w);
+    out[i] = ((uint64_t)tile_keys[i] << 32) | (uint64_t)__float_as_uint(rec[4 * (size_t)(point_list[i] & ~SGR_DEAD) + 2].w);
 }
 
 // ---- host launchers ---------------------------------------------------------------------------
@@ -444,11 +478,11 @@ void sgr_launch_filter(int P, const float* means3D, const float* scales, const f
 
 // bsum / sub: what sgr_launch_scan_head left for the two count sequences (aux_sorted in depth order, aux in index order)
 void sgr_launch_duplicate(int P, const SgrGeomView& gv, const uint32_t* order, const uint32_t* bsum, const uint32_t* sub,
-                          uint32_t* keys, uint32_t* vals, int gx, uint32_t cap, hipStream_t s) {
+                          uint32_t* keys, uint32_t* vals, int gx, uint32_t cap, int marks, hipStream_t s) {
     if (P <= 0) return;
     const uint32_t nb = (uint32_t)(((size_t)P + SGR_SCAN_ITEMS - 1) / SGR_SCAN_ITEMS);
     sgr_duplicate_kernel<<<(P + SGR_PRE_THREADS - 1) / SGR_PRE_THREADS, SGR_PRE_THREADS, 0, s>>>(P, gv, order, bsum, sub, nb, keys,
-                                                                                             vals, gx, cap);
+                                                                                             vals, gx, cap, marks);
 }
 
 void sgr_launch_tile_ranges(int L, const uint32_t* keys, uint2* ranges, uint8_t* touched, uint32_t T, hipStream_t s) {

@@ -40,10 +40,10 @@ __global__ void __launch_bounds__(256) sgr_scan_reduce_kernel(const uint32_t* __
                                                               uint32_t* __restrict__ block_sums,
                                                               const uint32_t* __restrict__ gather, int stride,
                                                               const uint32_t* __restrict__ in2, unsigned nb,
-                                                              uint32_t* __restrict__ sub) {
+                                                              uint32_t* __restrict__ sub, int stride2) {
     __shared__ uint32_t lds4[4];
     unsigned b = blockIdx.x;
-    if (b >= nb) { b -= nb; in = in2; gather = nullptr; block_sums += nb + 1; if (sub) sub += 8 * nb; }
+    if (b >= nb) { b -= nb; in = in2; gather = nullptr; block_sums += nb + 1; if (sub) sub += 8 * nb; stride = stride2; }
     const size_t base = (size_t)b * SGR_SCAN_ITEMS + (size_t)threadIdx.x * 8;
     uint32_t s = 0;
 #pragma unroll
@@ -111,17 +111,18 @@ void sgr_launch_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp,
     const size_t nb = (n + SGR_SCAN_ITEMS - 1) / SGR_SCAN_ITEMS;
     const unsigned seqs = in2 ? 2u : 1u;
 
-    sgr_scan_reduce_kernel<<<(unsigned)nb * seqs, 256, 0, s>>>(in, n, tmp, gather, in_stride, in2, (unsigned)nb, nullptr);
+    sgr_scan_reduce_kernel<<<(unsigned)nb * seqs, 256, 0, s>>>(in, n, tmp, gather, in_stride, in2, (unsigned)nb, nullptr, in_stride);
     sgr_scan_spine_kernel<<<seqs, 256, 0, s>>>(tmp, nb, total_out);
     sgr_scan_final_kernel<<<(unsigned)nb * seqs, 256, 0, s>>>(in, out, n, tmp, gather, in_stride, inclusive, in2, out2,
                                                              (unsigned)nb);
 }
 
 void sgr_launch_scan_head(const uint32_t* in, const uint32_t* in2, size_t n, int in_stride, uint32_t* tmp, uint32_t* sub,
-                          hipStream_t s) {
+                          hipStream_t s, int in2_stride) {
+    if (in2_stride <= 0) in2_stride = in_stride;
     if (n == 0) return;
     const size_t nb = (n + SGR_SCAN_ITEMS - 1) / SGR_SCAN_ITEMS;
-    sgr_scan_reduce_kernel<<<(unsigned)nb * 2u, 256, 0, s>>>(in, n, tmp, nullptr, in_stride, in2, (unsigned)nb, sub);
+    sgr_scan_reduce_kernel<<<(unsigned)nb * 2u, 256, 0, s>>>(in, n, tmp, nullptr, in_stride, in2, (unsigned)nb, sub, in2_stride);
     sgr_scan_spine_kernel<<<2, 256, 0, s>>>(tmp, nb, nullptr);
 }
 
@@ -199,7 +200,7 @@ sgr_sort_scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ 
                         uint32_t* __restrict__ vout, uint32_t n, int shift, uint32_t nblocks,
                         const uint32_t* __restrict__ hist_scanned, const uint32_t* __restrict__ totals,
                         unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket, uint32_t* __restrict__ err,
-                        uint32_t pass_tag, const uint2* __restrict__ aux_in, uint2* __restrict__ aux_out) {
+                        uint32_t pass_tag, const uint2* __restrict__ aux_in, uint2* __restrict__ aux_out, int aux16) {
     constexpr int NB = 1 << BITS;
     constexpr int BPT = NB > 256 ? NB / 256 : 1;  // bins per thread in the prefix section (9-bit digits: 2)
     static_assert(!(ONE && NB > 256), "the one-sweep form has one status word per thread");
@@ -348,7 +349,10 @@ sgr_sort_scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ 
             const uint32_t v = sV[li];
             kout[pos] = k;
             vout[pos] = v;
-            if (aux_in != nullptr) aux_out[pos] = aux_in[v];
+            if (aux_in != nullptr) {  // aux16: the per-id record is 16 bytes (marked-list mode of the forward: SgrGeomView::aux_ref)
+                if (aux16) reinterpret_cast<uint4*>(aux_out)[pos] = reinterpret_cast<const uint4*>(aux_in)[v];
+                else aux_out[pos] = aux_in[v];
+            }
         }
     }
 }
@@ -428,14 +432,14 @@ int sgr_sort_pass_count(int end_bit) { return (end_bit + 7) / 8; }  // buffer fl
 
 template <typename K, int BITS, int IPT>
 static void sort_pass(const K* kin, const uint32_t* vin, K* kout, uint32_t* vout, uint32_t n, int shift, uint32_t* hist,
-                      const uint2* aux_in, uint2* aux_out, hipStream_t s) {
+                      const uint2* aux_in, uint2* aux_out, int aux16, hipStream_t s) {
     const uint32_t nblocks = (n + 256u * IPT - 1) / (256u * IPT);
     constexpr int NB = 1 << BITS;
     sgr_sort_hist_kernel<K, IPT><<<nblocks, 256, 0, s>>>(kin, n, shift, (uint32_t)(NB - 1), nblocks, hist);
     uint32_t* totals = hist + (size_t)NB * nblocks;
     sgr_sort_rowscan_kernel<<<NB, 256, 0, s>>>(hist, nblocks, totals);
     sgr_sort_scatter_kernel<K, BITS, IPT, false><<<nblocks, 256, 0, s>>>(kin, vin, kout, vout, n, shift, nblocks, hist, totals,
-                                                                         nullptr, nullptr, nullptr, 0u, aux_in, aux_out);
+                                                                         nullptr, nullptr, nullptr, 0u, aux_in, aux_out, aux16);
 }
 
 // Sorts n pairs on key bits [0, end_bit).  keys[0]/vals[0] hold the input; returns the index (0/1)
@@ -447,7 +451,7 @@ static void sort_pass(const K* kin, const uint32_t* vin, K* kout, uint32_t* vout
 template <typename K>
 static int sort_pairs_impl(K* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
                            uint32_t* scan_tmp, hipStream_t s, bool iota = false, const uint2* aux_in = nullptr,
-                           uint2* aux_out = nullptr, int max_bits = 8) {
+                           uint2* aux_out = nullptr, int max_bits = 8, int aux16 = 0) {
     if (n == 0) return 0;
     int npass = (end_bit + 7) / 8;
     int cur = 0;
@@ -465,7 +469,7 @@ static int sort_pairs_impl(K* const keys[2], uint32_t* const vals[2], uint32_t n
         for (int p = 0; p < npass; p++) {
             sgr_sort_scatter_kernel<K, 8, SGR_SORT_IPT, true><<<nblocks, 256, 0, s>>>(
                 keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, 8 * p, nblocks, nullptr, ghist + p * 256, status,
-                tickets + p, err, (uint32_t)p + 1u, nullptr, nullptr);
+                tickets + p, err, (uint32_t)p + 1u, nullptr, nullptr, 0);
             cur ^= 1;
         }
         return cur;
@@ -480,7 +484,7 @@ static int sort_pairs_impl(K* const keys[2], uint32_t* const vals[2], uint32_t n
         const uint2* ai = last ? aux_in : nullptr;
         uint2* ao = last ? aux_out : nullptr;
         const int shift = bits * p;
-#define SGR_PASS(B, I) sort_pass<K, B, I>(keys[cur], vin, keys[cur ^ 1], vals[cur ^ 1], n, shift, hist, ai, ao, s)
+#define SGR_PASS(B, I) sort_pass<K, B, I>(keys[cur], vin, keys[cur ^ 1], vals[cur ^ 1], n, shift, hist, ai, ao, aux16, s)
         if constexpr (sizeof(K) == 8) { SGR_PASS(8, 8); }
         else if (ipt == 16 && bits <= 8) {
             if (bits <= 5) SGR_PASS(5, 16); else if (bits == 6) SGR_PASS(6, 16); else if (bits == 7) SGR_PASS(7, 16); else SGR_PASS(8, 16);
@@ -498,6 +502,6 @@ int sgr_launch_sort_pairs(uint64_t* const keys[2], uint32_t* const vals[2], uint
     return sort_pairs_impl<uint64_t>(keys, vals, n, end_bit, hist, scan_tmp, s);
 }
 int sgr_launch_sort_pairs32(uint32_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
-                            uint32_t* scan_tmp, hipStream_t s, bool iota, const uint2* aux_in, uint2* aux_out, int max_bits) {
-    return sort_pairs_impl<uint32_t>(keys, vals, n, end_bit, hist, scan_tmp, s, iota, aux_in, aux_out, max_bits);
+                            uint32_t* scan_tmp, hipStream_t s, bool iota, const uint2* aux_in, uint2* aux_out, int max_bits, int aux16) {
+    return sort_pairs_impl<uint32_t>(keys, vals, n, end_bit, hist, scan_tmp, s, iota, aux_in, aux_out, max_bits, aux16);
 }

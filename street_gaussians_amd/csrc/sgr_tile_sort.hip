@@ -108,7 +108,7 @@ sgr_tile_sort_wave_kernel(int T, const uint2* __restrict__ ranges, const uint32_
 #pragma unroll
     for (int s = 0; s < SGR_TS_STEPS_W; s++) {
         const uint32_t i = s * 64 + lane;
-        key[s] = (s * 64u < n && i < n) ? dkeys[val[s]] : 0u;
+        key[s] = (s * 64u < n && i < n) ? dkeys[val[s] & ~SGR_DEAD] : 0u;
     }
     for (int p = 0; p < npass; p++) {
         const int shift = p * SGR_TS_BITS;
@@ -242,7 +242,7 @@ sgr_tile_sort_block_kernel(const uint2* __restrict__ ranges, uint32_t* vals_in, 
             val[s] = i < s1 ? in[i] : 0u;
         }
 #pragma unroll
-        for (int s = 0; s < SGR_TS_STEPS; s++) key[s] = (s0 + s * 64 + lane) < s1 ? dkeys[val[s]] : 0u;
+        for (int s = 0; s < SGR_TS_STEPS; s++) key[s] = (s0 + s * 64 + lane) < s1 ? dkeys[val[s] & ~SGR_DEAD] : 0u;
         for (int p = 0; p < npass; p++) {
             const int shift = p * SGR_TS_BITS;
             const bool last = p == npass - 1;
@@ -286,7 +286,7 @@ sgr_tile_sort_block_kernel(const uint2* __restrict__ ranges, uint32_t* vals_in, 
         uint32_t* vs = vals_in + rg.x;
         uint32_t* kd = gk1 + rg.x;
         uint32_t* vd = out;
-        for (uint32_t i = tid; i < n; i += THREADS) ks[i] = dkeys[vs[i]];
+        for (uint32_t i = tid; i < n; i += THREADS) ks[i] = dkeys[vs[i] & ~SGR_DEAD];
         __syncthreads();
         for (int p = 0; p < npass; p++) {
             const int shift = p * SGR_TS_BITS;

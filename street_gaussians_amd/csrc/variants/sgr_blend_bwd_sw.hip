@@ -210,7 +210,7 @@ sgr_blend_bwd_sw_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
     {
         const int pos = base - lane;
         if (pos >= 0) {
-            g_c = point_list[range.x + (uint32_t)pos];
+            g_c = point_list[range.x + (uint32_t)pos] & ~SGR_DEAD;
             h_c = hit4[range.x + (uint32_t)pos];
         }
     }
@@ -220,7 +220,7 @@ sgr_blend_bwd_sw_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
         {
             const int posn = base - 64 - lane;
             if (posn >= 0) {
-                g_n = point_list[range.x + (uint32_t)posn];
+                g_n = point_list[range.x + (uint32_t)posn] & ~SGR_DEAD;
                 h_n = hit4[range.x + (uint32_t)posn];
             }
         }
