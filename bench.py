@@ -256,14 +256,17 @@ def reference_kernels_on_gpu(args, cam, sc):
 class Workload:
     """One rasterizer workload resident in HBM: `step()` = forward + backward (+ the exchange step when N > 1)."""
 
-    def __init__(self, args, P, S, rank, dev, dist=None, force_dist=False, scene_file=None):
+    def __init__(self, args, P, S, rank, dev, dist=None, force_dist=False, scene_file=None, scene=None):
         from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
         from street_gaussians_amd import multiview
         self.args, self.P, self.S, self.dev = args, P, S, dev
         W, H = args.width, args.height
         # identical Gaussians on every rank (seed 0); rank r renders view r (yawed r*5 degrees)
         self.cam0 = syn.make_camera(W, H, fx=2050.0 * W / 1920.0)
-        if scene_file:
+        if scene is not None:  # rasterizer inputs somebody composed already (street_config)
+            self.scene = scene
+            self.P = P = scene.P
+        elif scene_file:
             self.scene = load_scene_file(scene_file, S)
             self.P = P = self.scene.P
         else:
@@ -1236,6 +1239,92 @@ def main():
         dist.destroy_process_group()
 
 
+def tile_loads(wl):
+    """List length per tile of this view (untimed; the exported ranges of a fresh forward): how unequal the tiles are."""
+    from street_gaussians_amd import _C as native
+    st, p = wl.st, wl.params
+    sem = p["semantics"].detach() if "semantics" in p else torch.zeros(wl.P, 0, device=wl.dev)
+    out = native.rasterize_gaussians(st.bg, p["means3D"].detach(), torch.Tensor([]), sem, p["opacities"].detach(),
+                                     p["scales"].detach(), p["rotations"].detach(), 1.0, torch.Tensor([]), st.viewmatrix,
+                                     st.projmatrix, st.tanfovx, st.tanfovy, st.image_height, st.image_width,
+                                     p["shs"].detach(), 3, st.campos, False, False)
+    rg = native.export_internal("ranges", wl.P, int(out[0]), wl.args.height, wl.args.width, out[6], out[7], out[8]).view(-1, 2)
+    n = (rg[:, 1] - rg[:, 0]).to(torch.float64)
+    srt = torch.sort(n).values
+    q = lambda f: int(srt[min(srt.numel() - 1, int(f * srt.numel()))].item())
+    return {"tiles": int(n.numel()), "empty_tiles": int((n == 0).sum().item()), "min": int(srt[0].item()), "median": q(0.5),
+            "mean": round(float(n.mean().item()), 1), "p99": q(0.99), "max": int(srt[-1].item()),
+            "max_over_mean": round(float(srt[-1].item() / max(n.mean().item(), 1e-9)), 2)}
+
+
+def street_config(args, L, dev, fence, P=2_000_000, S=19):
+    """BASELINE.json configs[2] as the reference builds such a frame (lib/models/street_gaussian_model.py:219-449): a static
+    background model + 12 posed actors with Fourier DC features, composed by street_gaussians_amd.scene into the
+    rasterizer's inputs -- road, facades, clutter, EMPTY SKY in the upper middle of the image, the actors' tiles carrying
+    lists several times the mean (synthetic.make_street_segments).  Reports how unequal the tiles are, the blend kernels'
+    cost per (pixel, Gaussian) pair next to the uniform scene's (other_configs: configs[2] 2M + 19 channels), and the same
+    step with the blend launches in LONGEST-FIRST tile order (sgr_test_switches bit 14) -- the experiment the uniform scene
+    could not decide (it decided: the forward now picks the order per frame)."""
+    from street_gaussians_amd import scene as sg
+    from street_gaussians_amd import _C as native_c
+    W, H = args.width, args.height
+    cam0 = syn.make_camera(W, H, fx=2050.0 * W / 1920.0)
+    raw = syn.make_street_segments(P, cam0, S=S, seed=0)
+    segs = [sg.Segment(**{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in d.items() if v is not None}) for d in raw]
+    with torch.no_grad():
+        means, rot, scl, opa, shs, sem = sg.compose(segs, 16, S)
+    scene = syn.Scene(means.contiguous(), scl.contiguous(), rot.contiguous(), opa.contiguous(), shs.contiguous(),
+                      (sem if S else torch.zeros(means.shape[0], 0, device=dev)).contiguous())
+    del segs
+    wl = Workload(args, scene.P, S, 0, dev, scene=scene)
+
+    def measure():
+        t_w, n_w = time.perf_counter(), 0
+        while n_w < 3 or time.perf_counter() - t_w < 0.25:
+            wl.step()
+            n_w += 1
+            if n_w % 16 == 0:
+                torch.cuda.synchronize()
+        steps = 20
+        dt, _ = profiled_steps(L, wl, fence, steps, 0)
+        _, st = profiled_steps(L, wl, fence, 10, 0x1FF)
+        return round(1e3 * dt / steps, 4), {k: (round(v, 4) if v is not None else None) for k, v in st.items()}
+
+    ms, st = measure()
+    R, V, pairs = wl.counts()
+    loads = tile_loads(wl)
+    cur = native_c.test_switches(-1)
+    native_c.test_switches(cur | native_c.NO_LPT)
+    try:
+        ms_st, st_st = measure()
+    finally:
+        native_c.test_switches(cur)
+    fast = None
+    if cur & (native_c.EXACT | native_c.REF_RECT):
+        base = cur & ~(native_c.EXACT | native_c.REF_RECT)
+        try:
+            native_c.test_switches(base)
+            f_ms, f_st = measure()
+            native_c.test_switches(base | native_c.NO_LPT)
+            fl_ms, fl_st = measure()
+            fast = {"ms_per_step": f_ms, "stages_ms": f_st, "supertile_order": {"ms_per_step": fl_ms, "stages_ms": fl_st}}
+        finally:
+            native_c.test_switches(cur)
+    return {"config": "configs[2] street-like composed scene: background + 12 posed actors (scene.compose), empty sky, "
+                      f"{scene.P} Gaussians + {S} semantic channels", "gaussians": scene.P, "semantic_channels": S, "mode": args.mode,
+            "actors": len(raw) - 1, "ms_per_step": ms, "stages_ms": st, "num_rendered_R": R, "instances_emitted": wl.R_emitted,
+            "visible_V": V, "sum_n_contrib_pairs": pairs, "tile_list_length": loads,
+            "blend_ns_per_1000_pairs": {k: round(1e6 * st[k] / max(pairs, 1) * 1e3, 3) for k in ("blend_fwd", "blend_bwd") if st.get(k)},
+            "tile_order": {"default_ms_per_step": ms, "supertile_order_ms_per_step": ms_st, "supertile_order_stages_ms": st_st,
+                           "blend_fwd_plus_bwd_ms": {"default": round((st["blend_fwd"] or 0) + (st["blend_bwd"] or 0), 4),
+                                                     "supertile_order": round((st_st["blend_fwd"] or 0) + (st_st["blend_bwd"] or 0), 4)},
+                           "what": "default: the forward decides per frame (one one-workgroup launch, timed inside blend_fwd) -- this "
+                                   "scene's longest list is > 2.5 x the mean, so both blend launches walk the tiles LONGEST LIST "
+                                   "FIRST; supertile_order = sgr_test_switches bit 15 (SGR_NO_LPT), the XCD-aware order the uniform "
+                                   "scenes keep"},
+            "fast": fast}
+
+
 def other_configs(args, L, dev, fence):
     """BASELINE.json's other single-GPU configurations on the same build (untimed extras of the N = 1 run): configs[1]
     500 k Gaussians, configs[2] 2 M Gaussians + 19 semantic channels, configs[4]'s per-GPU load 5 M Gaussians -- first the
@@ -1258,7 +1347,7 @@ def other_configs(args, L, dev, fence):
             steps = 20
             dt, _ = profiled_steps(L, wl, fence, steps, 0)
             _, st = profiled_steps(L, wl, fence, 10, 0x1FF)
-            R, V, _ = wl.counts()
+            R, V, pairs = wl.counts()
             # the same in the library's default (fast) mode, when the run's mode is another one
             fast = None
             from street_gaussians_amd import _C as native_c
@@ -1282,7 +1371,8 @@ def other_configs(args, L, dev, fence):
             out.append({"config": name, "gaussians": P, "semantic_channels": S, "steps": steps, "mode": args.mode,
                         "ms_per_step": round(1e3 * dt / steps, 4), "iters_per_s": round(steps / dt, 3),
                         "ms_per_step_fast": (fast or {}).get("ms_per_step"), "fast": fast,
-                        "num_rendered_R": R, "instances_emitted": wl.R_emitted, "visible_V": V,
+                        "num_rendered_R": R, "instances_emitted": wl.R_emitted, "visible_V": V, "sum_n_contrib_pairs": pairs,
+                        "blend_ns_per_1000_pairs": {k: round(1e6 * st[k] / max(pairs, 1) * 1e3, 3) for k in ("blend_fwd", "blend_bwd") if st.get(k)},
                         "stages_hbm_frac": stage_hbm_frac(st, sbe), "stages_hbm_frac_on_reference_R": stage_hbm_frac(st, sb),
                         "blend_bwd_ms": round(st["blend_bwd"], 4) if st["blend_bwd"] else None,
                         "blend_fwd_ms": round(st["blend_fwd"], 4) if st["blend_fwd"] else None,
@@ -1292,6 +1382,11 @@ def other_configs(args, L, dev, fence):
             del wl
         except Exception as ex:  # an extra: never lose the headline over it
             out.append({"config": name, "error": f"{type(ex).__name__}: {ex}"[:200]})
+    try:  # configs[2] as a street scene: composed background + actors, empty sky, clustered tiles
+        torch.cuda.empty_cache()
+        out.append(street_config(args, L, dev, fence))
+    except Exception as ex:
+        out.append({"config": "configs[2] street-like composed scene", "error": f"{type(ex).__name__}: {ex}"[:300]})
     try:  # configs[4] as written: the densify / prune step active between iterations
         torch.cuda.empty_cache()
         # twice (fresh state each time), both kept: the region is ~0.15 s long with a host synchronisation at every

@@ -224,6 +224,10 @@ int sgr_export_internal(int which, int P, int R, int width, int height, char* ge
  * (bit 31 of the internal list entry; export 8 strips it): they are counted, sorted and ranged exactly like the reference's
  * -- num_rendered, point_list, keys, ranges, n_contrib entry for entry -- but the blend kernels skip them without fetching
  * their record and they own no partial-gradient row.
+ * bits 14 / 15: tile order of the two blend launches.  Default: decided per frame on the device -- one one-workgroup launch
+ * per forward looks at the list lengths and, when the longest list is more than 2.5 x the mean (a street scene: empty sky
+ * next to actors), sorts the tile ids longest list first; an even scene keeps the XCD-aware supertile order.  Same results
+ * either way.  bit 14 (SGR_LPT=1) always longest-first, bit 15 (SGR_NO_LPT=1) never (and no extra launch).
  * bit 12 (SGR_TILE_SORT=1) the binning chain runs in its per-tile form (csrc/sgr_tile_sort.hip: no depth pre-sort of the
  * Gaussians, emission in index order, stable tile sort, then every tile's list radix-sorted by depth in LDS) -- the same
  * lists entry for entry (tests/test_gpu_tile_sort.py); A/B design, measured in DESIGN.md section 3.

@@ -428,6 +428,8 @@ def lazy_status():
 
 NO_TILE_MASK = 2048  # bounding-box rects without the per-tile mask (A/B)
 TILE_SORT = 4096  # binning chain A/B: index-order emission + per-tile LDS radix sort by depth (csrc/sgr_tile_sort.hip)
+LPT = 16384  # blend launches ALWAYS walk the tiles longest list first (default: decided per frame, longest list > 2.5 x the mean)
+NO_LPT = 32768  # blend launches never do: the XCD-aware supertile order without looking at the lists (round-5 behaviour)
 REF_RECT_PLAIN = 8192  # with REF_RECT: the reference's rects WITHOUT the dead-instance marks (the round-5 form of the strict mode, A/B)
 REF_RECT = 1024  # emit every Gaussian for the reference's whole tile rect (default: cut down to where alpha >= 1/255 is possible)
 

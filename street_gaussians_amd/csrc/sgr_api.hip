@@ -27,6 +27,7 @@ void sgr_launch_filter(int P, const float* means3D, const float* scales, const f
 void sgr_launch_duplicate(int P, const SgrGeomView& gv, const uint32_t* order, const uint32_t* bsum, const uint32_t* sub, uint32_t* keys,
                           uint32_t* vals, int gx, uint32_t cap, int marks, hipStream_t s);
 void sgr_launch_tile_ranges(int L, const uint32_t* keys, uint2* ranges, uint8_t* touched, uint32_t T, hipStream_t s);
+void sgr_launch_tile_order(const uint2* ranges, int T, int force, hipStream_t s);
 void sgr_launch_compose_keys(int L, const uint32_t* tile_keys, const uint32_t* point_list, const float4* rec, uint64_t* out,
                              hipStream_t s);
 void sgr_launch_blend_fwd(bool cull, bool exact, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W, int H,
@@ -95,7 +96,8 @@ static int switches() {
             (env_flag("SGR_NO_HITS") ? 8 : 0) | (env_flag("SGR_V2") ? 16 : 0) | (env_flag("SGR_PRE_STAGE") ? 64 : 0) |
             (env_flag("SGR_EXACT") ? 128 : 0) | ((env_flag("SGR_SW8") || env_flag("SGR_SW")) ? 256 : 0) | ((env_flag("SGR_SW9") || env_flag("SGR_RS_WAVE")) ? 512 : 0) |
             (env_flag("SGR_REF_RECT") ? 1024 : 0) | (env_flag("SGR_NO_TILE_MASK") ? 2048 : 0) | (env_flag("SGR_TILE_SORT") ? 4096 : 0) |
-            (env_flag("SGR_REF_RECT_PLAIN") ? 8192 : 0);
+            (env_flag("SGR_REF_RECT_PLAIN") ? 8192 : 0) | (env_flag("SGR_LPT") ? 16384 : 0) |
+            (env_flag("SGR_NO_LPT") ? 32768 : 0);
         if (!SGR_WITH_VARIANTS) v &= ~SGR_VARIANT_BITS;
         g_switches.store(v, std::memory_order_relaxed);
     }
@@ -634,7 +636,15 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     const int lcur = tile_sort ? (cur ^ 1) : cur;  // which vals[] holds the final list (list_index())
     prof_begin(5, stream);
     const bool cull = !(switches() & 1);
-    sgr_launch_blend_fwd(cull, (switches() & 128) != 0, gx, gy, iv.ranges, bv.vals[lcur], W, H, S, gv.rec, semantics,
+    // Tile order of the two blend launches: decided per frame on the device (sgr_tile_order_kernel: longest list first when
+    // the longest list is more than 2.5 x the mean, else the XCD-aware supertile order); switch bit 14 forces longest-first,
+    // bit 15 keeps the supertile order without looking (no extra launch: the round-5 behaviour)
+    const bool lpt = (switches() & 32768) == 0;
+    if (lpt) {
+        sgr_launch_tile_order(iv.ranges, (int)T, (switches() & 16384) ? 1 : 0, stream);
+        SGR_STAGE("tile_order");
+    }
+    sgr_launch_blend_fwd(cull, (switches() & 128) != 0, gx, lpt ? -gy : gy, iv.ranges, bv.vals[lcur], W, H, S, gv.rec, semantics,
                          background, out_color, out_depth, out_alpha, out_semantic, iv.n_contrib, bv.hit4, stream);
     SGR_STAGE("blend_fwd");
     prof_end(stream);
@@ -777,7 +787,7 @@ int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, 
                                     iv.n_contrib, bv.hit4, dL_dpix, dL_dpix_depth, dL_dalphas, partials, stride, touched, stream);
         else
 #endif
-            sgr_launch_blend_bwd(cull, dpp, det, (sw & 16) != 0, (sw & 128) != 0, gx, gy, iv.ranges, bv.vals[cur], W, H, S, background, gv.rec, gv.u0, gv.tmask, semantics,
+            sgr_launch_blend_bwd(cull, dpp, det, (sw & 16) != 0, (sw & 128) != 0, gx, (sw & 32768) ? gy : -gy, iv.ranges, bv.vals[cur], W, H, S, background, gv.rec, gv.u0, gv.tmask, semantics,
                                  alphas, iv.n_contrib, hits, dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, partials,
                                  touched, (uint32_t)R, stream);
         SGR_STAGE("blend_bwd");

@@ -239,7 +239,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t tx, ty;
-    if (!sgr_xcd_tile(blockIdx.x, (uint32_t)gx, (uint32_t)gy, tx, ty)) return;  // whole workgroup: padding block
+    if (!sgr_wg_tile(blockIdx.x, gx, gy, ranges, tx, ty)) return;  // whole workgroup: padding block
     const uint32_t tile = ty * (uint32_t)gx + tx;
     const uint32_t px = tx * SGR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
     const uint32_t py = ty * SGR_BLOCK_Y + (wave >> 1) * 8 + (lane >> 3);
@@ -864,7 +864,7 @@ sgr_blend_bwd_kernel_v2(SGR_BWD_ARGS) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t tx, ty;
-    if (!sgr_xcd_tile(blockIdx.x, (uint32_t)gx, (uint32_t)gy, tx, ty)) return;  // whole workgroup: padding block
+    if (!sgr_wg_tile(blockIdx.x, gx, gy, ranges, tx, ty)) return;  // whole workgroup: padding block
     const uint32_t tile = ty * (uint32_t)gx + tx;
     const uint32_t qx0 = tx * SGR_BLOCK_X + (wave & 1) * 8, qy0 = ty * SGR_BLOCK_Y + (wave >> 1) * 8;
     const uint32_t px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
@@ -1162,8 +1162,8 @@ void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, bool v2, bool exact, in
                           int H, int S, const float* bg, const float4* rec, const uint32_t* u0, const uint64_t* tmask, const float* semantics, const float* alphas, const uint32_t* n_contrib,
                           const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha,
                           const float* dL_dsem, float* partials, uint8_t* touched, uint32_t row_limit, hipStream_t s) {
-    if (gx <= 0 || gy <= 0) return;
-    const unsigned tiles = sgr_xcd_grid_blocks(gx, gy);  // supertile-ordered grid incl. padding blocks
+    if (gx <= 0 || gy == 0) return;
+    const unsigned tiles = sgr_xcd_grid_blocks(gx, gy < 0 ? -gy : gy);  // supertile-ordered grid incl. padding blocks
     const int stride = sgr_partial_row_stride(S);
 #define SGR_BWD(N) launch_bwd<N>(cull, dpp, det, v2, exact, tiles, s, ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, \
                                  n_contrib, hit4, dL_dpix, dL_ddepth, dL_dalpha, dL_dsem, partials, stride, touched, row_limit)

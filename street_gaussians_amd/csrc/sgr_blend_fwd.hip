@@ -58,7 +58,7 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t tx, ty;
-    if (!sgr_xcd_tile(blockIdx.x, (uint32_t)gx, (uint32_t)gy, tx, ty)) return;  // whole workgroup: padding block
+    if (!sgr_wg_tile(blockIdx.x, gx, gy, ranges, tx, ty)) return;  // whole workgroup: padding block
     const uint32_t tile = ty * (uint32_t)gx + tx;
     const uint32_t px = tx * SGR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
     const uint32_t py = ty * SGR_BLOCK_Y + (wave >> 1) * 8 + (lane >> 3);
@@ -293,8 +293,8 @@ void sgr_launch_blend_fwd(bool cull, bool exact, int gx, int gy, const uint2* ra
                           int S, const float4* rec, const float* semantics,
                           const float* bg, float* out_color, float* out_depth, float* out_alpha, float* out_semantic,
                           uint32_t* n_contrib, uint8_t* hit4, hipStream_t s) {
-    if (gx <= 0 || gy <= 0) return;
-    const unsigned tiles = sgr_xcd_grid_blocks(gx, gy);  // supertile-ordered grid incl. padding blocks
+    if (gx <= 0 || gy == 0) return;
+    const unsigned tiles = sgr_xcd_grid_blocks(gx, gy < 0 ? -gy : gy);  // supertile-ordered grid incl. padding blocks
 #define SGR_FWD(N) launch_fwd<N>(cull, exact, tiles, s, ranges, point_list, W, H, S, gx, gy, rec, semantics, bg, \
                                  out_color, out_depth, out_alpha, out_semantic, n_contrib, hit4)
     if (S == 0) SGR_FWD(0);

@@ -178,7 +178,7 @@ static inline SgrImgView sgr_img_carve(char* base, size_t N, size_t T, char** en
     SgrImgView v;
     char* p = base;
     sgr_carve(p, v.n_contrib, N ? N : 1);
-    sgr_carve(p, v.ranges, T ? T : 1);
+    sgr_carve(p, v.ranges, (T ? T : 1) + ((T ? T : 1) + 2) / 2);  // + T + 1 words behind the ranges: the tile-order block (sgr_wg_tile)
     if (end) *end = p;
     return v;
 }
@@ -271,6 +271,24 @@ __device__ __forceinline__ bool sgr_xcd_tile(uint32_t b, uint32_t gx, uint32_t g
     tx = (st % sgx) * SGR_ST + (within % SGR_ST);
     ty = (st / sgx) * SGR_ST + (within / SGR_ST);
     return tx < gx && ty < gy;
+}
+
+// Tile of workgroup b.  gy >= 0: the XCD-aware supertile order above.  gy < 0: the grid is |gy| rows high and the frame's
+// tile-order block sits behind ranges[T] -- T tile ids sorted by descending list length, then ONE flag word: 1 = walk the
+// tiles in that LONGEST-FIRST order, 0 = the lists are even enough, use the supertile order (sgr_tile_order_kernel decides
+// per frame).  Heaviest tiles first shortens the ragged end of a launch whose tiles are very unequal -- a street scene: empty
+// sky next to actors, -10 % of the step -- at the price of the L2 locality of neighbouring tiles, which is what an even
+// scene lives on (+1 %): measured, DESIGN.md section 3.
+__device__ __forceinline__ bool sgr_wg_tile(uint32_t b, int gx, int gy, const uint2* __restrict__ ranges, uint32_t& tx, uint32_t& ty) {
+    if (gy >= 0) return sgr_xcd_tile(b, (uint32_t)gx, (uint32_t)gy, tx, ty);
+    const uint32_t T = (uint32_t)gx * (uint32_t)(-gy);
+    const uint32_t* order = reinterpret_cast<const uint32_t*>(ranges + T);
+    if (order[T] == 0u) return sgr_xcd_tile(b, (uint32_t)gx, (uint32_t)(-gy), tx, ty);
+    if (b >= T) return false;
+    const uint32_t t = order[b];
+    tx = t % (uint32_t)gx;
+    ty = t / (uint32_t)gx;
+    return true;
 }
 
 // Move a wave-uniform 64-bit value into SGPRs.  __builtin_amdgcn_readfirstlane returns a SIGNED int:

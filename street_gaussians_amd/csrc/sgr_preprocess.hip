@@ -7,6 +7,8 @@
 // instance with three 16-byte loads.
 #include "sgr_math.h"
 
+#include <cstdlib>
+
 #ifndef SGR_PRE_THREADS
 #define SGR_PRE_THREADS 256
 #endif
@@ -438,6 +440,66 @@ sgr_tile_ranges_kernel(int L, const uint32_t* __restrict__ keys, uint2* __restri
         }
     }
     if (idx == L - 1 && currtile < T) ranges[currtile].y = L;
+}
+
+// ---- tile order of the blend launches (sgr_wg_tile): decides per frame whether the lists are unequal enough for a
+// LONGEST-FIRST walk -- the longest list more than `ratio_x16` / 16 times the mean (force: always) -- and if so sorts the T
+// tile ids by descending list length into the T words behind the ranges; the word behind those is the flag.  One workgroup:
+// maximum + sum, a 1024-bucket histogram of length * 1023 / max (descending), scan, scatter; the order inside a bucket is
+// whatever the LDS atomics give (tiles are independent: no result depends on it).
+__global__ void __launch_bounds__(1024)
+sgr_tile_order_kernel(const uint2* __restrict__ ranges, uint32_t T, uint32_t* __restrict__ order, uint32_t ratio_x16, int force) {
+    __shared__ uint32_t hist[1024];
+    __shared__ uint32_t smax;
+    __shared__ unsigned long long ssum;
+    __shared__ uint32_t sw[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    hist[tid] = 0u;
+    if (tid == 0) { smax = 0u; ssum = 0ull; }
+    __syncthreads();
+    uint32_t mx = 0;
+    unsigned long long sm = 0;
+    for (uint32_t t = tid; t < T; t += 1024) {
+        const uint32_t len = ranges[t].y - ranges[t].x;
+        mx = max(mx, len);
+        sm += len;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+        sm += (unsigned long long)__shfl_xor((long long)sm, o, 64);
+    }
+    if (lane == 0) { atomicMax(&smax, mx); atomicAdd(&ssum, sm); }
+    __syncthreads();
+    // longest list vs the mean list: max * T * 16 > ratio_x16 * sum
+    const bool lpt = force || (unsigned long long)smax * T * 16ull > (unsigned long long)ratio_x16 * ssum;
+    if (tid == 0) order[T] = lpt ? 1u : 0u;
+    if (!lpt) return;
+    const float sc = 1023.0f / (float)max(smax, 1u);
+    for (uint32_t t = tid; t < T; t += 1024) {
+        const uint32_t len = ranges[t].y - ranges[t].x;
+        atomicAdd(&hist[1023u - min(1023u, (uint32_t)((float)len * sc))], 1u);
+    }
+    __syncthreads();
+    const uint32_t c = hist[tid];
+    const uint32_t inc = sgr_wave_incl_scan(c, lane);
+    if (lane == 63) sw[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; w++) base += sw[w];
+    __syncthreads();
+    hist[tid] = base + inc - c;
+    __syncthreads();
+    for (uint32_t t = tid; t < T; t += 1024) {
+        const uint32_t len = ranges[t].y - ranges[t].x;
+        order[atomicAdd(&hist[1023u - min(1023u, (uint32_t)((float)len * sc))], 1u)] = t;
+    }
+}
+void sgr_launch_tile_order(const uint2* ranges, int T, int force, hipStream_t s) {
+    if (T <= 0) return;
+    // threshold: the longest list > 2.5 x the mean list (the benchmark's uniform scenes: 1.4-1.7 x; a street scene: 5 x)
+    static const uint32_t ratio_x16 = [] { const char* e = getenv("SGR_LPT_RATIO_X16"); return e ? (uint32_t)atoi(e) : 40u; }();
+    sgr_tile_order_kernel<<<1, 1024, 0, s>>>(ranges, (uint32_t)T, reinterpret_cast<uint32_t*>(const_cast<uint2*>(ranges) + T), ratio_x16, force);
 }
 
 // parity introspection: the reference's 64-bit sorted keys, recomposed from tile id and depth bits

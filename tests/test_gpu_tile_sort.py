@@ -103,3 +103,28 @@ def test_tile_sort_form_is_deterministic_over_repeated_forwards():
     first = _run(kw, wts, _C.TILE_SORT)
     for _ in range(3):
         _same(first, _run(kw, wts, _C.TILE_SORT), "repeat")
+
+
+@pytest.mark.parametrize("mode", ["default", "strict"])
+def test_longest_first_tile_order_changes_nothing(mode):
+    """The tile order of the blend launches (XCD-aware supertiles / longest list first / decided per frame: sgr_test_switches
+    bits 15 / 14 / default) changes no output and no internal array, bit for bit (tiles are independent) -- on a street-like
+    scene with an empty sky and actor clusters composed by scene.compose."""
+    from street_gaussians_amd import scene as sg
+    cam = syn.make_camera(480, 320, fx=512.5)
+    raw = syn.make_street_segments(60000, cam, n_actors=5, S=3, seed=2)
+    segs = [sg.Segment(**{k: (v.cuda() if torch.is_tensor(v) else v) for k, v in d.items() if v is not None}) for d in raw]
+    with torch.no_grad():
+        means, rot, scl, opa, shs, sem = sg.compose(segs, 16, 3)
+    sc = syn.Scene(means.cpu(), scl.cpu(), rot.cpu(), opa.cpu(), shs.cpu(), sem.cpu())
+    kw = oracle_kwargs(cam, sc)
+    wts = syn.loss_weights(cam, S=3)
+    base = (_C.EXACT | _C.REF_RECT) if mode == "strict" else 0
+    a = _run(kw, wts, base | _C.NO_LPT)          # XCD-aware supertile order, no look at the lists
+    b = _run(kw, wts, base | _C.LPT)             # always longest-first
+    c = _run(kw, wts, base)                      # decided per frame (this scene: longest-first)
+    _same(a, b, "lpt/" + mode)
+    _same(a, c, "adaptive/" + mode)
+    rg = a["i_ranges"].reshape(-1, 2).astype(np.int64)
+    n = rg[:, 1] - rg[:, 0]
+    assert (n == 0).sum() > 10 and n.max() > 4 * n.mean()  # empty sky tiles and tiles several times the mean
