@@ -208,8 +208,9 @@ int sgr_export_internal(int which, int P, int R, int width, int height, char* ge
  * geometric cull, bit 4 the S = 0 backward runs the transposed-accumulation kernel (A/B design, slower),
  * bit 5 the radix sorts run in their one-sweep (decoupled look-back) form (A/B design, slower; SGR_ONESWEEP),
  * bit 7 (SGR_EXACT=1) PARITY MODE: the blend FORWARD evaluates the reference's own power expression, the device
- * library's expf and the unfused C += c * alpha * T -- alpha / depth / semantic images and n_contrib bit-identical to the
- * reference's kernels; the blend BACKWARD evaluates the reference's power expression and makes every blend / skip decision
+ * library's expf and the unfused D += d * alpha * T of the depth, alpha and semantic sums -- alpha / depth / semantic images
+ * and n_contrib bit-identical to the reference's kernels; the three COLOUR sums are formed as FMAs (their inputs, the SH
+ * colours, already differ from the reference's in the last bit): the colour image is held to rel 1e-4, not bit-exact; the blend BACKWARD evaluates the reference's power expression and makes every blend / skip decision
  * exactly as the forward did (a visit with a pixel within 4e-6 of the 1/255 threshold falls back to the accurate expf), the
  * per-Gaussian backward runs without FP contraction -- gradients within rel 1e-4 end to end,
  * bit 8 (SGR_SW=1) the S = 0 blend backward runs its scalar-walk form (csrc/sgr_blend_bwd_sw.hip: A/B design, slower),

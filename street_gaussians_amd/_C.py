@@ -11,7 +11,7 @@ import torch
 
 from . import _native
 from . import _alloc
-from ._native import ALLOC_FN, SgrError, check
+from ._native import ALLOC_FN, SgrError, SgrLazyError, check
 
 NUM_CHANNELS = 3  # config.h:15
 
@@ -62,7 +62,8 @@ def _call_ext(fn, *args):
     except RuntimeError as ex:  # std::runtime_error of the C++ side -> the error type of the ctypes binding
         if isinstance(ex, SgrError):
             raise
-        raise SgrError(str(ex).split("\n")[0]) from None
+        msg = str(ex).split("\n")[0]
+        raise (SgrLazyError if "PREVIOUS lazy forward" in msg else SgrError)(msg) from None
 
 
 class _StatSegment(C.Structure):  # sgr_stat_segment (include/sgr.h)

@@ -6,7 +6,10 @@ for a block size it has not seen, the cached blocks of the old size stay behind 
 allocation -- tens of milliseconds for a multi-GB block on some hosts (measured: BENCH_r04 configs[4], 7-40 device
 allocations inside a 30-iteration region).  Rounding the BACKING size of those tensors up to a ladder of eight steps per
 octave makes consecutive sizes repeat: P + 5 % asks for the block P used (or the next step, once per ~2 densify steps),
-at a cost of at most 12.5 % of slack.  The tensor itself keeps its exact shape (a view of the rounded storage)."""
+at a cost of at most 12.5 % of slack.  The tensor itself keeps its exact shape (a view of the rounded storage) -- which
+also means ``untyped_storage().nbytes()`` exceeds ``numel() * 4`` and ``torch.save`` would write the slack: use
+``checkpoint.save`` / ``checkpoint.exact_storage`` (it clones such tensors into exact storages) for anything that goes to
+disk, and do not ``resize_`` these tensors."""
 from __future__ import annotations
 
 import math

@@ -36,6 +36,17 @@ class SgrError(RuntimeError):
     pass
 
 
+class SgrLazyError(SgrError):
+    """-SGR_E_LAZY (lazy mode, sgr_set_lazy): the PREVIOUS lazy forward of this thread was invalid (list capacity overflow,
+    prefilter violation, a depth beyond the narrow depth sort) -- ITS outputs and the gradients computed from them must be
+    discarded (redo that step; do not apply its optimiser update).  The call that raised this rendered nothing; the thread's
+    next forward is a blocking one that re-seeds the capacity.  Check ``_C.lazy_status()`` after a synchronisation and BEFORE
+    applying gradients when a one-step-late report is not acceptable."""
+
+
+SGR_E_LAZY = 5
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -153,5 +164,5 @@ def lib():
 
 def check(rc: int) -> int:
     if rc < 0:
-        raise SgrError(lib().sgr_last_error().decode())
+        raise (SgrLazyError if rc == -SGR_E_LAZY else SgrError)(lib().sgr_last_error().decode())
     return rc

@@ -77,8 +77,25 @@ def load(path: str) -> "OrderedDict[str, Dict[str, torch.Tensor]]":
     return models_from_state(torch.load(path, map_location="cpu", weights_only=False))
 
 
+def exact_storage(obj):
+    """torch.save writes a tensor's WHOLE storage.  Tensors that come out of this library's densify step (and its gradient
+    outputs) are views of ladder-sized storages (street_gaussians_amd/_alloc.py: up to 12.5 % of uninitialised slack behind
+    the data), so they are cloned into storages of exactly their size here -- the file then holds what the reference's
+    ``torch.cat`` outputs would (gaussian_model.py:363-407).  Recurses through dicts / lists / tuples."""
+    if isinstance(obj, torch.Tensor):
+        exact = obj.numel() * obj.element_size()
+        if obj.layout == torch.strided and obj.untyped_storage().nbytes() != exact:
+            return obj.detach().clone(memory_format=torch.contiguous_format)
+        return obj
+    if isinstance(obj, dict):
+        return type(obj)((k, exact_storage(v)) for k, v in obj.items())
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(exact_storage(v) for v in obj)
+    return obj
+
+
 def save(path: str, models, **kw) -> None:
-    torch.save(state_from_models(models, **kw), path)
+    torch.save(exact_storage(state_from_models(models, **kw)), path)
 
 
 def segments(models: Dict[str, Dict], device, poses: Optional[Dict[str, torch.Tensor]] = None, idfts=None):

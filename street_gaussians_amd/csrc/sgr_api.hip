@@ -164,20 +164,23 @@ int sgr_set_error(int code, const std::string& msg) { return fail(code, msg); } 
         if (e__ != hipSuccess) return fail(SGR_E_HIP, std::string("stage ") + name + ": " + hipGetErrorString(e__)); \
     } while (0)
 
-// per-thread pinned landing zone for the forward's one device->host readback
-static uint32_t* pinned_pair() {
-    static thread_local uint32_t* p = nullptr;
+// per-thread pinned landing zones for the forward's one device->host readback.  Slot 0: the blocking forward and
+// sgr_visible_filter(prefiltered = 1), both of which wait for their copy before they return.  Slot 1: the LAZY forward, whose
+// copy is looked at one call later -- its own slot, so that a filter call or a blocking forward in between cannot overwrite
+// words a pending late check still has to read.
+static uint32_t* pinned_pair(int slot = 0) {
+    static thread_local uint32_t* p[2] = {nullptr, nullptr};
     // coherent (uncached on the device side): the host watches these words while the copy is in flight
-    if (!p && hipHostMalloc((void**)&p, 64, hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess) p = nullptr;
-    return p;
+    if (!p[slot] && hipHostMalloc((void**)&p[slot], 64, hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess) p[slot] = nullptr;
+    return p[slot];
 }
 // ... and the event that marks "the readback has landed" while later kernels are already queued behind it
-static hipEvent_t readback_event() {
-    static thread_local hipEvent_t ev[64] = {};  // events belong to a device: one per (thread, device)
+static hipEvent_t readback_event(int slot = 0) {
+    static thread_local hipEvent_t ev[2][64] = {};  // events belong to a device: one per (thread, slot, device)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!ev[dev] && hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming) != hipSuccess) ev[dev] = nullptr;
-    return ev[dev];
+    if (!ev[slot][dev] && hipEventCreateWithFlags(&ev[slot][dev], hipEventDisableTiming) != hipSuccess) ev[slot][dev] = nullptr;
+    return ev[slot][dev];
 }
 
 // The forward's one host wait.  hipEventSynchronize() parks the thread on an interrupt, and how long it takes to come
@@ -422,7 +425,9 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(stream, &cap_status);
     const bool capturing = cap_status != hipStreamCaptureStatusNone;
-    if (t_lazy.pending && !capturing) {
+    // (also inside a stream capture: the pending copy and its event were queued BEFORE the capture began, waiting for them
+    // on the host is legal, and the frame they belong to must not lose its check)
+    if (t_lazy.pending) {
         t_lazy.pending = false;
         SGR_HIP(wait_for_readback(t_lazy.host_vals, t_lazy.landed));  // queued a whole step ago: landed long since
         const int fl = lazy_flags(t_lazy);
@@ -466,12 +471,19 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
                               rmode, stream);
         SGR_STAGE("preprocess");
         prof_end(stream);
-        host_vals = pinned_pair();
-        hipEvent_t landed = readback_event();
+        host_vals = pinned_pair(1);
+        hipEvent_t landed = readback_event(1);
         if (!host_vals || !landed) return fail(SGR_E_HIP, "pinned readback slot / event creation failed");
         if (!capturing) host_vals[0] = host_vals[2] = host_vals[4] = host_vals[5] = SGR_READBACK_PENDING;
         SGR_HIP(hipMemcpyAsync(host_vals, gv.header, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         if (!capturing) SGR_HIP(hipEventRecord(landed, stream));
+        // from here on a copy is in flight: the late check is owed whatever happens to the rest of this call (an error
+        // return below must not leave a copy nobody waits for -- the next forward would take its late arrival for its own)
+        t_lazy.pending = !capturing;
+        t_lazy.host_vals = host_vals;
+        t_lazy.landed = landed;
+        t_lazy.wide = wide_depth;
+        t_lazy.cap = 0x7fffffffu;  // (set below; until then "no overflow")
         prof_begin(1, stream);
         const int dcur = sgr_launch_sort_pairs32(gv.dkeys, gv.dvals, (uint32_t)P, wide_depth ? 32 : SGR_DEPTH_KEY_BITS, gv.dhist,
                                                  gv.scan_tmp, stream, true, aux_emit, gv.aux_sorted, P < 750000 ? 9 : 8, aux16);
@@ -490,11 +502,7 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
         bbase = binning_buffer(sgr_binning_bytes((int)cap), binning_user);
         if (!bbase) return fail(SGR_E_ALLOC, "binning buffer allocation failed");
         R = (int)cap;  // what the caller hands to sgr_backward: it sizes the same carving there
-        t_lazy.pending = !capturing;
         t_lazy.cap = cap;
-        t_lazy.host_vals = host_vals;
-        t_lazy.landed = landed;
-        t_lazy.wide = wide_depth;
     }
     for (int attempt = 0; attempt < 2 && !lazy; attempt++) {
         prof_begin(0, stream);

@@ -400,21 +400,31 @@ SGR_HD float sgr_power_ref_staged(float hx, float ny, float hz, float dx, float 
 // ---- parity-mode elementary functions ------------------------------------------------------------------------------
 // expf as the device library evaluates it on gfx950 (ocml expF / LLVM's f32 exp lowering, read off the ISA hipcc emits
 // for `expf`: ph = x*c, pl = fma(x, cc, fma(x, c, -ph)), e = rint(ph), v_exp_f32(ph - e + pl), ldexp by e), operation by
-// operation -- WITHOUT its two range selects (x < -103.28 -> 0, x > 88.72 -> inf: two v_cmp + two v_cndmask + the wait
-// states between them, 6 issue slots of 15).  The blend kernels never use G for a positive power, and for very negative
-// arguments ldexp underflows to the same 0 on its own as long as `e` is finite; one v_max on ph keeps it finite (for
-// ph >= -200 the clamp is the identity, below it pl absorbs the difference and the result is 0 either way; a NaN
-// argument still gives NaN through pl).  Bit-identical to expf for every -103 <= x <= 88.72, 0 or 2^-149 below, NaN for NaN
-// (sgr_test_exact_math, tests/test_gpu_primitives.py).
+// operation, for the arguments the blend kernels USE G for -- power <= 0 and alpha = opacity * G >= 1/255, i.e. x >= -5.6 --
+// with three shortcuts that change no bit there (round 6; round 4 had dropped the library's two range selects):
+//   * e = rint(ph) as (ph + 1.5 * 2^23) - 1.5 * 2^23: two full-rate adds instead of v_rndne_f32 (4.2 cycles per wave
+//     instruction on gfx950, profiles/r5/valu_rates2.jsonl); exact for |ph| < 2^22;
+//   * the scaling by 2^e as an integer add into the exponent field -- bits(v) + (bits(ph + 1.5 * 2^23) << 23), the low bits of
+//     that sum ARE e in two's complement -- one v_lshl_add_u32 instead of v_cvt_i32_f32 + v_ldexp_f32 (4 + 4.2 cycles);
+//     exact whenever the result is a normal number, which the clamp below guarantees (v in [0.7, 1.42], e >= -124);
+//   * the ARGUMENT clamped at -86 (one v_max, where round 4 clamped ph at -200): exp(-86) = 4.5e-38 is as much "alpha <
+//     1/255" as the 0 expf returns further down, and with it every intermediate stays in the range the two shortcuts above
+//     are exact in (clamping ph instead leaves `a` unbounded below, and an exponent-field add on a tiny v can land on a NaN
+//     pattern -- a NaN alpha PASSES the kernels' !(alpha < thr) test).
+// Bit-identical to expf for every -86 <= x <= 87 (sgr_test_exact_math, tests/test_gpu_primitives.py); expf(-86) below; NaN
+// -> expf(-86) as well (the reference blends a NaN power with alpha 0.99: fminf(0.99f, NaN)); x > 88 is not meaningful (the
+// kernels never use G for a positive power).  10 -> 8 instructions, 34 -> 28 issue cycles.
 SGR_HD float sgr_expf_ref(float x) {
 #pragma clang fp contract(off)
     const float c = 0x1.715476p+0f, cc = 0x1.4ae0bep-26f;  // c + cc = 49 bits of log2(e)
-    const float ph = fmaxf(x * c, -200.0f);
-    const float pl = fmaf(x, cc, fmaf(x, c, -ph));
-    const float e = __builtin_rintf(ph);
+    const float xc = fmaxf(x, -86.0f);
+    const float ph = xc * c;
+    const float pl = fmaf(xc, cc, fmaf(xc, c, -ph));
+    const float t = ph + 12582912.0f;  // 1.5 * 2^23: the sum's low mantissa bits hold rint(ph)
+    const float e = t - 12582912.0f;
     const float a = (ph - e) + pl;
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(a), (int)e);
+    return __uint_as_float(__float_as_uint(__builtin_amdgcn_exp2f(a)) + (__float_as_uint(t) << 23));
 #else
     return ldexpf(exp2f(a), (int)e);
 #endif

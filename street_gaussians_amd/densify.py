@@ -49,7 +49,7 @@ def _p(t):
 # gaussian_model.py:363-407).  Here the trainer reserves ONE block of about twice the bytes that are live at the largest
 # size it expects and hands it straight back to torch's caching allocator, which then serves every re-sized tensor by
 # splitting it: no device allocation inside the loop.  The pool belongs to the library (round 4 left a fixed 48 GB
-# reservation in bench.py); it grows by an eighth when the estimate outgrows it and never exceeds `factor` x live.
+# reservation in bench.py); it grows (by the difference, at least an eighth) when the estimate outgrows it; a request that did not fit is not repeated.
 def live_bytes_estimate(n_points: int, sh_coeffs: int = 16, semantic_channels: int = 0, instances_per_point: float = 8.0) -> int:
     """Bytes live at n_points Gaussians in one training iteration: raw parameters, gradients, two Adam moments, the activated
     rasterizer inputs with their gradients, the geometry / binning buffers and the backward's partial rows
@@ -66,19 +66,26 @@ class Pool:
 
     def __init__(self, device, factor: float = 1.5, **estimate_kw):
         self.device, self.factor, self.kw = torch.device(device), float(factor), estimate_kw
-        self.reserved = 0  # bytes of the block handed to the allocator so far
+        self.reserved = 0  # bytes handed to the allocator so far (the sum of the blocks below)
+        self.failed_at = None  # smallest request that did not fit: not asked for again (a failed torch allocation flushes the
+                               # caching allocator first -- exactly the stall the pool exists to remove)
 
     def reserve(self, n_points: int) -> int:
         want = int(self.factor * live_bytes_estimate(n_points, **self.kw))
         if want <= self.reserved:
             return self.reserved
         want = max(want, self.reserved + self.reserved // 8)
+        # grow by the DELTA: the block reserved earlier stays with the allocator (possibly split among live tensors), so a
+        # fresh block of `want` bytes next to it would make the allocator hold reserved + want
+        delta = want - self.reserved
+        if self.failed_at is not None and delta >= self.failed_at:
+            return self.reserved
         try:
-            blk = torch.empty(want, dtype=torch.uint8, device=self.device)
-            del blk  # stays with the caching allocator as one free block
+            blk = torch.empty(delta, dtype=torch.uint8, device=self.device)
+            del blk  # stays with the caching allocator as a free block
             self.reserved = want
         except RuntimeError:
-            self.reserved = 0  # not enough memory for the head-room: the loop falls back to allocating as it goes
+            self.failed_at = delta  # not enough memory for the head-room: the loop allocates as it goes, and is not asked again
         return self.reserved
 
 

@@ -199,3 +199,20 @@ def test_viewer_ply_matches_the_reference_make_ply_script(tmp_path):
     # and it reads back as a single-model scene
     m = plyio.read_scene_ply(out)[""]
     assert np.allclose(m["xyz"], stub.get_xyz.numpy()) and m["features_rest"].shape == (n, M - 1, 3)
+
+
+def test_checkpoint_save_drops_the_size_ladders_slack(tmp_path):
+    """Tensors backed by ladder-sized storages (street_gaussians_amd/_alloc.py: the densify step's outputs) must reach the
+    file with storages of exactly their size: torch.save writes whole storages."""
+    import torch
+    from street_gaussians_amd import checkpoint
+    big = torch.zeros(1 << 19, dtype=torch.float32)          # 2 MiB storage
+    view = big[:300_000].view(100_000, 3)                    # 1.2 MB of it: what _alloc.empty hands out
+    assert view.untyped_storage().nbytes() > view.numel() * 4
+    out = checkpoint.exact_storage({"a": view, "b": [view, 3], "c": torch.ones(4)})
+    assert out["a"].untyped_storage().nbytes() == view.numel() * 4 and torch.equal(out["a"], view)
+    assert out["b"][0].untyped_storage().nbytes() == view.numel() * 4 and out["b"][1] == 3
+    assert out["c"].untyped_storage().nbytes() == 16
+    p = tmp_path / "t.pth"
+    torch.save(out, p)
+    assert p.stat().st_size < 2 * view.numel() * 4 + 20_000 + view.numel() * 4  # three exact copies at most, no 2 MiB storages
