@@ -13,6 +13,12 @@ sys.path.insert(0, ROOT)
 from street_gaussians_amd import synthetic as syn  # noqa: E402
 from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer  # noqa: E402
 
+from street_gaussians_amd import _C as native_c  # noqa: E402
+
+# the mode bench.py's headline runs in (bench.py --mode): strict = parity arithmetic on the reference's tile rects
+MODE = os.environ.get("SGR_PMC_MODE", "strict")
+native_c.test_switches((native_c.test_switches(-1) & ~(native_c.EXACT | native_c.REF_RECT)) |
+                       {"strict": native_c.EXACT | native_c.REF_RECT, "exact": native_c.EXACT, "fast": 0}[MODE])
 dev = torch.device("cuda")
 # calibration: 1 GiB float4-wide device copy (reads 2^30 B, writes 2^30 B) -- scale past the 256 MiB Infinity Cache
 a = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()

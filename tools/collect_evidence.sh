@@ -1,11 +1,11 @@
 #!/bin/bash
 # Copies what tools/gpu_evidence.sh <tag> left under gpurun_out/ev_<tag>/ into profiles/ (tracked): run here after gpurun.
-# usage: bash tools/collect_evidence.sh <tag> [round-dir, default r5]
+# usage: bash tools/collect_evidence.sh <tag> [round-dir, default r6]
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 E=$R/gpurun_out/ev_$1
-D=$R/profiles/${2:-r5}
-N=${2:-r5}
+D=$R/profiles/${2:-r6}
+N=${2:-r6}
 mkdir -p $D
 cp $E/pmc_blend_bwd.json $R/profiles/pmc_blend_bwd.json
 cp $E/pmc_blend_bwd.json $D/pmc_blend_bwd.json

@@ -4,7 +4,7 @@
 # Everything lands in gpurun_out/ev_<tag>/; tools/pmc_summary.py turns the PMC passes into profiles/pmc_blend_bwd.json
 # (stamped with the kernel-source hash bench.py checks).  Copy what is cited into profiles/<round>/.
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r5}
+TAG=${1:-r6}
 E=$R/gpurun_out/ev_$TAG
 mkdir -p $E
 rm -f $R/gpurun_out/parity_measured.jsonl $R/gpurun_out/fullsize_parity.json $R/gpurun_out/threeway_fullsize.json

@@ -18,7 +18,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from street_gaussians_amd import build as sgr_build  # noqa: E402
 
-KERNEL = "sgr_blend_bwd_kernel"
+# which blend backward the workload ran: the parity-mode kernel in the strict / exact modes (bench.py --mode), the S = 0 default
+# instantiation in the fast mode
+MODE = os.environ.get("SGR_PMC_MODE", "strict")
+KERNEL = "sgr_blend_bwd_kernel_exact" if MODE in ("strict", "exact") else "sgr_blend_bwd_kernel_s0"
 
 
 def per_kernel_means(path):
@@ -62,14 +65,8 @@ def derive(res):
         if dur:
             d["effective_clock_ghz"] = round(cyc / dur, 3)
         if res.get("sq_insts_valu"):
-            trans = res.get("sq_insts_valu_trans_f32", 0.0)
-            # issue slots at NOMINAL instruction costs: 2 cycles per wave64 VALU instruction, 8 for the quarter-rate
-            # transcendentals.  A LOWER bound of the pipe occupancy: measured in cycles on MI355X
-            # (tools/ubench/valu_rates2.hip) a plain f32 op takes 2.2-2.4, a DPP add 4.2, v_permlane32/16_swap 8.1 -- the
-            # counters do not separate those classes, tools/valu_model.py does from the ISA (profiles/r5/valu_model.json)
-            d["valu_issue_slot_frac_at_nominal_costs"] = round((2.0 * (res["sq_insts_valu"] - trans) + 8.0 * trans) / 1024.0 / cyc, 3)
             try:
-                vm = json.load(open(os.path.join(ROOT, "profiles", "r5", "valu_model.json")))["default"]
+                vm = json.load(open(os.path.join(ROOT, "profiles", "r6", "valu_model.json")))["parity_mode" if MODE in ("strict", "exact") else "default"]
                 if vm.get("source_sha16") == res.get("source_sha16"):
                     d["valu_pipe_cycles_per_visit_model"] = vm["valu_pipe_cycles_per_visit"]
             except (OSError, KeyError, ValueError):
@@ -92,7 +89,7 @@ def derive(res):
 def main():
     ev = sys.argv[1]
     out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "pmc_blend_bwd.json")
-    res = {"gaussians": int(os.environ.get("SGR_BENCH_P", "1000000")), "width": 1920, "height": 1280,
+    res = {"gaussians": int(os.environ.get("SGR_BENCH_P", "1000000")), "width": 1920, "height": 1280, "mode": MODE, "semantics": 0,
            "source_sha16": sgr_build.source_sha16(), "fetch_correction": 2.0,
            "source": f"{ev}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / three SQ(+GRBM) groups, separate passes over "
                      "profiles/pmc_workload.py (tools/gpu_evidence.sh)"}

@@ -14,7 +14,7 @@ the k = 1 case, + k - 1 adds).  Costs are MEASURED IN CYCLES by tools/ubench/val
 launch time x the clock the waves read from s_memtime / wall_clock64, 8 waves per SIMD, >= 20 ms per launch).  The mix of
 the paths is the replay's histogram of hitting lanes per visit (tools/lane_hist.py -> profiles/r5/lane_hist_1M.json).
 
-    python tools/valu_model.py   ->  profiles/r5/valu_model.json   (what bench.py reports as roofline.valu_issue)
+    python tools/valu_model.py   ->  profiles/r6/valu_model.json   (what bench.py reports as roofline.valu_issue)
 """
 import collections
 import json
@@ -29,7 +29,7 @@ from street_gaussians_amd import build as b  # noqa: E402
 
 RATES = os.path.join(ROOT, "profiles", "r5", "valu_rates2.jsonl")
 HIST = os.path.join(ROOT, "profiles", "r5", "lane_hist_1M.json")
-OUT = os.path.join(ROOT, "profiles", "r5", "valu_model.json")
+OUT = os.path.join(ROOT, "profiles", "r6", "valu_model.json")
 SPARSE_K = 9  # SGR_SPARSE_K of the shipped build
 
 
