@@ -299,3 +299,34 @@ def test_scene_graph_segments_keep_the_factored_exchange():
             assert red.nbytes == 4 * (segs[0].xyz.numel() + 3 + 3 * 9000 + 3 * 3000 + 2 * C)
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_line_names_its_mode_and_carries_the_contracts_objects():
+    """`bench.py --mode strict|exact|fast` (N = 1): `value` is the named mode's throughput, the other two ride along, and the
+    line carries the objects the contract asks for -- roofline {bound, achieved, peak, unit, frac, traffic} for the dominant
+    kernel of THAT mode and cpu_baseline {value, unit, cores, kind, sample}."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    for mode, kernel in (("strict", "sgr_blend_bwd_kernel_exact"), ("fast", "sgr_blend_bwd_kernel_s0")):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--device-warmup", "0",
+                              "--gaussians", "60000", "--no-other-configs", "--mode", mode],
+                             env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = json.loads([ln for ln in out.stdout.strip().split("\n") if ln.startswith("{")][-1])
+        assert line["mode"] == mode and line["conforming"] == (mode == "strict") and line["value"] > 0
+        assert line["value"] == line["value_" + mode] and line["ms_per_step"] == line["ms_per_step_" + mode]
+        for k in ("value_strict", "value_exact", "value_fast"):
+            assert line[k] and line[k] > 0, k
+        r = line["roofline"]
+        assert r["bound"] == "valu_issue" and kernel in r["kernel"] and r["unit"] == "GB/s" and r["peak"] == 8000.0
+        assert r["achieved"] > 0 and 0 < r["frac"] < 1 and "traffic" in r and r["mode"] == mode
+        cb = line["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["host"]["threads"] >= cb["cores"] and cb["sample"]
+        assert line["config"]["num_rendered_R"] >= line["config"]["instances_emitted"] > 0
+        if mode == "strict":
+            assert line["config"]["num_rendered_R"] == line["config"]["instances_emitted"]
+        assert line["summary"]["mode"] == mode and list(line)[-1] == "summary"
