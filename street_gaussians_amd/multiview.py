@@ -55,8 +55,9 @@ class GradReducer:
         self.direct = ref.is_cuda
         if self.direct and type(self)._register_sink:
             from . import rasterizer as _rast
+            import weakref
             self._rast_mod = _rast
-            _rast.BACKWARD_SINKS.append(self._sink)
+            _rast.BACKWARD_SINKS.append(weakref.WeakMethod(self._sink))
 
     _register_sink = True
     _GRAD_NAME = {"means3D": "means3D", "scales": "scales", "rotations": "rotations", "sh": "sh", "semantics": "semantics",
@@ -88,8 +89,8 @@ class GradReducer:
 
     def close(self) -> None:
         m = getattr(self, "_rast_mod", None)
-        if m is not None and self._sink in m.BACKWARD_SINKS:
-            m.BACKWARD_SINKS.remove(self._sink)
+        if m is not None:
+            m.remove_sink(self._sink)
 
     def _layout(self) -> None:
         """(Re)builds the flat bucket and its per-parameter views for ``self.params``.  The storage is kept when it is
@@ -286,7 +287,8 @@ class FactoredGradReducer:
         self._rast = _rast
         self._direct_slot = None
         _rast.BACKWARD_OBSERVERS.append(self._observe)
-        _rast.BACKWARD_SINKS.append(self._sink)
+        import weakref
+        _rast.BACKWARD_SINKS.append(weakref.WeakMethod(self._sink))
 
     def rebuild(self, dense_params: Iterable[torch.Tensor], shs=None, means3D: Optional[torch.Tensor] = None,
                 segments: Optional[Sequence[SHSegment]] = None) -> None:
@@ -624,8 +626,7 @@ class FactoredGradReducer:
     def close(self) -> None:
         if self._observe in self._rast.BACKWARD_OBSERVERS:
             self._rast.BACKWARD_OBSERVERS.remove(self._observe)
-        if self._sink in self._rast.BACKWARD_SINKS:
-            self._rast.BACKWARD_SINKS.remove(self._sink)
+        self._rast.remove_sink(self._sink)
         self.dense.close()
 
     def __enter__(self):

@@ -42,8 +42,31 @@ BACKWARD_OBSERVERS = []
 # callables invoked BEFORE the native backward with the call's input tensors; each may return a dict with
 #   "out": {gradient name: destination tensor}   (see _C.rasterize_gaussians_backward: e.g. views of an exchange bucket),
 #   "masked_color_out": [P, 3] destination of the clamp-masked colour gradient, "skip_sh_grad": True
-# (extension, not part of the reference API; empty unless a multiview reducer is alive)
+# (extension, not part of the reference API; empty unless a multiview reducer is alive).  Entries may be weakref.WeakMethod
+# objects (the reducers register themselves that way): a reducer that is dropped without close() does not stay alive -- with
+# its exchange buffers -- through this list; dead entries are pruned as they are met.
 BACKWARD_SINKS = []
+
+
+def _live_sinks():
+    import weakref
+    out = []
+    for s in list(BACKWARD_SINKS):
+        fn = s() if isinstance(s, weakref.WeakMethod) else s
+        if fn is None:
+            BACKWARD_SINKS.remove(s)
+        else:
+            out.append(fn)
+    return out
+
+
+def remove_sink(method) -> None:
+    """Removes `method` (or the weak reference to it) from BACKWARD_SINKS."""
+    import weakref
+    for s in list(BACKWARD_SINKS):
+        fn = s() if isinstance(s, weakref.WeakMethod) else s
+        if fn is None or fn == method:
+            BACKWARD_SINKS.remove(s)
 
 
 _COLOR_EVENTS = {}
@@ -125,10 +148,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         if BACKWARD_OBSERVERS and means3D.is_cuda:
             color_event = _color_event(means3D.device)
         kw = {}
-        if BACKWARD_SINKS and means3D.is_cuda:
+        if BACKWARD_SINKS and means3D.is_cuda:  # (weakly held reducers: see BACKWARD_SINKS)
             inputs = {"means3D": means3D, "scales": scales, "rotations": rotations, "sh": sh, "semantics": semantics,
                       "colors": colors_precomp, "cov3D": cov3Ds_precomp}
-            for sink in list(BACKWARD_SINKS):
+            for sink in _live_sinks():
                 d = sink(inputs=inputs, opacities_key=ctx.opacities_key, num_points=means3D.shape[0])
                 if d:
                     if d.get("out"):

@@ -183,7 +183,7 @@ def test_direct_bucket_writes_match_the_copying_exchange():
             with multiview.FactoredGradReducer(dense, t["shs"], t["means3D"], force=True) as red:
                 if label == "copying":
                     red.dense.direct = False
-                    rasterizer.BACKWARD_SINKS.remove(red._sink)
+                    rasterizer.remove_sink(red._sink)
                 for rnd in range(2):
                     for p in t.values():
                         p.grad = None
