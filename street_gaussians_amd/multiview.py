@@ -72,9 +72,12 @@ class GradReducer:
             return None
         by_ptr = {}
         off = 0
-        for p, n in zip(self.params, self._numel):
-            if p.grad is None and p.is_leaf and p.requires_grad:
-                by_ptr[p.data_ptr()] = (off, n, tuple(p.shape))
+        given = self.__dict__.setdefault("_direct_given", set())
+        for i, (p, n) in enumerate(zip(self.params, self._numel)):
+            # (a slice is handed out ONCE per exchange: two rasterizer calls over the same leaves in one autograd pass both
+            # run before either gradient has been installed -- the second one must take the ordinary route and be accumulated)
+            if p.grad is None and p.is_leaf and p.requires_grad and i not in given:
+                by_ptr[p.data_ptr()] = (off, n, tuple(p.shape), i)
             off += n
         out = {}
         cand = [(self._GRAD_NAME[k], t.data_ptr(), tuple(t.shape)) for k, t in inputs.items()
@@ -85,6 +88,8 @@ class GradReducer:
             hit = by_ptr.get(ptr)
             if hit is not None and hit[2] == shape:
                 out[name] = self.flat[hit[0]:hit[0] + hit[1]].view(shape)  # a FRESH view: autograd may adopt it as p.grad
+                given.add(hit[3])
+                by_ptr.pop(ptr)
         return {"out": out} if out else None
 
     def close(self) -> None:
@@ -158,6 +163,7 @@ class GradReducer:
             raise RuntimeError("begin() called twice without wait()")
         if self.world == 1 and not self.force:
             return
+        self.__dict__.setdefault("_direct_given", set()).clear()
         grads = [p.grad if p.grad is not None else torch.zeros_like(v) for p, v in zip(self.params, self._views)]
         # gradients the rasterizer backward wrote straight into the bucket (self._sink) are already in place
         todo = [(v, g) for v, g in zip(self._views, grads) if g.data_ptr() != v.data_ptr()]

@@ -330,3 +330,43 @@ def test_bench_line_names_its_mode_and_carries_the_contracts_objects():
         if mode == "strict":
             assert line["config"]["num_rendered_R"] == line["config"]["instances_emitted"]
         assert line["summary"]["mode"] == mode and list(line)[-1] == "summary"
+
+
+def test_two_views_in_one_autograd_pass_accumulate_correctly_with_direct_bucket_writes():
+    """loss = render(view 1) + render(view 2); ONE backward: both rasterizer backwards run before either gradient has been
+    installed, so only the first may write into the exchange bucket -- the second is accumulated the ordinary way.  The summed
+    gradients equal those of two separate backward passes without any reducer."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    cams = _views(2)
+    sc = syn.make_scene(20000, cams[0], S=0, seed=23)
+    names = ["means3D", "scales", "rotations", "opacities", "shs"]
+    ws = [{k: dev(v) for k, v in syn.loss_weights(c, seed=7 + i).items()} for i, c in enumerate(cams)]
+
+    def joint(t):
+        loss = 0.0
+        for cam, w in zip(cams, ws):
+            color, radii, depth, alpha, _ = GaussianRasterizer(settings(cam))(t["means3D"], None, t["opacities"], shs=t["shs"],
+                                                                              scales=t["scales"], rotations=t["rotations"])
+            loss = loss + (color * w["color"]).sum() + (depth * w["depth"]).sum() + (alpha * w["alpha"]).sum()
+        loss.backward()
+
+    t0 = {k: dev(getattr(sc, k)).requires_grad_(True) for k in names}
+    joint(t0)
+    want = {k: t0[k].grad.clone() for k in names}
+    port = socket.socket()
+    port.bind(("127.0.0.1", 0))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port.getsockname()[1])
+    port.close()
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        t = {k: dev(getattr(sc, k)).requires_grad_(True) for k in names}
+        red = multiview.GradReducer([t[k] for k in names], force=True)
+        try:
+            joint(t)
+            red.all_reduce()
+            for k in names:
+                assert torch.allclose(t[k].grad, want[k], rtol=0, atol=1e-6 * float(want[k].abs().max())), k
+        finally:
+            red.close()
+    finally:
+        dist.destroy_process_group()
