@@ -220,8 +220,21 @@ sgr_sort_scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ 
     __syncthreads();
     const uint32_t block = ONE ? lds4[0] : blockIdx.x;
 
+    // Wave 0 turns the digit counts into positions after the ranking (below).  What it needs from global memory for that --
+    // the digit totals and this block's row of the scanned [digit][block] table -- does not depend on the ranking: requested
+    // here, so that the two round trips overlap the key loads and the ballots (lane l owns bins [l * BPL, (l + 1) * BPL)).
+    constexpr int BPL = NB > 64 ? NB / 64 : 1;
+    uint32_t pre_before[BPL], pre_total[BPL];
+    if (!ONE && wave == 0) {
+#pragma unroll
+        for (int j = 0; j < BPL; j++) {
+            const int bin = lane * BPL + j;
+            pre_before[j] = bin < NB ? hist_scanned[(size_t)bin * nblocks + block] : 0u;
+            pre_total[j] = bin < NB ? totals[bin] : 0u;
+        }
+    }
+
     const uint32_t base = block * ITEMS + wave * (64 * IPT);
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
     K key[IPT];
     uint32_t val[IPT], rnk[IPT];
 #pragma unroll
@@ -230,27 +243,67 @@ sgr_sort_scatter_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ 
         const bool valid = i < n;
         key[s] = valid ? kin[i] : (K)0;
         val[s] = valid ? (vin ? vin[i] : i) : 0u;
+    }
+#pragma unroll
+    for (int s = 0; s < IPT; s++) {
+        const bool valid = base + s * 64 + lane < n;
         const uint32_t d = (uint32_t)(key[s] >> shift) & (uint32_t)(NB - 1);
-        uint64_t m = __ballot(valid);
+        // the lanes that share this lane's digit: per bit, keep the lanes whose bit equals mine -- m &= ballot XNOR (my bit
+        // spread over the word).  On 32-bit halves with v_bfe_i32 / v_xor / v_and: a `bit ? bal : ~bal` select compiles to
+        // v_cndmask on VCC, 23 cycles per wave instruction back to back on gfx950 (profiles/r5/valu_rates2.jsonl)
+        const uint64_t vm = __builtin_amdgcn_ballot_w64(valid);
+        uint32_t mlo = (uint32_t)vm, mhi = (uint32_t)(vm >> 32);
 #pragma unroll
         for (int b = 0; b < BITS; b++) {
-            const bool bit = (d >> b) & 1u;
-            const uint64_t bal = __ballot(valid && bit);
-            m &= bit ? bal : ~bal;
+            const int y = __builtin_amdgcn_sbfe((int)d, b, 1);  // 0 or -1
+            const uint64_t bal = __builtin_amdgcn_ballot_w64(y != 0);
+            mlo &= ~((uint32_t)bal ^ (uint32_t)y);
+            mhi &= ~((uint32_t)(bal >> 32) ^ (uint32_t)y);
         }
-        const uint32_t prefix = __popcll(m & lt_mask);
-        const uint32_t count = __popcll(m);
-        uint32_t prev = 0;
-        if (valid && prefix == 0) {  // lowest lane of each digit group: bump this wave's counter
-            prev = cnt[wave][d];
-            cnt[wave][d] = prev + count;
-        }
-        const int leader = m ? (__ffsll((unsigned long long)m) - 1) : lane;
-        prev = __shfl(prev, leader, 64);
+        const uint32_t prefix = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));  // set bits of m below this lane
+        // every lane of the group reads the wave's counter of the digit, its lowest lane moves it on by the group's size
+        const uint32_t prev = valid ? cnt[wave][d] : 0u;
+        __builtin_amdgcn_wave_barrier();
+        if (valid && prefix == 0) cnt[wave][d] = prev + (uint32_t)(__builtin_popcount(mlo) + __builtin_popcount(mhi));
         rnk[s] = prev + prefix;
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
+    if constexpr (!ONE) {
+        // counts -> positions, by wave 0 alone (two wave-level scans; the block-wide form cost four more barriers): for its
+        // BPL consecutive bins a lane sums the four waves' counts, the two exclusive scans run over the lanes' sums, and the
+        // bins of a lane are prefixed in order.  gbase = where this block's keys of the digit start in the output
+        // (keys of lower digits anywhere + keys of the digit in earlier blocks), lstart / cnt[w] = where they start in LDS.
+        if (wave == 0) {
+            uint32_t c[BPL][4], tot[BPL];
+            uint32_t sum_t = 0, sum_g = 0;
+#pragma unroll
+            for (int j = 0; j < BPL; j++) {
+                const int bin = lane * BPL + j;
+#pragma unroll
+                for (int w = 0; w < 4; w++) c[j][w] = bin < NB ? cnt[w][bin] : 0u;
+                tot[j] = c[j][0] + c[j][1] + c[j][2] + c[j][3];
+                sum_t += tot[j];
+                sum_g += pre_total[j];
+            }
+            uint32_t g = sgr_wave_incl_scan(sum_g, lane) - sum_g;
+            uint32_t ls = sgr_wave_incl_scan(sum_t, lane) - sum_t;
+#pragma unroll
+            for (int j = 0; j < BPL; j++) {
+                const int bin = lane * BPL + j;
+                if (bin < NB) {
+                    gbase[bin] = pre_before[j] + g;
+                    lstart[bin] = ls;
+                    cnt[0][bin] = ls;
+                    cnt[1][bin] = ls + c[j][0];
+                    cnt[2][bin] = ls + c[j][0] + c[j][1];
+                    cnt[3][bin] = ls + c[j][0] + c[j][1] + c[j][2];
+                }
+                g += pre_total[j];
+                ls += tot[j];
+            }
+        }
+    } else
     if constexpr (BPT == 1) {
         const bool bin = tid < NB;
         const uint32_t c0 = bin ? cnt[0][tid] : 0u, c1 = bin ? cnt[1][tid] : 0u, c2 = bin ? cnt[2][tid] : 0u,
