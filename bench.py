@@ -911,7 +911,7 @@ def main():
                     n_p = max(args.steps, int(0.6 / max(dt / args.steps, 1e-5)) + 1)  # the same kind of region as `sustained`
                     pdt, _ = profiled_steps(L, wl, fence, n_p, 0)
                 _, p_stage = profiled_steps(L, wl, fence, 16, 0x1FF)
-                m_R, m_V, _ = wl.counts()  # under the switch: what this mode emits
+                wl.counts()  # under the switch: what this mode emits (wl.R_emitted)
                 modes[label] = {"steps": n_p, "ms_per_step": round(1e3 * pdt / n_p, 4), "iters_per_s": round(n_p / pdt, 3),
                                 "instances_emitted": wl.R_emitted, "stages_ms": {k: (round(v, 4) if v is not None else None)
                                                                                  for k, v in p_stage.items()},
@@ -920,7 +920,6 @@ def main():
                 native_c.test_switches(base_switches | MODE_MASK[args.mode])
         for _ in range(3):
             wl.step()
-    parity_mode = modes.get("exact")
     # ---- the step without a host wait (sgr_set_lazy, opt-in: include/sgr.h) and the same step replayed from a hipGraph:
     # extra regions, never the reported value
     lazy_info = None
@@ -998,11 +997,10 @@ def main():
 
     if rank == 0:
         bwd_ms = timed["blend_bwd"]
-        algo_bytes, fwd_bytes = blend_bytes(S, R, N, V)
+        algo_bytes = blend_bytes(S, R, N, V)[0]
         T_tiles = ((args.width + 15) // 16) * ((args.height + 15) // 16)
         sb = stage_bytes(args.gaussians, wl.V_in, V, R, N, T_tiles, S)
         sb_emitted = stage_bytes(args.gaussians, wl.V_in, V, wl_R_emitted, N, T_tiles, S)
-        achieved = algo_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms else None
         fwd_ms = stage_ms["blend_fwd"]
         traffic, valu, traffic_note, pmc_derived = None, None, None, None
         tfile = os.path.join(ROOT, "profiles", "pmc_blend_bwd.json")
