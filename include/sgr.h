@@ -199,7 +199,11 @@ int sgr_profile_sample(int every);
  *           restricted to these rects
  *        17 u32[1]: what num_rendered is with the reference's rects (reporting)
  *        18 tile mask u64[P]: for rects of 2..64 tiles, bit j = tile (x0 + j % w, y0 + j / w) of the rect is emitted
- *           (inside the bounding box only the tiles the alpha >= 1/255 ellipse reaches); 0 = every tile of the rect  */
+ *           (inside the bounding box only the tiles the alpha >= 1/255 ellipse reaches); 0 = every tile of the rect
+ *        19 compact hit list u32[R]: per tile, from its range's start, the list positions (relative to the range,
+ *           ascending) of the instances whose hit record is non-zero -- what the blend backward walks; entries
+ *           behind a tile's count (= the largest value of 20 over its pixels, at least) are undefined
+ *        20 u32[H*W]: n_contrib counted in entries of 19 (a pixel's last contributor's index in its tile's list + 1) */
 int sgr_export_internal(int which, int P, int R, int width, int height, char* geom_buffer, char* binning_buffer,
                         char* image_buffer, void* dst, void* stream);
 
@@ -229,6 +233,11 @@ int sgr_export_internal(int which, int P, int R, int width, int height, char* ge
  * per forward looks at the list lengths and, when the longest list is more than 2.5 x the mean (a street scene: empty sky
  * next to actors), sorts the tile ids longest list first; an even scene keeps the XCD-aware supertile order.  Same results
  * either way.  bit 14 (SGR_LPT=1) always longest-first, bit 15 (SGR_NO_LPT=1) never (and no extra launch).
+ * bits 16 / 17: with the reference's rects (bit 10) the forward also writes the COMPACT list of the instances it blended
+ * somewhere (exports 19 / 20) and the blend backward walks that list instead of the list positions (the marked-dead 40 % and
+ * the instances behind saturated pixels are never staged); same gradients bit for bit.  bit 16 (SGR_NO_HLIST=1) never (the
+ * round-5 walk, A/B), bit 17 (SGR_HLIST_ALWAYS=1) in every mode (with the cut-down rects it costs the forward more than it
+ * saves the backward).  Set before a forward; its backward must see the same value.
  * bit 12 (SGR_TILE_SORT=1) the binning chain runs in its per-tile form (csrc/sgr_tile_sort.hip: no depth pre-sort of the
  * Gaussians, emission in index order, stable tile sort, then every tile's list radix-sorted by depth in LDS) -- the same
  * lists entry for entry (tests/test_gpu_tile_sort.py); A/B design, measured in DESIGN.md section 3.

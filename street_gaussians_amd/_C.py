@@ -363,7 +363,8 @@ _EXPORT = {"depths": (0, torch.float32, lambda P, R, N, T: (P,)), "clamped": (1,
            "extents": (14, torch.float32, lambda P, R, N, T: (P, 2)), "hits": (15, torch.uint8, lambda P, R, N, T: (R,)),
            "tile_rect": (16, torch.int32, lambda P, R, N, T: (P, 4)),
            "num_rendered_reference": (17, torch.int32, lambda P, R, N, T: (1,)),
-           "tile_mask": (18, torch.int64, lambda P, R, N, T: (P,))}
+           "tile_mask": (18, torch.int64, lambda P, R, N, T: (P,)),
+           "hit_list": (19, torch.int32, lambda P, R, N, T: (R,)), "n_contrib_k": (20, torch.int32, lambda P, R, N, T: (N,))}
 
 
 def masked_color_grad(geomBuffer, grad_colors, P):
@@ -430,6 +431,8 @@ def lazy_status():
 NO_TILE_MASK = 2048  # bounding-box rects without the per-tile mask (A/B)
 TILE_SORT = 4096  # binning chain A/B: index-order emission + per-tile LDS radix sort by depth (csrc/sgr_tile_sort.hip)
 LPT = 16384  # blend launches ALWAYS walk the tiles longest list first (default: decided per frame, longest list > 2.5 x the mean)
+NO_HLIST = 65536  # the blend backward steps through list POSITIONS instead of the forward's compact list of hit instances (A/B)
+HLIST_ALWAYS = 131072  # ... the compact list in every mode (default: with the reference's rects, REF_RECT, only)
 NO_LPT = 32768  # blend launches never do: the XCD-aware supertile order without looking at the lists (round-5 behaviour)
 REF_RECT_PLAIN = 8192  # with REF_RECT: the reference's rects WITHOUT the dead-instance marks (the round-5 form of the strict mode, A/B)
 REF_RECT = 1024  # emit every Gaussian for the reference's whole tile rect (default: cut down to where alpha >= 1/255 is possible)

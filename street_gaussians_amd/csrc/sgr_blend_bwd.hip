@@ -199,7 +199,8 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                      const uint32_t* __restrict__ n_contrib, const uint8_t* __restrict__ hit4,
                      const float* __restrict__ dL_dpixels, const float* __restrict__ dL_dpixel_depths,
                      const float* __restrict__ dL_dalphas, const float* __restrict__ dL_dpixel_semantics,
-                     float* __restrict__ partials, int row_stride, uint8_t* __restrict__ touched, uint32_t row_limit) {
+                     float* __restrict__ partials, int row_stride, uint8_t* __restrict__ touched, uint32_t row_limit,
+                     const uint32_t* __restrict__ hlist, const uint32_t* __restrict__ n_contrib_k) {
     // Every fused multiply-add below is written out (fmaf / __builtin_elementwise_fma): with contraction left to the
     // optimiser, the CULL / !CULL and DPP / shuffle instantiations of this body can fuse differently and the "culling
     // is invisible, bit for bit" property (tests) would depend on code-generation luck.
@@ -252,7 +253,16 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
     // backward.cu:466-500
     const float T_final = inside ? (1.0f - alphas[pix_id]) : 0.0f;
     float T = T_final;
-    const int lastc = inside ? (int)n_contrib[pix_id] : 0;
+    // COMPACT walk (round 6).  With the forward's hit record the kernel does not step through the list positions
+    // maxc - 1 ... 0 but through the forward's compact list of the instances that have a hit byte (SgrBinView::hlist,
+    // ascending positions): `hi` and the slots then count ENTRIES OF THAT LIST, and a pixel's `lastc` is its last contributor's
+    // index in that list + 1 (n_contrib_k, written by the forward next to n_contrib: entry e lies before the pixel's last
+    // contributor in the list iff its compact index is below that) -- the walk's arithmetic is unchanged.  A round stages 128
+    // instances that all have work: in the strict mode 40 % of a tile's list is marked dead, in every mode the instances
+    // behind saturated pixels and the cull's margin have no hit, so a tile takes fewer rounds (barriers, staging).
+    // Without a hit record (A/B switch bit 3) or without the list (bit 16) the walk is positional as before.
+    const bool HL = SGR_HLIST && CULL && hit4 != nullptr && hlist != nullptr;
+    const int lastc = inside ? (int)(HL ? n_contrib_k : n_contrib)[pix_id] : 0;
     float dLdC0 = 0.f, dLdC1 = 0.f, dLdC2 = 0.f, dLdD = 0.f, dLdA = 0.f;
     float dLdS[NS];
 #pragma unroll
@@ -318,12 +328,17 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
 #ifndef SGR_BWD_PREFETCH
 #define SGR_BWD_PREFETCH 1
 #endif
+    // list position of entry k of the walk (HL: through the compact list; maxc is then the largest compact count of a pixel)
+    auto entry = [&](const int k) __attribute__((always_inline)) -> uint32_t {
+        return HL ? hlist[range.x + (uint32_t)k] : (uint32_t)k;
+    };
     uint32_t g_pre = 0, h_pre = 0;
     if (SGR_BWD_PREFETCH) {
         const int pos0 = (tid < BATCH) ? (maxc - 1) - tid : -1;
         if (pos0 >= 0) {
-            g_pre = point_list[range.x + (uint32_t)pos0];
-            if (CULL && hit4 != nullptr) h_pre = hit4[range.x + (uint32_t)pos0];
+            const uint32_t lp = entry(pos0);
+            g_pre = point_list[range.x + lp];
+            if (CULL && hit4 != nullptr) h_pre = hit4[range.x + lp];
         }
     }
     for (int hi = maxc - 1; hi >= 0;) {
@@ -343,8 +358,8 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
         // An entry no quadrant has to visit is not staged at all -- no record gather, no row: with the forward's hit record
         // that is every instance the forward blended nowhere (hit byte 0), among them the ones the marked-list mode flags as
         // unable to blend (SGR_DEAD, bit 31 of the list entry: sgr_duplicate_kernel)
-        const uint32_t g_raw = pos >= 0 ? (SGR_BWD_PREFETCH ? g_pre : point_list[range.x + (uint32_t)pos]) : SGR_DEAD;
-        const uint32_t h_raw = (pos >= 0 && CULL && hit4 != nullptr) ? (SGR_BWD_PREFETCH ? h_pre : (uint32_t)hit4[range.x + (uint32_t)pos]) : 0xFu;
+        const uint32_t g_raw = pos >= 0 ? (SGR_BWD_PREFETCH ? g_pre : point_list[range.x + entry(pos)]) : SGR_DEAD;
+        const uint32_t h_raw = (pos >= 0 && CULL && hit4 != nullptr) ? (SGR_BWD_PREFETCH ? h_pre : (uint32_t)hit4[range.x + entry(pos)]) : 0xFu;
         if (pos >= 0 && !(g_raw & SGR_DEAD) && h_raw != 0u) {
             const uint32_t g = g_raw;
             const float4* r = rec + 4 * (size_t)g;  // one 64-byte line
@@ -374,8 +389,9 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
         if (SGR_BWD_PREFETCH) {  // next round's list entries: in flight under this round's walk
             const int posn = stager ? (hi - BATCH) - tid : -1;
             if (posn >= 0) {
-                g_pre = point_list[range.x + (uint32_t)posn];
-                if (CULL && hit4 != nullptr) h_pre = hit4[range.x + (uint32_t)posn];
+                const uint32_t lp = entry(posn);
+                g_pre = point_list[range.x + lp];
+                if (CULL && hit4 != nullptr) h_pre = hit4[range.x + lp];
             }
         }
         if (stager) {
@@ -782,8 +798,9 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
         if (SGR_BWD_PREFETCH && lim != BATCH) {  // rare: the entries fetched ahead were those of hi - BATCH
             const int posn = stager ? hi - tid : -1;
             if (posn >= 0) {
-                g_pre = point_list[range.x + (uint32_t)posn];
-                if (CULL && hit4 != nullptr) h_pre = hit4[range.x + (uint32_t)posn];
+                const uint32_t lp = entry(posn);
+                g_pre = point_list[range.x + lp];
+                if (CULL && hit4 != nullptr) h_pre = hit4[range.x + lp];
             }
         }
     }
@@ -797,10 +814,11 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
         const float *__restrict__ dL_dpixels, const float *__restrict__ dL_dpixel_depths,                                  \
         const float *__restrict__ dL_dalphas,                                                                              \
         const float *__restrict__ dL_dpixel_semantics, float *__restrict__ partials, int row_stride,                      \
-        uint8_t *__restrict__ touched, uint32_t row_limit
+        uint8_t *__restrict__ touched, uint32_t row_limit, const uint32_t *__restrict__ hlist,  \
+        const uint32_t *__restrict__ n_contrib_k
 #define SGR_BWD_PASS                                                                                                  \
     ranges, point_list, W, H, S, gx, gy, bg_color, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpixels,               \
-        dL_dpixel_depths, dL_dalphas, dL_dpixel_semantics, partials, row_stride, touched, row_limit
+        dL_dpixel_depths, dL_dalphas, dL_dpixel_semantics, partials, row_stride, touched, row_limit, hlist, n_contrib_k
 template <int SMAX, bool CULL, bool DPP, bool DET>
 __global__ void __launch_bounds__(SGR_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(SGR_BWD_WAVES(SMAX))))
 sgr_blend_bwd_kernel(SGR_BWD_ARGS) {
@@ -1097,12 +1115,13 @@ static void launch_bwd(bool cull, bool dpp, bool det, bool v2, bool exact, unsig
                        int W, int H, int S, int gx, int gy, const float* bg, const float4* rec, const uint32_t* u0, const uint64_t* tmask, const float* semantics,
                        const float* alphas,
                        const uint32_t* n_contrib, const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth,
-                       const float* dL_dalpha, const float* dL_dsem, float* partials, int row_stride, uint8_t* touched, uint32_t row_limit) {
+                       const float* dL_dalpha, const float* dL_dsem, float* partials, int row_stride, uint8_t* touched, uint32_t row_limit,
+                       const uint32_t* hlist, const uint32_t* n_contrib_k) {
     constexpr bool kDet = true;  // every instantiation has the two-row deterministic combine (see SgrBwdBatch)
     if (exact) {
         sgr_blend_bwd_kernel_exact<SMAX><<<tiles, SGR_TILE_THREADS, 0, s>>>(
             ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth, dL_dalpha,
-            dL_dsem, partials, row_stride, touched, row_limit);
+            dL_dsem, partials, row_stride, touched, row_limit, hlist, n_contrib_k);
         return;
     }
 #if SGR_WITH_VARIANTS
@@ -1110,7 +1129,7 @@ static void launch_bwd(bool cull, bool dpp, bool det, bool v2, bool exact, unsig
         if (v2 && dpp) {  // transposed accumulation (S = 0)
 #define SGR_V2(C, D) sgr_blend_bwd_kernel_v2<C, D><<<tiles, SGR_TILE_THREADS, 0, s>>>(                                    \
             ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,         \
-            dL_dalpha, dL_dsem, partials, row_stride, touched, row_limit)
+            dL_dalpha, dL_dsem, partials, row_stride, touched, row_limit, hlist, n_contrib_k)
             if (cull) { if (det) SGR_V2(true, true); else SGR_V2(true, false); }
             else { if (det) SGR_V2(false, true); else SGR_V2(false, false); }
 #undef SGR_V2
@@ -1127,19 +1146,19 @@ static void launch_bwd(bool cull, bool dpp, bool det, bool v2, bool exact, unsig
             if (det)                                                                                                 \
                 sgr_blend_bwd_kernel_s0<C, D, true><<<tiles, SGR_TILE_THREADS, 0, s>>>(                               \
                     ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,    \
-                    dL_dalpha, dL_dsem, partials, row_stride, touched, row_limit);                                               \
+                    dL_dalpha, dL_dsem, partials, row_stride, touched, row_limit, hlist, n_contrib_k);                                               \
             else                                                                                                     \
                 sgr_blend_bwd_kernel_s0<C, D, false><<<tiles, SGR_TILE_THREADS, 0, s>>>(                              \
                     ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,    \
-                    dL_dalpha, dL_dsem, partials, row_stride, touched, row_limit);                                               \
+                    dL_dalpha, dL_dsem, partials, row_stride, touched, row_limit, hlist, n_contrib_k);                                               \
         } else if (kDet && det)                                                                                      \
             sgr_blend_bwd_kernel<SMAX, C, D, kDet><<<tiles, SGR_TILE_THREADS, 0, s>>>(                                \
                 ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,        \
-                dL_dalpha, dL_dsem, partials, row_stride, touched, row_limit);                                                   \
+                dL_dalpha, dL_dsem, partials, row_stride, touched, row_limit, hlist, n_contrib_k);                                                   \
         else                                                                                                         \
             sgr_blend_bwd_kernel<SMAX, C, D, false><<<tiles, SGR_TILE_THREADS, 0, s>>>(                               \
                 ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,        \
-                dL_dalpha, dL_dsem, partials, row_stride, touched, row_limit);                                                   \
+                dL_dalpha, dL_dsem, partials, row_stride, touched, row_limit, hlist, n_contrib_k);                                                   \
     } while (0)
     if (cull && dpp) SGR_GO(true, true);
     else if constexpr (SMAX <= 4) {
@@ -1161,12 +1180,13 @@ int sgr_partial_row_stride(int S) {
 void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, bool v2, bool exact, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W,
                           int H, int S, const float* bg, const float4* rec, const uint32_t* u0, const uint64_t* tmask, const float* semantics, const float* alphas, const uint32_t* n_contrib,
                           const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha,
-                          const float* dL_dsem, float* partials, uint8_t* touched, uint32_t row_limit, hipStream_t s) {
+                          const float* dL_dsem, float* partials, uint8_t* touched, uint32_t row_limit, const uint32_t* hlist,
+                          const uint32_t* n_contrib_k, hipStream_t s) {
     if (gx <= 0 || gy == 0) return;
     const unsigned tiles = sgr_xcd_grid_blocks(gx, gy < 0 ? -gy : gy);  // supertile-ordered grid incl. padding blocks
     const int stride = sgr_partial_row_stride(S);
 #define SGR_BWD(N) launch_bwd<N>(cull, dpp, det, v2, exact, tiles, s, ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, \
-                                 n_contrib, hit4, dL_dpix, dL_ddepth, dL_dalpha, dL_dsem, partials, stride, touched, row_limit)
+                                 n_contrib, hit4, dL_dpix, dL_ddepth, dL_dalpha, dL_dsem, partials, stride, touched, row_limit, hlist, n_contrib_k)
     if (S == 0) SGR_BWD(0);
     else if (S <= 4) SGR_BWD(4);
     else if (S <= 8) SGR_BWD(8);

@@ -43,7 +43,7 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                      int gx, int gy, const float4* __restrict__ rec, const float* __restrict__ semantics,
                      const float* __restrict__ bg_color, float* __restrict__ out_color, float* __restrict__ out_depth,
                      float* __restrict__ out_alpha, float* __restrict__ out_semantic, uint32_t* __restrict__ n_contrib,
-                     uint8_t* __restrict__ hit4) {
+                     uint8_t* __restrict__ hit4, uint32_t* __restrict__ hlist, uint32_t* __restrict__ n_contrib_k) {
     // fused multiply-adds are written out (fmaf): the CULL / !CULL instantiations must produce bit-identical images
 #pragma clang fp contract(off)
     __shared__ float4 sA[SGR_TILE_THREADS];  // {x, y, -, -}
@@ -54,6 +54,8 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
     // [quadrant][chunk]: the instances of the current batch that were blended into >= 1 pixel of the quadrant.  They go
     // to hit4[] (one byte per sorted instance, bit q = quadrant q); the backward kernel walks exactly those.
     __shared__ uint64_t sHit[4][4];
+    __shared__ __attribute__((aligned(16))) uint64_t sAny[2][4];  // [batch parity][chunk]: OR of the four waves' masks (LDS atomics)
+    __shared__ uint32_t sCnt[SGR_TILE_THREADS];  // per slot of the batch store_hits last saw: its index in the compact hit list + 1
     __shared__ __attribute__((aligned(16))) float sSem[SMAX > 0 ? SGR_TILE_THREADS * SMAX : 4];  // zero-padded to SMAX
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -81,24 +83,58 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
     // quadrant bounds (pixel centres) used by the staging lanes for the cull test
     const float tx0 = (float)(tx * SGR_BLOCK_X), ty0 = (float)(ty * SGR_BLOCK_Y);
 
-    // one byte per instance of the batch that starts at list index b0 (after the barrier that follows its walk)
-    auto store_hits = [&](const uint32_t b0) __attribute__((always_inline)) {
+    // One byte per instance of the batch that starts at list index b0 (after the barrier that follows its walk) ... and the
+    // COMPACT list of the instances that have a hit byte at all (SgrBinView::hlist: positions relative to the tile's range,
+    // ascending): what the backward walks.  A thread's slot is (chunk = its wave, bit = its lane), so its place in the list =
+    // hit instances of earlier batches (`nhit`, scalar) + of earlier chunks of this batch + of lower lanes of its own
+    // (v_mbcnt on the OR of the four waves' masks).  The same number + 1 goes to sCnt[slot]: each thread also owns a PIXEL,
+    // and once the counts of the batch that holds the pixel's last contributor are in LDS (behind the next barrier) it
+    // converts its n_contrib (`last`, a list position + 1) into the same counting -- `lastk` = index of the last contributor
+    // in the compact list + 1 (that instance has a hit bit: its wave blended it) -- so that the backward's per-pixel test
+    // "this instance lies before my last contributor" works on compact indices.  The masks are wave-uniform: they are moved to
+    // scalar registers (v_readfirstlane) and counted there; per lane it is four selects, two v_mbcnt and the stores.
+    const bool hl = SGR_HLIST && hit4 != nullptr && hlist != nullptr;  // kernel argument: uniform
+    uint32_t nhit = 0, lastk = 0, jl_wait = ~0u;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    auto store_hits = [&](const uint32_t b0, const int par) __attribute__((always_inline)) {
+        if (hit4 == nullptr) return;
         const uint32_t idx = b0 + (uint32_t)tid;
-        if (hit4 != nullptr && idx < range.y) {
-            const int c = tid >> 6, b = tid & 63;
-            const uint32_t h = (uint32_t)((sHit[0][c] >> b) & 1ull) | ((uint32_t)((sHit[1][c] >> b) & 1ull) << 1) |
-                               ((uint32_t)((sHit[2][c] >> b) & 1ull) << 2) | ((uint32_t)((sHit[3][c] >> b) & 1ull) << 3);
-            hit4[idx] = (uint8_t)h;
+        // the four waves' masks of this wave's chunk, in scalar registers: a lane's bit of each is one select on the mask
+        const uint64_t m0 = sgr_uniform_u64(sHit[0][wave_s]), m1 = sgr_uniform_u64(sHit[1][wave_s]);
+        const uint64_t m2 = sgr_uniform_u64(sHit[2][wave_s]), m3 = sgr_uniform_u64(sHit[3][wave_s]);
+        const uint32_t h = __float_as_uint(sgr_sel_mask(m0, __uint_as_float(1u), 0.0f)) | __float_as_uint(sgr_sel_mask(m1, __uint_as_float(2u), 0.0f)) |
+                           __float_as_uint(sgr_sel_mask(m2, __uint_as_float(4u), 0.0f)) | __float_as_uint(sgr_sel_mask(m3, __uint_as_float(8u), 0.0f));
+        if (idx < range.y) hit4[idx] = (uint8_t)h;
+        if (hl) {
+            const uint64_t mine = m0 | m1 | m2 | m3;
+            uint32_t before = 0, total = 0;  // scalar
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) {
+                const uint32_t pc = (uint32_t)__builtin_popcountll(sgr_uniform_u64(sAny[par][cc]));
+                before += cc < wave_s ? pc : 0u;
+                total += pc;
+            }
+            const uint32_t k = nhit + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+            if (h) hlist[range.x + k] = idx - range.x;
+            sCnt[tid] = k + 1u;
+            jl_wait = last - 1u - (b0 - range.x);  // slot of this pixel's last contributor, if it lies in this batch (< 256)
+            nhit += total;
         }
+    };
+    // ... behind a barrier after store_hits
+    auto take_lastk = [&]() __attribute__((always_inline)) {
+        if (jl_wait < (uint32_t)SGR_TILE_THREADS) lastk = sCnt[jl_wait];
+        jl_wait = ~0u;
     };
     bool pending = false;
     uint32_t pbase = 0;
-    for (uint32_t base = range.x; base < range.y; base += SGR_TILE_THREADS) {
+    int par = 0;  // parity of the batch being walked: its sAny[] half (the other half is being read by store_hits)
+    for (uint32_t base = range.x; base < range.y; base += SGR_TILE_THREADS, par ^= 1) {
         // tile-wide early exit (forward.cu:394-396); also the barrier that protects LDS reuse
         // (each wave posts "all my pixels are finished"; hipcc's __syncthreads_and is a 20-instruction DPP reduction)
         if (lane == 0) sDone[wave] = (done_mask == ~0ull) ? 1u : 0u;
         __syncthreads();
-        if (pending) store_hits(pbase);  // hit masks of the previous batch (complete: every wave is past its walk)
+        if (pending) store_hits(pbase, par ^ 1);  // hit masks of the previous batch (complete: every wave is past its walk)
         pending = false;
         if (sDone[0] & sDone[1] & sDone[2] & sDone[3]) break;
 
@@ -127,7 +163,9 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
             const uint64_t m = __ballot((mask4 >> q) & 1u);
             if (lane == 0) sBits[q][wave] = m;
         }
+        if (hl && tid < 4) sAny[par][tid] = 0ull;  // last read one batch ago, two barriers back
         __syncthreads();
+        if (hl) take_lastk();
         // this wave's hit masks of the new batch start empty (the reads of the previous batch's are behind the barrier)
         if (lane < 4) sHit[wave][lane] = 0ull;
         pending = true;
@@ -248,19 +286,27 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
                     blend_one(j0, b0, pw0, al0);
                     blend_one(j1, b1, pw1, al1);  // if the wave finished on j0 every lane's threshold is +inf: a no-op
                 }
-                if (lane == 0) sHit[wave][chunk] = hb;
+                if (lane == 0) {
+                    sHit[wave][chunk] = hb;
+                    if (hl && hb) __hip_atomic_fetch_or(&sAny[par][chunk], hb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         }
     }
     if (pending) {  // the list ended before the tile was finished: the last batch's hit masks are still in LDS
         __syncthreads();
-        store_hits(pbase);
+        store_hits(pbase, par ^ 1);
+    }
+    if (hl) {  // the counts store_hits left last (uniform branch)
+        __syncthreads();
+        take_lastk();
     }
 
     if (inside) {
         const size_t pix_id = (size_t)W * py + px;
         const size_t plane = (size_t)H * W;
         n_contrib[pix_id] = last;
+        if (hl) n_contrib_k[pix_id] = lastk;
         out_color[pix_id] = C0 + T * bg_color[0];
         out_color[plane + pix_id] = C1 + T * bg_color[1];
         out_color[2 * plane + pix_id] = C2 + T * bg_color[2];
@@ -277,11 +323,11 @@ sgr_blend_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
 template <int SMAX>
 static void launch_fwd(bool cull, bool exact, unsigned tiles, hipStream_t s, const uint2* ranges, const uint32_t* point_list, int W,
                        int H, int S, int gx, int gy, const float4* rec, const float* semantics, const float* bg, float* out_color, float* out_depth, float* out_alpha,
-                       float* out_semantic, uint32_t* n_contrib, uint8_t* hit4) {
+                       float* out_semantic, uint32_t* n_contrib, uint8_t* hit4, uint32_t* hlist, uint32_t* n_contrib_k) {
 #define SGR_FWD_GO(C, E)                                                                                              \
     sgr_blend_fwd_kernel<SMAX, C, E><<<tiles, SGR_TILE_THREADS, 0, s>>>(ranges, point_list, W, H, S, gx, gy, rec, semantics, \
                                                                         bg, out_color, out_depth, out_alpha, out_semantic,   \
-                                                                        n_contrib, hit4)
+                                                                        n_contrib, hit4, hlist, n_contrib_k)
     if (exact) SGR_FWD_GO(true, true);  // parity mode: with the cull (it is invisible in the results)
     else if (cull) SGR_FWD_GO(true, false);
     else SGR_FWD_GO(false, false);
@@ -292,11 +338,11 @@ static void launch_fwd(bool cull, bool exact, unsigned tiles, hipStream_t s, con
 void sgr_launch_blend_fwd(bool cull, bool exact, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W, int H,
                           int S, const float4* rec, const float* semantics,
                           const float* bg, float* out_color, float* out_depth, float* out_alpha, float* out_semantic,
-                          uint32_t* n_contrib, uint8_t* hit4, hipStream_t s) {
+                          uint32_t* n_contrib, uint8_t* hit4, uint32_t* hlist, uint32_t* n_contrib_k, hipStream_t s) {
     if (gx <= 0 || gy == 0) return;
     const unsigned tiles = sgr_xcd_grid_blocks(gx, gy < 0 ? -gy : gy);  // supertile-ordered grid incl. padding blocks
 #define SGR_FWD(N) launch_fwd<N>(cull, exact, tiles, s, ranges, point_list, W, H, S, gx, gy, rec, semantics, bg, \
-                                 out_color, out_depth, out_alpha, out_semantic, n_contrib, hit4)
+                                 out_color, out_depth, out_alpha, out_semantic, n_contrib, hit4, hlist, n_contrib_k)
     if (S == 0) SGR_FWD(0);
     else if (S <= 4) SGR_FWD(4);
     else if (S <= 8) SGR_FWD(8);

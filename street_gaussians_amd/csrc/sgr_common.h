@@ -68,6 +68,12 @@ struct SgrGeomView {
     uint32_t* header;     // [6]=tile-rect mode of the frame (0 reference rects, 1 bounding box, 2 box + mask, 3 marked list), [0]=error flag, [2]=depth beyond the 27-bit sort keys, [4]=num_rendered, [5]=num_rendered with the reference rects (one u64 counter), [16..]=SgrCam
 };
 
+// 1: the forward writes the compact hit list (SgrBinView::hlist, SgrImgView::n_contrib_k) and the blend backward walks it.
+// 0 compiles it out of both kernels (tools/build_variant.py nohlist -DSGR_HLIST=0: what the list costs the forward, A/B).
+#ifndef SGR_HLIST
+#define SGR_HLIST 1
+#endif
+
 struct SgrBinView {
     uint32_t* keys[2];   // tile id per instance (the depth order is already in the emission order)
     uint32_t* vals[2];
@@ -76,6 +82,10 @@ struct SgrBinView {
     uint32_t* header;    // [0]=index (0/1) of the buffer pair holding the sorted result
     uint8_t* hit4;       // per sorted instance: bit q = the forward blended it into >= 1 pixel of quadrant q of its tile
     uint8_t* touched;    // per partial-gradient row: written by the backward (cleared by the forward's tile-ranges launch)
+    uint32_t* hlist;     // per tile (at its range's start): the list positions, relative to the range, of the instances the forward
+                         // blended into at least one quadrant, ascending -- the COMPACT list the blend backward walks (it has
+                         // nothing to do for the others: dead instances of the marked-list mode, instances behind a saturated
+                         // pixel block, culled ones); a pixel's last contributor's index in it + 1 is SgrImgView::n_contrib_k
     uint32_t* tkeys;     // per-tile LDS sort (sgr_tile_sort.hip, switch bit 12): depth-key scratch of the lists too long for LDS
 };
 
@@ -96,6 +106,7 @@ struct SgrStatSink {
 struct SgrImgView {
     uint32_t* n_contrib;
     uint2* ranges;
+    uint32_t* n_contrib_k;  // per pixel: n_contrib counted in entries of SgrBinView::hlist (last contributor's index in it + 1)
 };
 
 static inline size_t sgr_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -170,6 +181,7 @@ static inline SgrBinView sgr_bin_carve(char* base, size_t R, char** end = nullpt
     sgr_carve(p, v.hit4, Rn);
     sgr_carve(p, v.touched, Rn);
     sgr_carve(p, v.tkeys, Rn);
+    sgr_carve(p, v.hlist, Rn);
     if (end) *end = p;
     return v;
 }
@@ -179,6 +191,7 @@ static inline SgrImgView sgr_img_carve(char* base, size_t N, size_t T, char** en
     char* p = base;
     sgr_carve(p, v.n_contrib, N ? N : 1);
     sgr_carve(p, v.ranges, (T ? T : 1) + ((T ? T : 1) + 2) / 2);  // + T + 1 words behind the ranges: the tile-order block (sgr_wg_tile)
+    sgr_carve(p, v.n_contrib_k, N ? N : 1);
     if (end) *end = p;
     return v;
 }
