@@ -125,3 +125,81 @@ void replay_lane_hist(int W, int H, const uint32_t* ranges, const uint32_t* plis
   }
   for (int i = 0; i < 65; ++i) hist[i] = acc[i];
 }
+
+// What a ROW-GRANULAR backward walk would cost: every 16-lane row of a quadrant's wave owns a block of
+// pixels (shape 0: 4x4, shape 1: 8x2 strips) and walks only the instances that hit ITS block.  Rounds of `round_n` entries of
+// the tile's list that have at least one hit (the compact hit list).  out[0] = quadrant visits (today's walk: one step each),
+// out[1] = block visits, out[2] = steps of the row walk (per round and wave: the busiest row's visits),
+// out[3] = sum over rounds of the busiest WAVE's steps x 4 today, out[4] = the same for the row walk (barrier skew included).
+void replay_row_walk(int W, int H, const uint32_t* ranges, const uint32_t* plist, const float* m2d, const float* co,
+                     const uint32_t* ncontrib, int shape, int round_n, double* out) {
+  int gx = (W + 15) / 16, gy = (H + 15) / 16;
+  double acc[5] = {0};
+#pragma omp parallel
+  {
+    double a[5] = {0};
+#pragma omp for schedule(dynamic, 8)
+    for (int t = 0; t < gx * gy; ++t) {
+      uint32_t r0 = ranges[2 * t], r1 = ranges[2 * t + 1];
+      if (r1 <= r0) continue;
+      int tx = t % gx, ty = t / gx;
+      uint32_t nc[256]; uint32_t maxc = 0;
+      for (int p = 0; p < 256; ++p) {
+        int px = tx * 16 + (p & 15), py = ty * 16 + (p >> 4);
+        nc[p] = (px < W && py < H) ? ncontrib[py * W + px] : 0;
+        if (nc[p] > maxc) maxc = nc[p];
+      }
+      int in_round = 0;
+      int vis_w[4] = {0, 0, 0, 0}, row_w[4][4] = {{0}};
+      // the backward walks back to front; the round structure is the same counted from either end up to the remainder
+      for (int64_t pos = (int64_t)maxc - 1; pos >= -1; --pos) {
+        int flush = pos < 0;
+        if (!flush) {
+          uint32_t g = plist[r0 + pos];
+          float X = m2d[2 * g], Y = m2d[2 * g + 1], A = co[4 * g], B = co[4 * g + 1], Cc = co[4 * g + 2], O = co[4 * g + 3];
+          int blk[4][4] = {{0}};
+          int any = 0;
+          for (int p = 0; p < 256; ++p) {
+            if ((uint32_t)pos >= nc[p]) continue;
+            int lx = p & 15, ly = p >> 4;
+            float dx = X - (float)(tx * 16 + lx), dy = Y - (float)(ty * 16 + ly);
+            float pw = -0.5f * (A * dx * dx + Cc * dy * dy) - B * dx * dy;
+            if (pw > 0.f) continue;
+            if (fminf(0.99f, O * expf(pw)) < 1.f / 255.f) continue;
+            int q = (ly >> 3) * 2 + (lx >> 3), qx = lx & 7, qy = ly & 7;
+            int r = shape == 0 ? (qy >> 2) * 2 + (qx >> 2) : (qy >> 1);
+            blk[q][r] = 1;
+            any = 1;
+          }
+          if (any) {
+            for (int q = 0; q < 4; ++q) {
+              int v = blk[q][0] | blk[q][1] | blk[q][2] | blk[q][3];
+              vis_w[q] += v;
+              for (int r = 0; r < 4; ++r) row_w[q][r] += blk[q][r];
+            }
+            in_round++;
+          }
+        }
+        if ((in_round == round_n || flush) && in_round > 0) {
+          int mx_vis = 0, mx_steps = 0;
+          for (int q = 0; q < 4; ++q) {
+            int st = 0;
+            for (int r = 0; r < 4; ++r) { a[1] += row_w[q][r]; if (row_w[q][r] > st) st = row_w[q][r]; }
+            a[0] += vis_w[q];
+            a[2] += st;
+            if (vis_w[q] > mx_vis) mx_vis = vis_w[q];
+            if (st > mx_steps) mx_steps = st;
+            vis_w[q] = 0;
+            for (int r = 0; r < 4; ++r) row_w[q][r] = 0;
+          }
+          a[3] += 4.0 * mx_vis;
+          a[4] += 4.0 * mx_steps;
+          in_round = 0;
+        }
+      }
+    }
+#pragma omp critical
+    for (int i = 0; i < 5; ++i) acc[i] += a[i];
+  }
+  for (int i = 0; i < 5; ++i) out[i] = acc[i];
+}
