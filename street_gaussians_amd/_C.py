@@ -432,6 +432,7 @@ NO_TILE_MASK = 2048  # bounding-box rects without the per-tile mask (A/B)
 TILE_SORT = 4096  # binning chain A/B: index-order emission + per-tile LDS radix sort by depth (csrc/sgr_tile_sort.hip)
 LPT = 16384  # blend launches ALWAYS walk the tiles longest list first (default: decided per frame, longest list > 2.5 x the mean)
 NO_HLIST = 65536  # the blend backward steps through list POSITIONS instead of the forward's compact list of hit instances (A/B)
+KEY32 = 262144  # 32-bit tile keys in the instance list (default: 16-bit whenever the frame has fewer than 65535 tiles; A/B)
 HLIST_ALWAYS = 131072  # ... the compact list in every mode (default: with the reference's rects, REF_RECT, only)
 NO_LPT = 32768  # blend launches never do: the XCD-aware supertile order without looking at the lists (round-5 behaviour)
 REF_RECT_PLAIN = 8192  # with REF_RECT: the reference's rects WITHOUT the dead-instance marks (the round-5 form of the strict mode, A/B)

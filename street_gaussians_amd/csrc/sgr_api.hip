@@ -24,11 +24,11 @@ void sgr_launch_preprocess(int P, int D, int M, const float* means3D, const floa
 void sgr_launch_filter(int P, const float* means3D, const float* scales, const float* rotations,
                        const float* cov3D_precomp, const SgrCamArgs& ca, const SgrGeomView& gv, int* radii,
                        float* means2D, int prefiltered, hipStream_t s);
-void sgr_launch_duplicate(int P, const SgrGeomView& gv, const uint32_t* order, const uint32_t* bsum, const uint32_t* sub, uint32_t* keys,
-                          uint32_t* vals, int gx, uint32_t cap, int marks, hipStream_t s);
-void sgr_launch_tile_ranges(int L, const uint32_t* keys, uint2* ranges, uint8_t* touched, uint32_t T, hipStream_t s);
+void sgr_launch_duplicate(int P, const SgrGeomView& gv, const uint32_t* order, const uint32_t* bsum, const uint32_t* sub, void* keys,
+                          int key16, uint32_t* vals, int gx, uint32_t cap, int marks, hipStream_t s);
+void sgr_launch_tile_ranges(int L, const void* keys, int key16, uint2* ranges, uint8_t* touched, uint32_t T, hipStream_t s);
 void sgr_launch_tile_order(const uint2* ranges, int T, int force, hipStream_t s);
-void sgr_launch_compose_keys(int L, const uint32_t* tile_keys, const uint32_t* point_list, const float4* rec, uint64_t* out,
+void sgr_launch_compose_keys(int L, const void* tile_keys, int key16, const uint32_t* point_list, const float4* rec, uint64_t* out,
                              hipStream_t s);
 void sgr_launch_blend_fwd(bool cull, bool exact, int gx, int gy, const uint2* ranges, const uint32_t* point_list, int W, int H,
                           int S, const float4* rec, const float* semantics, const float* bg, float* out_color,
@@ -98,7 +98,8 @@ static int switches() {
             (env_flag("SGR_EXACT") ? 128 : 0) | ((env_flag("SGR_SW8") || env_flag("SGR_SW")) ? 256 : 0) | ((env_flag("SGR_SW9") || env_flag("SGR_RS_WAVE")) ? 512 : 0) |
             (env_flag("SGR_REF_RECT") ? 1024 : 0) | (env_flag("SGR_NO_TILE_MASK") ? 2048 : 0) | (env_flag("SGR_TILE_SORT") ? 4096 : 0) |
             (env_flag("SGR_REF_RECT_PLAIN") ? 8192 : 0) | (env_flag("SGR_LPT") ? 16384 : 0) |
-            (env_flag("SGR_NO_LPT") ? 32768 : 0) | (env_flag("SGR_NO_HLIST") ? 65536 : 0) | (env_flag("SGR_HLIST_ALWAYS") ? 131072 : 0);
+            (env_flag("SGR_NO_LPT") ? 32768 : 0) | (env_flag("SGR_NO_HLIST") ? 65536 : 0) | (env_flag("SGR_HLIST_ALWAYS") ? 131072 : 0) |
+            (env_flag("SGR_KEY32") ? 262144 : 0);
         if (!SGR_WITH_VARIANTS) v &= ~SGR_VARIANT_BITS;
         g_switches.store(v, std::memory_order_relaxed);
     }
@@ -247,6 +248,10 @@ static bool hit_list_on() {
     const int sw = switches();
     return SGR_HLIST && !(sw & 65536) && ((sw & 1024) || (sw & 131072));
 }
+// The tile keys of the instance list are 16-bit whenever the frame has fewer than 65535 tiles (the all-ones key is the padding of
+// the lazy mode): the tile sort moves 6 instead of 8 bytes per pair and pass and its histogram reads half.  Bit 18 (SGR_KEY32=1)
+// keeps 32-bit keys (A/B; frames with more tiles -- beyond 4096 x 4080 pixels -- take them anyway).  Same buffers either way.
+static int tile_key16(size_t T) { return (T < 65535u && !(switches() & 262144)) ? 1 : 0; }
 static int pre_stage_min_p() {
     static const int v = [] { const char* e = getenv("SGR_PRE_STAGE_MIN_P"); return e ? atoi(e) : 3000000; }();
     return v;
@@ -630,18 +635,24 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
     prof_begin(2, stream);
     SgrGeomView gv_dup = gv;
     if (tile_sort) gv_dup.aux_sorted = const_cast<uint2*>(aux_emit);  // index-order emission: "depth order" is the identity
-    sgr_launch_duplicate(P, gv_dup, order, gv.scan_tmp, gv.sub_sums, bv.keys[0], bv.vals[0], gx, cap, rmode == 3 ? 1 : 0, stream);
+    const int key16 = tile_key16(T);
+    sgr_launch_duplicate(P, gv_dup, order, gv.scan_tmp, gv.sub_sums, bv.keys[0], key16, bv.vals[0], gx, cap, rmode == 3 ? 1 : 0, stream);
     SGR_STAGE("duplicate");
     prof_end(stream);
     if (R > 0) {
         prof_begin(3, stream);
         const int bit = (int)getHigherMsb((uint32_t)T);  // rasterizer_impl.cu:303
         // (lazy: over all `cap` slots; the padding's keys are all ones in every sorted bit and stay behind the instances)
-        cur = sgr_launch_sort_pairs32(bv.keys, bv.vals, (uint32_t)R, bit, bv.hist, bv.scan_tmp, stream);
+        if (key16) {
+            uint16_t* const k16[2] = {reinterpret_cast<uint16_t*>(bv.keys[0]), reinterpret_cast<uint16_t*>(bv.keys[1])};
+            cur = sgr_launch_sort_pairs16(k16, bv.vals, (uint32_t)R, bit, bv.hist, bv.scan_tmp, stream);
+        } else {
+            cur = sgr_launch_sort_pairs32(bv.keys, bv.vals, (uint32_t)R, bit, bv.hist, bv.scan_tmp, stream);
+        }
         SGR_STAGE("sort");
         prof_end(stream);
         prof_begin(4, stream);
-        sgr_launch_tile_ranges(R, bv.keys[cur], iv.ranges, bv.touched, lazy ? (uint32_t)T : 0xffffffffu, stream);
+        sgr_launch_tile_ranges(R, bv.keys[cur], key16, iv.ranges, bv.touched, lazy ? (uint32_t)T : 0xffffffffu, stream);
         SGR_STAGE("tile_ranges");
         if (tile_sort) {
             // every tile's list (ascending id so far) into (depth, id) order: a stable radix sort on the depth keys in LDS
@@ -1081,7 +1092,7 @@ int sgr_export_internal(int which, int P, int R, int width, int height, char* ge
             SGR_STAGE("export point_list");
         } else {
             const SgrGeomView gv = sgr_geom_carve(geom_buffer, (size_t)P);
-            sgr_launch_compose_keys(R, bv.keys[cur], bv.vals[lcur], gv.rec, (uint64_t*)dst, stream);
+            sgr_launch_compose_keys(R, bv.keys[cur], tile_key16(T), bv.vals[lcur], gv.rec, (uint64_t*)dst, stream);
             SGR_STAGE("export keys");
         }
         return 0;

@@ -240,6 +240,8 @@ int sgr_launch_sort_pairs32(uint32_t* const keys[2], uint32_t* const vals[2], ui
                             uint32_t* scan_tmp, hipStream_t s, bool iota = false, const uint2* aux_in = nullptr,
                             uint2* aux_out = nullptr, int max_bits = 8, int aux16 = 0);  // max_bits: digit width cap, 8 or 9;
                             // aux16: the aux records are 16 bytes (uint4) instead of 8
+int sgr_launch_sort_pairs16(uint16_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
+                            uint32_t* scan_tmp, hipStream_t s);
 int sgr_sort_pass_count(int end_bit);  // passes (= buffer flips) of a sort on key bits [0, end_bit)
 // per-tile LDS sort by depth (sgr_tile_sort.hip): vals_in (tile-major, ascending id inside a tile) -> vals_out in (depth, id) order
 void sgr_launch_tile_sort(int T, const uint2* ranges, uint32_t* vals_in, uint32_t* vals_out, const uint32_t* dkeys,

@@ -319,9 +319,11 @@ sgr_preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, co
 // (4 bytes / Gaussian written and read back, 8 more read) less per forward: scan + duplicate 0.045 -> 0.036 ms at 1 M
 // Gaussians, 0.16 -> 0.12 ms at 5 M.
 static_assert(SGR_PRE_THREADS == 256 && SGR_SCAN_ITEMS == 8 * SGR_PRE_THREADS, "one workgroup = one sub-block of the scan");
+// K = the tile keys' type: uint16_t whenever the frame has fewer than 65535 tiles (the sort's key traffic halves), else uint32_t
+template <typename K>
 __global__ void __launch_bounds__(SGR_PRE_THREADS)
 sgr_duplicate_kernel(int P, SgrGeomView gv, const uint32_t* __restrict__ order, const uint32_t* __restrict__ bsum,
-                     const uint32_t* __restrict__ sub, uint32_t nb, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                     const uint32_t* __restrict__ sub, uint32_t nb, K* __restrict__ keys, uint32_t* __restrict__ vals,
                      int gx, uint32_t cap, int marks) {
     // cap != 0 (the forward without a host wait, sgr_set_lazy): the list buffers hold `cap` slots whatever the frame's
     // instance count R turns out to be (bsum[nb], known to the device only) -- nothing is written past them, and the slots
@@ -329,7 +331,7 @@ sgr_duplicate_kernel(int P, SgrGeomView gv, const uint32_t* __restrict__ order, 
     if (cap != 0) {
         const uint32_t R = bsum[nb];
         for (uint32_t s = R + blockIdx.x * SGR_PRE_THREADS + threadIdx.x; s < cap; s += gridDim.x * SGR_PRE_THREADS) {
-            keys[s] = 0xffffffffu;
+            keys[s] = (K)~(K)0;
             vals[s] = 0u;
         }
     }
@@ -401,7 +403,7 @@ sgr_duplicate_kernel(int P, SgrGeomView gv, const uint32_t* __restrict__ order, 
         if (rem < 0) { q--; rem += (int)w; }
         if (rem >= (int)w) { q++; rem -= (int)w; }
         const uint32_t tx = x0 + (uint32_t)rem, ty = y0 + q;
-        keys[s] = ty * (uint32_t)gx + tx;
+        keys[s] = (K)(ty * (uint32_t)gx + tx);
         uint32_t v = sIdx[wave][o];
         if (marks) {
             // live = inside the cut-down rect and, with a mask, one of its set tiles (index j inside that rect: below the
@@ -420,8 +422,9 @@ sgr_duplicate_kernel(int P, SgrGeomView gv, const uint32_t* __restrict__ order, 
 }
 
 // ---- K9: tile ranges from the sorted tile keys (rasterizer_impl.cu:116-138) -------------------
+template <typename K>
 __global__ void __launch_bounds__(256)
-sgr_tile_ranges_kernel(int L, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges, uint8_t* __restrict__ touched,
+sgr_tile_ranges_kernel(int L, const K* __restrict__ keys, uint2* __restrict__ ranges, uint8_t* __restrict__ touched,
                        uint32_t T) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= L) return;
@@ -503,8 +506,9 @@ void sgr_launch_tile_order(const uint2* ranges, int T, int force, hipStream_t s)
 }
 
 // parity introspection: the reference's 64-bit sorted keys, recomposed from tile id and depth bits
+template <typename K>
 __global__ void __launch_bounds__(256)
-sgr_compose_keys_kernel(int L, const uint32_t* __restrict__ tile_keys, const uint32_t* __restrict__ point_list,
+sgr_compose_keys_kernel(int L, const K* __restrict__ tile_keys, const uint32_t* __restrict__ point_list,
                         const float4* __restrict__ rec, uint64_t* __restrict__ out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= L) return;
@@ -539,21 +543,25 @@ void sgr_launch_filter(int P, const float* means3D, const float* scales, const f
 }
 
 // bsum / sub: what sgr_launch_scan_head left for the two count sequences (aux_sorted in depth order, aux in index order)
+// key16: the tile keys are uint16_t (sgr_api.hip: tile_key16) -- `keys` points at the same buffer either way
 void sgr_launch_duplicate(int P, const SgrGeomView& gv, const uint32_t* order, const uint32_t* bsum, const uint32_t* sub,
-                          uint32_t* keys, uint32_t* vals, int gx, uint32_t cap, int marks, hipStream_t s) {
+                          void* keys, int key16, uint32_t* vals, int gx, uint32_t cap, int marks, hipStream_t s) {
     if (P <= 0) return;
     const uint32_t nb = (uint32_t)(((size_t)P + SGR_SCAN_ITEMS - 1) / SGR_SCAN_ITEMS);
-    sgr_duplicate_kernel<<<(P + SGR_PRE_THREADS - 1) / SGR_PRE_THREADS, SGR_PRE_THREADS, 0, s>>>(P, gv, order, bsum, sub, nb, keys,
-                                                                                             vals, gx, cap, marks);
+    const unsigned grid = (P + SGR_PRE_THREADS - 1) / SGR_PRE_THREADS;
+    if (key16) sgr_duplicate_kernel<uint16_t><<<grid, SGR_PRE_THREADS, 0, s>>>(P, gv, order, bsum, sub, nb, (uint16_t*)keys, vals, gx, cap, marks);
+    else sgr_duplicate_kernel<uint32_t><<<grid, SGR_PRE_THREADS, 0, s>>>(P, gv, order, bsum, sub, nb, (uint32_t*)keys, vals, gx, cap, marks);
 }
 
-void sgr_launch_tile_ranges(int L, const uint32_t* keys, uint2* ranges, uint8_t* touched, uint32_t T, hipStream_t s) {
+void sgr_launch_tile_ranges(int L, const void* keys, int key16, uint2* ranges, uint8_t* touched, uint32_t T, hipStream_t s) {
     if (L <= 0) return;
-    sgr_tile_ranges_kernel<<<(L + 255) / 256, 256, 0, s>>>(L, keys, ranges, touched, T);
+    if (key16) sgr_tile_ranges_kernel<uint16_t><<<(L + 255) / 256, 256, 0, s>>>(L, (const uint16_t*)keys, ranges, touched, T);
+    else sgr_tile_ranges_kernel<uint32_t><<<(L + 255) / 256, 256, 0, s>>>(L, (const uint32_t*)keys, ranges, touched, T);
 }
 
-void sgr_launch_compose_keys(int L, const uint32_t* tile_keys, const uint32_t* point_list, const float4* rec, uint64_t* out,
+void sgr_launch_compose_keys(int L, const void* tile_keys, int key16, const uint32_t* point_list, const float4* rec, uint64_t* out,
                              hipStream_t s) {
     if (L <= 0) return;
-    sgr_compose_keys_kernel<<<(L + 255) / 256, 256, 0, s>>>(L, tile_keys, point_list, rec, out);
+    if (key16) sgr_compose_keys_kernel<uint16_t><<<(L + 255) / 256, 256, 0, s>>>(L, (const uint16_t*)tile_keys, point_list, rec, out);
+    else sgr_compose_keys_kernel<uint32_t><<<(L + 255) / 256, 256, 0, s>>>(L, (const uint32_t*)tile_keys, point_list, rec, out);
 }

@@ -530,7 +530,7 @@ static int sort_pairs_impl(K* const keys[2], uint32_t* const vals[2], uint32_t n
 #endif
     const int bits = sizeof(K) == 8 ? 8 : sort_pass_bits(end_bit, max_bits);
     const int ipt = sizeof(K) == 8 ? 8 : sort_ipt(n);
-    if (sizeof(K) == 4) npass = sort_passes(end_bit, max_bits);
+    if (sizeof(K) <= 4) npass = sort_passes(end_bit, max_bits);
     for (int p = 0; p < npass; p++) {
         const uint32_t* vin = (iota && p == 0) ? nullptr : vals[cur];
         const bool last = p == npass - 1;
@@ -557,4 +557,9 @@ int sgr_launch_sort_pairs(uint64_t* const keys[2], uint32_t* const vals[2], uint
 int sgr_launch_sort_pairs32(uint32_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
                             uint32_t* scan_tmp, hipStream_t s, bool iota, const uint2* aux_in, uint2* aux_out, int max_bits, int aux16) {
     return sort_pairs_impl<uint32_t>(keys, vals, n, end_bit, hist, scan_tmp, s, iota, aux_in, aux_out, max_bits, aux16);
+}
+// 16-bit keys (the forward's tile sort when the frame has fewer than 65535 tiles): the same kernels on half the key bytes
+int sgr_launch_sort_pairs16(uint16_t* const keys[2], uint32_t* const vals[2], uint32_t n, int end_bit, uint32_t* hist,
+                            uint32_t* scan_tmp, hipStream_t s) {
+    return sort_pairs_impl<uint16_t>(keys, vals, n, end_bit > 16 ? 16 : end_bit, hist, scan_tmp, s);
 }
