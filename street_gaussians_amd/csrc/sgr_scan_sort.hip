@@ -469,16 +469,18 @@ static inline int sort_pass_bits(int end_bit, int max_bits) {
     const int npass = sort_passes(end_bit, max_bits);
     return npass ? (end_bit + npass - 1) / npass : 8;
 }
-// Keys per thread: large inputs use 4096-key blocks (longer store runs); small ones keep 2048 so that the launch
-// still has a few hundred workgroups.
-static inline int sort_ipt(uint32_t n) {
+// Keys per thread = block size (256 * IPT keys): a larger block gives every digit a longer store run (32 instead of 16 pairs at
+// 7-bit digits) at the price of occupancy (registers, LDS).  Measured on MI355X, interleaved (profiles/r6/ab_sort_ipt_*.jsonl):
+//   16-bit keys (the forward's tile sort; 2 KB less LDS and shorter key runs than 32-bit keys): 4096-key blocks win at every
+//     size -- 0.103 -> 0.090 ms at 7.8 M pairs, 0.500 -> 0.403 ms at 39 M;
+//   32-bit keys (the depth pre-sort of the Gaussians): 2048-key blocks at 1 M (0.096 vs 0.108 ms, sort + scan), 4096-key blocks
+//     at 5 M (0.371 vs 0.353 ms); rounds 4 / 5 had measured the 32-bit tile sort the same way (40.7 / 221.6 vs 42.3 / 242.9 us
+//     per pass at 7.8 / 38.9 M pairs) and kept 2048.
+static inline int sort_ipt(uint32_t n, size_t key_bytes) {
     static const int forced = [] { const char* e = getenv("SGR_SORT_IPT"); return e ? atoi(e) : 0; }();  // A/B only
     if (forced == 8 || forced == 16) return forced;
-    // measured on MI355X (rocprofv3, tile sort of 7.8 M / 38.9 M pairs, 7-bit digits): 2048-key blocks 40.7 / 221.6 us per
-    // pass, 4096-key blocks 42.3 / 242.9 us -- the longer store runs of the larger block do not pay for its occupancy
-    // (115 vs 67 VGPRs, 38 vs 19 KB of LDS); the 16-key template stays for the A/B
-    (void)n;
-    return 8;
+    if (key_bytes == 2) return n >= 500000u ? 16 : 8;
+    return n >= 3000000u ? 16 : 8;
 }
 
 int sgr_sort_pass_count(int end_bit) { return (end_bit + 7) / 8; }  // buffer flips of a sort with the default 8-bit cap
@@ -529,7 +531,7 @@ static int sort_pairs_impl(K* const keys[2], uint32_t* const vals[2], uint32_t n
     }
 #endif
     const int bits = sizeof(K) == 8 ? 8 : sort_pass_bits(end_bit, max_bits);
-    const int ipt = sizeof(K) == 8 ? 8 : sort_ipt(n);
+    const int ipt = sizeof(K) == 8 ? 8 : sort_ipt(n, sizeof(K));
     if (sizeof(K) <= 4) npass = sort_passes(end_bit, max_bits);
     for (int p = 0; p < npass; p++) {
         const uint32_t* vin = (iota && p == 0) ? nullptr : vals[cur];
