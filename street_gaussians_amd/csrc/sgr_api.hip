@@ -252,6 +252,11 @@ static bool hit_list_on() {
 // the lazy mode): the tile sort moves 6 instead of 8 bytes per pair and pass and its histogram reads half.  Bit 18 (SGR_KEY32=1)
 // keeps 32-bit keys (A/B; frames with more tiles -- beyond 4096 x 4080 pixels -- take them anyway).  Same buffers either way.
 static int tile_key16(size_t T) { return (T < 65535u && !(switches() & 262144)) ? 1 : 0; }
+// depth pre-sort: three passes of 9-bit digits below this many Gaussians, four of 7 bits from it on (sgr_scan_sort.hip)
+static int depth9_max_p() {
+    static const int v = [] { const char* e = getenv("SGR_DEPTH9_MAX_P"); return e ? atoi(e) : 750000; }();
+    return v;
+}
 static int pre_stage_min_p() {
     static const int v = [] { const char* e = getenv("SGR_PRE_STAGE_MIN_P"); return e ? atoi(e) : 3000000; }();
     return v;
@@ -500,7 +505,7 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
         t_lazy.cap = 0x7fffffffu;  // (set below; until then "no overflow")
         prof_begin(1, stream);
         const int dcur = sgr_launch_sort_pairs32(gv.dkeys, gv.dvals, (uint32_t)P, wide_depth ? 32 : SGR_DEPTH_KEY_BITS, gv.dhist,
-                                                 gv.scan_tmp, stream, true, aux_emit, gv.aux_sorted, P < 750000 ? 9 : 8, aux16);
+                                                 gv.scan_tmp, stream, true, aux_emit, gv.aux_sorted, P < depth9_max_p() ? 9 : 8, aux16);
         order = gv.dvals[dcur];
         sgr_launch_scan_head(reinterpret_cast<const uint32_t*>(gv.aux_sorted), reinterpret_cast<const uint32_t*>(gv.aux), (size_t)P,
                              aux16 ? 4 : 2, gv.scan_tmp, gv.sub_sums, stream, 2);
@@ -573,7 +578,7 @@ int sgr_forward(sgr_alloc_fn geometry_buffer, void* geometry_user, sgr_alloc_fn 
                                  aux16 ? 4 : 2, gv.scan_tmp, gv.sub_sums, stream, 2);
         } else {
         const int dcur = sgr_launch_sort_pairs32(gv.dkeys, gv.dvals, (uint32_t)P, wide_depth ? 32 : SGR_DEPTH_KEY_BITS, gv.dhist,
-                                                 gv.scan_tmp, stream, true, aux_emit, gv.aux_sorted, P < 750000 ? 9 : 8, aux16);
+                                                 gv.scan_tmp, stream, true, aux_emit, gv.aux_sorted, P < depth9_max_p() ? 9 : 8, aux16);
         order = gv.dvals[dcur];
         // (second sequence of the same launches: the exclusive scan in index order = every Gaussian's first partial-gradient
         // row of the backward, SgrGeomView::u0)

@@ -422,27 +422,48 @@ sgr_duplicate_kernel(int P, SgrGeomView gv, const uint32_t* __restrict__ order, 
 }
 
 // ---- K9: tile ranges from the sorted tile keys (rasterizer_impl.cu:116-138) -------------------
+// Eight consecutive entries per thread: one 16- / 32-byte load of the keys (+ the key in front of them), one 8-byte store of
+// row flags -- the launch is a stream of 6 (10) bytes per entry, and one entry per thread left it latency-bound (1.7 TB/s).
+#define SGR_RANGES_PER_THREAD 8
 template <typename K>
 __global__ void __launch_bounds__(256)
 sgr_tile_ranges_kernel(int L, const K* __restrict__ keys, uint2* __restrict__ ranges, uint8_t* __restrict__ touched,
                        uint32_t T) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= L) return;
-    // one byte per partial-gradient row of the backward ("row written"), cleared here instead of by a memset dispatch
-    // in front of the backward's dominant kernel (the index spaces coincide: one row per instance)
-    touched[idx] = 0;
-    // keys >= T: the padding behind the frame's instances when the list has a fixed capacity (sgr_duplicate_kernel, cap)
-    const uint32_t currtile = keys[idx];
-    if (idx == 0) {
-        if (currtile < T) ranges[currtile].x = 0;
+    constexpr int E = SGR_RANGES_PER_THREAD;
+    const int i0 = (blockIdx.x * 256 + threadIdx.x) * E;
+    if (i0 >= L) return;
+    K k[E];
+    if (i0 + E <= L) {  // (the key / flag arrays start 256-byte aligned and i0 is a multiple of 8)
+        struct alignas(sizeof(K) * E) Pack { K v[E]; };
+        const Pack p = *reinterpret_cast<const Pack*>(keys + i0);
+#pragma unroll
+        for (int e = 0; e < E; e++) k[e] = p.v[e];
+        // one byte per partial-gradient row of the backward ("row written"), cleared here instead of by a memset dispatch
+        // in front of the backward's dominant kernel (the index spaces coincide: one row per instance)
+        *reinterpret_cast<uint2*>(touched + i0) = make_uint2(0u, 0u);
     } else {
-        const uint32_t prevtile = keys[idx - 1];
-        if (currtile != prevtile) {
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            k[e] = i0 + e < L ? keys[i0 + e] : (K)0;
+            if (i0 + e < L) touched[i0 + e] = 0;
+        }
+    }
+    // keys >= T: the padding behind the frame's instances when the list has a fixed capacity (sgr_duplicate_kernel, cap)
+    uint32_t prevtile = i0 > 0 ? (uint32_t)keys[i0 - 1] : 0u;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int idx = i0 + e;
+        if (idx >= L) break;
+        const uint32_t currtile = k[e];
+        if (idx == 0) {
+            if (currtile < T) ranges[currtile].x = 0;
+        } else if (currtile != prevtile) {
             if (prevtile < T) ranges[prevtile].y = idx;
             if (currtile < T) ranges[currtile].x = idx;
         }
+        if (idx == L - 1 && currtile < T) ranges[currtile].y = L;
+        prevtile = currtile;
     }
-    if (idx == L - 1 && currtile < T) ranges[currtile].y = L;
 }
 
 // ---- tile order of the blend launches (sgr_wg_tile): decides per frame whether the lists are unequal enough for a
@@ -555,8 +576,9 @@ void sgr_launch_duplicate(int P, const SgrGeomView& gv, const uint32_t* order, c
 
 void sgr_launch_tile_ranges(int L, const void* keys, int key16, uint2* ranges, uint8_t* touched, uint32_t T, hipStream_t s) {
     if (L <= 0) return;
-    if (key16) sgr_tile_ranges_kernel<uint16_t><<<(L + 255) / 256, 256, 0, s>>>(L, (const uint16_t*)keys, ranges, touched, T);
-    else sgr_tile_ranges_kernel<uint32_t><<<(L + 255) / 256, 256, 0, s>>>(L, (const uint32_t*)keys, ranges, touched, T);
+    const unsigned grid = (unsigned)((L + 256 * SGR_RANGES_PER_THREAD - 1) / (256 * SGR_RANGES_PER_THREAD));
+    if (key16) sgr_tile_ranges_kernel<uint16_t><<<grid, 256, 0, s>>>(L, (const uint16_t*)keys, ranges, touched, T);
+    else sgr_tile_ranges_kernel<uint32_t><<<grid, 256, 0, s>>>(L, (const uint32_t*)keys, ranges, touched, T);
 }
 
 void sgr_launch_compose_keys(int L, const void* tile_keys, int key16, const uint32_t* point_list, const float4* rec, uint64_t* out,
