@@ -141,10 +141,23 @@ sgr_sort_hist_kernel(const K* __restrict__ keys, uint32_t n, int shift, uint32_t
     __syncthreads();
     const int wave = threadIdx.x >> 6;
     const uint32_t base = blockIdx.x * (256u * IPT);
+    // (a histogram does not care which thread counts which key: 16 bytes of consecutive keys per load -- a wave instruction
+    // then moves 1 KB instead of the 128 / 256 bytes of 64 two- / four-byte loads; the key buffers are 256-byte aligned)
+    constexpr int V = 16 / (int)sizeof(K);  // keys per 16-byte load
+    static_assert(IPT % V == 0, "keys per thread must be a multiple of the vector width");
+    struct alignas(16) Vec { K k[V]; };
 #pragma unroll
-    for (int s = 0; s < IPT; s++) {
-        const uint32_t i = base + s * 256 + threadIdx.x;
-        if (i < n) atomicAdd(&h[wave][(uint32_t)(keys[i] >> shift) & mask], 1u);
+    for (int s = 0; s < IPT / V; s++) {
+        const uint32_t i = base + (s * 256 + threadIdx.x) * V;
+        if (i + V <= n) {
+            const Vec v = *reinterpret_cast<const Vec*>(keys + i);
+#pragma unroll
+            for (int e = 0; e < V; e++) atomicAdd(&h[wave][(uint32_t)(v.k[e] >> shift) & mask], 1u);
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; e++)
+                if (i + e < n) atomicAdd(&h[wave][(uint32_t)(keys[i + e] >> shift) & mask], 1u);
+        }
     }
     __syncthreads();
     for (uint32_t d = threadIdx.x; d <= mask; d += 256)
