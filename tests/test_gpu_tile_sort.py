@@ -128,3 +128,21 @@ def test_longest_first_tile_order_changes_nothing(mode):
     rg = a["i_ranges"].reshape(-1, 2).astype(np.int64)
     n = rg[:, 1] - rg[:, 0]
     assert (n == 0).sum() > 10 and n.max() > 4 * n.mean()  # empty sky tiles and tiles several times the mean
+
+
+@pytest.mark.parametrize("mode", ["default", "strict"])
+def test_32_bit_tile_keys_give_the_same_lists_as_the_16_bit_default(mode):
+    """The instance list's tile keys are 16-bit whenever the frame has fewer than 65535 tiles (the tile sort then moves 6
+    instead of 8 bytes per pair and pass); switch bit 18 keeps the 32-bit keys that larger frames take anyway.  Same keys,
+    lists, ranges, images and gradients bit for bit -- also through the per-tile sort form, whose scratch shares the key
+    buffers."""
+    cam, sc, S = _scene("mid")
+    kw = oracle_kwargs(cam, sc, bg=torch.tensor([0.2, 0.1, 0.4]))
+    wts = syn.loss_weights(cam, S=S)
+    base = (_C.EXACT | _C.REF_RECT) if mode == "strict" else 0
+    a = _run(kw, wts, base)
+    b = _run(kw, wts, base | _C.KEY32)
+    _same(a, b, "key32/" + mode)
+    c = _run(kw, wts, base | _C.KEY32 | _C.TILE_SORT)
+    _same(a, c, "key32+tile_sort/" + mode)
+    assert int(a["i_keys"].max() >> 32) < 65535  # the frame is one the default sorts on 16-bit keys
