@@ -43,7 +43,7 @@ typedef float sgr_f2 __attribute__((ext_vector_type(2)));
 // Gaussians) and 2.14 -> 1.99 ms (2 M + 19 channels); 6 waves at 20 channels spills into the walk (2.07 ms).  1-8
 // channels are LDS-limited at 128-entry rounds (64-entry rounds measured 5 % slower there).
 #ifndef SGR_BWD_WAVES
-#define SGR_BWD_WAVES(SMAX) ((SMAX) >= 12 && (SMAX) <= 16 ? 6 : ((SMAX) >= 20 && (SMAX) <= 24 ? 5 : 1))
+#define SGR_BWD_WAVES(SMAX) ((SMAX) >= 12 && (SMAX) <= 16 ? 6 : ((SMAX) >= 20 && (SMAX) <= 24 ? 5 : ((SMAX) > 24 ? 4 : 1)))
 #endif
 template <int SMAX>
 struct SgrBwdBatch { static constexpr int value = SMAX <= 8 ? SGR_BWD_BATCH : SGR_BWD_BATCH_WIDE; };

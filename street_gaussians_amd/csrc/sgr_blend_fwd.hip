@@ -33,9 +33,11 @@ __device__ __forceinline__ float sgr_sel_mask(uint64_t m, float a, float b) {
 // Register budget (tools/occupancy_audit.py).  Left alone the allocator lands a few registers past an occupancy step
 // in most instantiations -- S = 0: 65 VGPRs (the allocation granule is 8, so that is 72 and 7 waves / SIMD instead of
 // 8), 1-4 channels 71 (7 instead of 8), 5-8: 89 (5 instead of 6), 9-12: 101 (4 instead of 5), 21-24: 138 (3 instead of
-// 4) -- and fits the step without a spill when asked to.  13-20 and 25-32 channels are limited by LDS, not registers.
+// 4) -- and fits the step without a spill when asked to; 17-20 channels: 136 (3 instead of the 4 workgroups the LDS allows: capped
+// in round 6, forward 1.15 -> 0.98 ms at 2 M Gaussians + 19 channels, profiles/r6/ab_fwd20_waves.jsonl), 25-32: 172 (2 instead
+// of 3).  13-16 channels are limited by LDS, not registers.
 #ifndef SGR_FWD_WAVES
-#define SGR_FWD_WAVES(SMAX) ((SMAX) <= 4 ? 8 : (SMAX) == 8 ? 6 : (SMAX) == 12 ? 5 : (SMAX) == 24 ? 4 : 1)
+#define SGR_FWD_WAVES(SMAX) ((SMAX) <= 4 ? 8 : (SMAX) == 8 ? 6 : (SMAX) == 12 ? 5 : ((SMAX) == 20 || (SMAX) == 24) ? 4 : (SMAX) == 32 ? 3 : 1)
 #endif
 template <int SMAX, bool CULL, bool EXACT>
 __global__ void __launch_bounds__(SGR_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(SGR_FWD_WAVES(SMAX))))
