@@ -130,14 +130,16 @@ void replay_lane_hist(int W, int H, const uint32_t* ranges, const uint32_t* plis
 // pixels (shape 0: 4x4, shape 1: 8x2 strips) and walks only the instances that hit ITS block.  Rounds of `round_n` entries of
 // the tile's list that have at least one hit (the compact hit list).  out[0] = quadrant visits (today's walk: one step each),
 // out[1] = block visits, out[2] = steps of the row walk (per round and wave: the busiest row's visits),
-// out[3] = sum over rounds of the busiest WAVE's steps x 4 today, out[4] = the same for the row walk (barrier skew included).
+// out[3] = sum over rounds of the busiest WAVE's steps x 4 today, out[4] = the same for the row walk (barrier skew included),
+// out[5] = list entries with at least one hit (the compact hit list's length), out[6] = rounds whose quadrant visits exceed
+// 2 * round_n (the visit rows a round of the shipped kernel has).
 void replay_row_walk(int W, int H, const uint32_t* ranges, const uint32_t* plist, const float* m2d, const float* co,
                      const uint32_t* ncontrib, int shape, int round_n, double* out) {
   int gx = (W + 15) / 16, gy = (H + 15) / 16;
-  double acc[5] = {0};
+  double acc[7] = {0};
 #pragma omp parallel
   {
-    double a[5] = {0};
+    double a[7] = {0};
 #pragma omp for schedule(dynamic, 8)
     for (int t = 0; t < gx * gy; ++t) {
       uint32_t r0 = ranges[2 * t], r1 = ranges[2 * t + 1];
@@ -182,6 +184,8 @@ void replay_row_walk(int W, int H, const uint32_t* ranges, const uint32_t* plist
         }
         if ((in_round == round_n || flush) && in_round > 0) {
           int mx_vis = 0, mx_steps = 0;
+          a[5] += in_round;
+          if (vis_w[0] + vis_w[1] + vis_w[2] + vis_w[3] > 2 * round_n) a[6] += 1;
           for (int q = 0; q < 4; ++q) {
             int st = 0;
             for (int r = 0; r < 4; ++r) { a[1] += row_w[q][r]; if (row_w[q][r] > st) st = row_w[q][r]; }
@@ -199,7 +203,7 @@ void replay_row_walk(int W, int H, const uint32_t* ranges, const uint32_t* plist
       }
     }
 #pragma omp critical
-    for (int i = 0; i < 5; ++i) acc[i] += a[i];
+    for (int i = 0; i < 7; ++i) acc[i] += a[i];
   }
-  for (int i = 0; i < 5; ++i) out[i] = acc[i];
+  for (int i = 0; i < 7; ++i) out[i] = acc[i];
 }

@@ -24,7 +24,7 @@ L=C.CDLL("/tmp/replay_visits.so"); p=lambda a:a.ctypes.data_as(C.c_void_p)
 arrs=[np.ascontiguousarray(x) for x in (fw.ranges.astype(np.uint32), fw.point_list.astype(np.uint32), fw.means2D.astype(np.float32), fw.conic_opacity.astype(np.float32), fw.n_contrib.astype(np.uint32))]
 for shape in (0,1):
     for rn in (64,128,256,100000):
-        o=np.zeros(5)
+        o=np.zeros(7)
         t0=time.time()
         L.replay_row_walk(1920,1280,*[p(a) for a in arrs],shape,rn,p(o))
-        print("shape",shape,"round",rn,"visits %.3gM blockvisits %.3gM steps %.3gM  skewed: today %.3gM  rowwalk %.3gM"%tuple(o/1e6), "t", round(time.time()-t0,1))
+        print("shape",shape,"round",rn,"visits %.3gM blockvisits %.3gM steps %.3gM  skewed: today %.3gM  rowwalk %.3gM  hit entries %.3gM  rounds over the row cap %.4gM"%tuple(o/1e6), "t", round(time.time()-t0,1))
