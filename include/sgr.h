@@ -237,7 +237,8 @@ int sgr_export_internal(int which, int P, int R, int width, int height, char* ge
  * somewhere (exports 19 / 20) and the blend backward walks that list instead of the list positions (the marked-dead 40 % and
  * the instances behind saturated pixels are never staged); same gradients bit for bit.  bit 16 (SGR_NO_HLIST=1) never (the
  * round-5 walk, A/B), bit 17 (SGR_HLIST_ALWAYS=1) in every mode (with the cut-down rects it costs the forward more than it
- * saves the backward).  Set before a forward; its backward must see the same value.
+ * saves the backward).  Read when the forward runs and recorded in the frame's buffers: the backward walks the list if its
+ * frame has one (bit 16 at backward time forces the positional walk, which every frame supports).
  * bit 18 (SGR_KEY32=1) the instance list's tile keys stay 32-bit (default: 16-bit whenever the frame has fewer than 65535
  * tiles -- the tile sort then moves 6 instead of 8 bytes per pair and pass; same lists, A/B).
  * bit 12 (SGR_TILE_SORT=1) the binning chain runs in its per-tile form (csrc/sgr_tile_sort.hip: no depth pre-sort of the

@@ -39,7 +39,7 @@ void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, bool v2, bool exact, in
                           int H, int S, const float* bg, const float4* rec, const uint32_t* u0, const uint64_t* tmask, const float* semantics, const float* alphas,
                           const uint32_t* n_contrib, const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth,
                           const float* dL_dalpha, const float* dL_dsem, float* partials, uint8_t* touched, uint32_t row_limit,
-                          const uint32_t* hlist, const uint32_t* n_contrib_k, hipStream_t s);
+                          const uint32_t* hlist, const uint32_t* n_contrib_k, const uint32_t* hl_flag, hipStream_t s);
 int sgr_launch_gauss_bwd(int P, int D, int M, int S, const float* means3D, const int* radii, const float* shs,
                           const float* scales, const float* rotations, const float* cov3D_precomp, const SgrCam* cam,
                           const SgrGeomView& gv, const float* partials, int row_stride, const uint8_t* touched,
@@ -287,7 +287,9 @@ sgr_pack_camera_kernel(SgrCam* cam, const float* view, const float* proj, const 
     for (int i = blockIdx.x * 256 + t; i < T; i += gridDim.x * 256) ranges[i] = make_uint2(0u, 0u);
     if (blockIdx.x != 0) return;
     if (t < 16) {
-        header[t] = t == 6 ? rect_mode : 0u;
+        // word 6: the frame's tile-rect mode; word 7: whether its forward writes the compact hit list (the blend backward
+        // follows the FRAME's flag, whatever the switches say by the time it runs)
+        header[t] = t == 6 ? (rect_mode & 0xffu) : (t == 7 ? (rect_mode >> 8) : 0u);
         cam->view[t] = view[t];
         cam->proj[t] = proj ? proj[t] : 0.f;
     }
@@ -313,7 +315,8 @@ static void pack_camera(const SgrGeomView& gv, const float* view, const float* p
     const int gx = (W + SGR_BLOCK_X - 1) / SGR_BLOCK_X, gy = (H + SGR_BLOCK_Y - 1) / SGR_BLOCK_Y;
     const int nb = std::max(1, std::min(64, (T + 255) / 256));
     sgr_pack_camera_kernel<<<nb, 256, 0, s>>>(cam_slot(gv), view, proj, campos, tan_fovx, tan_fovy, focal_x, focal_y, W, H,
-                                             gx, gy, scale_modifier, gv.header, ranges, T, (uint32_t)rect_mode);
+                                             gx, gy, scale_modifier, gv.header, ranges, T,
+                                             (uint32_t)rect_mode | (hit_list_on() ? 0x100u : 0u));
 }
 
 // ---- the forward without a host wait (sgr_set_lazy) ---------------------------------------------------------------
@@ -822,7 +825,8 @@ int sgr_backward_ex(int P, int D, int M, int R, int S, const float* background, 
 #endif
             sgr_launch_blend_bwd(cull, dpp, det, (sw & 16) != 0, (sw & 128) != 0, gx, (sw & 32768) ? gy : -gy, iv.ranges, bv.vals[cur], W, H, S, background, gv.rec, gv.u0, gv.tmask, semantics,
                                  alphas, iv.n_contrib, hits, dL_dpix, dL_dpix_depth, dL_dalphas, dL_dpix_semantic, partials,
-                                 touched, (uint32_t)R, hit_list_on() ? bv.hlist : nullptr, iv.n_contrib_k, stream);
+                                 touched, (uint32_t)R, (SGR_HLIST && !(sw & 65536)) ? bv.hlist : nullptr, iv.n_contrib_k,
+                                 gv.header + 7, stream);
         SGR_STAGE("blend_bwd");
         prof_end(stream);
     }

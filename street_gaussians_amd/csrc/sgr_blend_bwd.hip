@@ -200,7 +200,7 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
                      const float* __restrict__ dL_dpixels, const float* __restrict__ dL_dpixel_depths,
                      const float* __restrict__ dL_dalphas, const float* __restrict__ dL_dpixel_semantics,
                      float* __restrict__ partials, int row_stride, uint8_t* __restrict__ touched, uint32_t row_limit,
-                     const uint32_t* __restrict__ hlist, const uint32_t* __restrict__ n_contrib_k) {
+                     const uint32_t* __restrict__ hlist, const uint32_t* __restrict__ n_contrib_k, const uint32_t* __restrict__ hl_flag) {
     // Every fused multiply-add below is written out (fmaf / __builtin_elementwise_fma): with contraction left to the
     // optimiser, the CULL / !CULL and DPP / shuffle instantiations of this body can fuse differently and the "culling
     // is invisible, bit for bit" property (tests) would depend on code-generation luck.
@@ -261,7 +261,9 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
     // instances that all have work: in the strict mode 40 % of a tile's list is marked dead, in every mode the instances
     // behind saturated pixels and the cull's margin have no hit, so a tile takes fewer rounds (barriers, staging).
     // Without a hit record (A/B switch bit 3) or without the list (bit 16) the walk is positional as before.
-    const bool HL = SGR_HLIST && CULL && hit4 != nullptr && hlist != nullptr;
+    // (hl_flag: word 7 of the geometry header -- whether THIS frame's forward wrote the list: a backward under other switches
+    // than its forward then falls back to the positional walk instead of gathering through a list that is not there)
+    const bool HL = SGR_HLIST && CULL && hit4 != nullptr && hlist != nullptr && hl_flag[0] != 0u;
     const int lastc = inside ? (int)(HL ? n_contrib_k : n_contrib)[pix_id] : 0;
     float dLdC0 = 0.f, dLdC1 = 0.f, dLdC2 = 0.f, dLdD = 0.f, dLdA = 0.f;
     float dLdS[NS];
@@ -815,10 +817,10 @@ sgr_blend_bwd_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
         const float *__restrict__ dL_dalphas,                                                                              \
         const float *__restrict__ dL_dpixel_semantics, float *__restrict__ partials, int row_stride,                      \
         uint8_t *__restrict__ touched, uint32_t row_limit, const uint32_t *__restrict__ hlist,  \
-        const uint32_t *__restrict__ n_contrib_k
+        const uint32_t *__restrict__ n_contrib_k, const uint32_t *__restrict__ hl_flag
 #define SGR_BWD_PASS                                                                                                  \
     ranges, point_list, W, H, S, gx, gy, bg_color, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpixels,               \
-        dL_dpixel_depths, dL_dalphas, dL_dpixel_semantics, partials, row_stride, touched, row_limit, hlist, n_contrib_k
+        dL_dpixel_depths, dL_dalphas, dL_dpixel_semantics, partials, row_stride, touched, row_limit, hlist, n_contrib_k, hl_flag
 template <int SMAX, bool CULL, bool DPP, bool DET>
 __global__ void __launch_bounds__(SGR_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(SGR_BWD_WAVES(SMAX))))
 sgr_blend_bwd_kernel(SGR_BWD_ARGS) {
@@ -1116,12 +1118,12 @@ static void launch_bwd(bool cull, bool dpp, bool det, bool v2, bool exact, unsig
                        const float* alphas,
                        const uint32_t* n_contrib, const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth,
                        const float* dL_dalpha, const float* dL_dsem, float* partials, int row_stride, uint8_t* touched, uint32_t row_limit,
-                       const uint32_t* hlist, const uint32_t* n_contrib_k) {
+                       const uint32_t* hlist, const uint32_t* n_contrib_k, const uint32_t* hl_flag) {
     constexpr bool kDet = true;  // every instantiation has the two-row deterministic combine (see SgrBwdBatch)
     if (exact) {
         sgr_blend_bwd_kernel_exact<SMAX><<<tiles, SGR_TILE_THREADS, 0, s>>>(
             ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth, dL_dalpha,
-            dL_dsem, partials, row_stride, touched, row_limit, hlist, n_contrib_k);
+            dL_dsem, partials, row_stride, touched, row_limit, hlist, n_contrib_k, hl_flag);
         return;
     }
 #if SGR_WITH_VARIANTS
@@ -1129,7 +1131,7 @@ static void launch_bwd(bool cull, bool dpp, bool det, bool v2, bool exact, unsig
         if (v2 && dpp) {  // transposed accumulation (S = 0)
 #define SGR_V2(C, D) sgr_blend_bwd_kernel_v2<C, D><<<tiles, SGR_TILE_THREADS, 0, s>>>(                                    \
             ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,         \
-            dL_dalpha, dL_dsem, partials, row_stride, touched, row_limit, hlist, n_contrib_k)
+            dL_dalpha, dL_dsem, partials, row_stride, touched, row_limit, hlist, n_contrib_k, hl_flag)
             if (cull) { if (det) SGR_V2(true, true); else SGR_V2(true, false); }
             else { if (det) SGR_V2(false, true); else SGR_V2(false, false); }
 #undef SGR_V2
@@ -1146,19 +1148,19 @@ static void launch_bwd(bool cull, bool dpp, bool det, bool v2, bool exact, unsig
             if (det)                                                                                                 \
                 sgr_blend_bwd_kernel_s0<C, D, true><<<tiles, SGR_TILE_THREADS, 0, s>>>(                               \
                     ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,    \
-                    dL_dalpha, dL_dsem, partials, row_stride, touched, row_limit, hlist, n_contrib_k);                                               \
+                    dL_dalpha, dL_dsem, partials, row_stride, touched, row_limit, hlist, n_contrib_k, hl_flag);                                               \
             else                                                                                                     \
                 sgr_blend_bwd_kernel_s0<C, D, false><<<tiles, SGR_TILE_THREADS, 0, s>>>(                              \
                     ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,    \
-                    dL_dalpha, dL_dsem, partials, row_stride, touched, row_limit, hlist, n_contrib_k);                                               \
+                    dL_dalpha, dL_dsem, partials, row_stride, touched, row_limit, hlist, n_contrib_k, hl_flag);                                               \
         } else if (kDet && det)                                                                                      \
             sgr_blend_bwd_kernel<SMAX, C, D, kDet><<<tiles, SGR_TILE_THREADS, 0, s>>>(                                \
                 ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,        \
-                dL_dalpha, dL_dsem, partials, row_stride, touched, row_limit, hlist, n_contrib_k);                                                   \
+                dL_dalpha, dL_dsem, partials, row_stride, touched, row_limit, hlist, n_contrib_k, hl_flag);                                                   \
         else                                                                                                         \
             sgr_blend_bwd_kernel<SMAX, C, D, false><<<tiles, SGR_TILE_THREADS, 0, s>>>(                               \
                 ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, n_contrib, hit4, dL_dpix, dL_ddepth,        \
-                dL_dalpha, dL_dsem, partials, row_stride, touched, row_limit, hlist, n_contrib_k);                                                   \
+                dL_dalpha, dL_dsem, partials, row_stride, touched, row_limit, hlist, n_contrib_k, hl_flag);                                                   \
     } while (0)
     if (cull && dpp) SGR_GO(true, true);
     else if constexpr (SMAX <= 4) {
@@ -1181,12 +1183,12 @@ void sgr_launch_blend_bwd(bool cull, bool dpp, bool det, bool v2, bool exact, in
                           int H, int S, const float* bg, const float4* rec, const uint32_t* u0, const uint64_t* tmask, const float* semantics, const float* alphas, const uint32_t* n_contrib,
                           const uint8_t* hit4, const float* dL_dpix, const float* dL_ddepth, const float* dL_dalpha,
                           const float* dL_dsem, float* partials, uint8_t* touched, uint32_t row_limit, const uint32_t* hlist,
-                          const uint32_t* n_contrib_k, hipStream_t s) {
+                          const uint32_t* n_contrib_k, const uint32_t* hl_flag, hipStream_t s) {
     if (gx <= 0 || gy == 0) return;
     const unsigned tiles = sgr_xcd_grid_blocks(gx, gy < 0 ? -gy : gy);  // supertile-ordered grid incl. padding blocks
     const int stride = sgr_partial_row_stride(S);
 #define SGR_BWD(N) launch_bwd<N>(cull, dpp, det, v2, exact, tiles, s, ranges, point_list, W, H, S, gx, gy, bg, rec, u0, tmask, semantics, alphas, \
-                                 n_contrib, hit4, dL_dpix, dL_ddepth, dL_dalpha, dL_dsem, partials, stride, touched, row_limit, hlist, n_contrib_k)
+                                 n_contrib, hit4, dL_dpix, dL_ddepth, dL_dalpha, dL_dsem, partials, stride, touched, row_limit, hlist, n_contrib_k, hl_flag)
     if (S == 0) SGR_BWD(0);
     else if (S <= 4) SGR_BWD(4);
     else if (S <= 8) SGR_BWD(8);

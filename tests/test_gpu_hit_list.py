@@ -102,3 +102,28 @@ def test_compact_walk_is_what_runs_by_default_and_shortens_the_walk():
     cmp_walk = sum(int(nk[y * 16:(y + 1) * 16, x * 16:(x + 1) * 16].max()) for y in range(gy) for x in range(gx))
     assert 0 < cmp_walk < 0.8 * pos_walk, (cmp_walk, pos_walk)
     assert not (_C.test_switches(-1) & _C.NO_HLIST)
+
+
+def test_backward_follows_what_its_frames_forward_did():
+    """Whether a frame has a compact hit list is recorded in its own buffers (word 7 of the geometry header): a backward that
+    runs under other switches than its forward -- list wanted, frame has none; list not wanted, frame has one -- must give
+    the same gradients as the matching pair, not gather through a list that is not there."""
+    cam, sc, S = _scene("mid")
+    kw = oracle_kwargs(cam, sc)
+    wts = syn.loss_weights(cam, S=S)
+    with switches(_C.EXACT):  # cut-down rects: no list by default
+        res, _ = raw_forward(kw)
+        want = {k: npy(v).copy() for k, v in raw_backward(kw, res, wts).items()}
+    with switches(_C.EXACT | _C.HLIST_ALWAYS):  # the backward would like a list; this frame has none
+        got = {k: npy(v).copy() for k, v in raw_backward(kw, res, wts).items()}
+    for k in want:
+        assert np.array_equal(want[k], got[k]), k
+    with switches(_C.EXACT | _C.HLIST_ALWAYS):  # a frame WITH a list ...
+        res2, _ = raw_forward(kw)
+    with switches(_C.EXACT):  # ... walked by a backward that would not have asked for one
+        got2 = {k: npy(v).copy() for k, v in raw_backward(kw, res2, wts).items()}
+    with switches(_C.EXACT | _C.NO_HLIST):  # ... and by one that refuses it
+        got3 = {k: npy(v).copy() for k, v in raw_backward(kw, res2, wts).items()}
+    for k in want:
+        assert np.array_equal(want[k], got2[k]), k
+        assert np.array_equal(want[k], got3[k]), k
